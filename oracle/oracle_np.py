@@ -1,0 +1,364 @@
+"""NumPy CPU restatement of the reference's Gray-code decode + triangulation path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it, and only as the checker / the timed CPU baseline.  The product path
+(``3dscanner-graycode_amd/scanner``) never imports this module and fails loudly when the HIP
+library is missing.
+
+Pinning status
+--------------
+* decode half (a0-a5, a7, a9): **pinned** -- bit-exact against outputs of the reference
+  itself (imported in the build container by ``tests/golden/make_golden.py``), committed
+  as ``tests/golden/*.npz`` and checked by ``tests/test_oracle_golden.py``.
+* law-of-sines half of a8 (``triangulate.py:86-95``): **pinned** the same way (the
+  reference's own ``Triangulate.triangulate`` is run with its two cv2 calls served by
+  :func:`undistort_points` below).
+* ``cv2.undistortPoints`` (OpenCV 4.8.0.76, ``requirements.txt:4``; not vendored, wheel not
+  installed, no reference test holds vectors for it): **parity unpinned**.
+  :func:`undistort_points` restates the published algorithm of
+  ``cvUndistortPointsInternal`` (calib3d/undistort.dispatch.cpp, 4.8): 5 fixed-point
+  iterations, ``icdist < 0`` bail-out, ``R`` applied after, float32 output.
+
+All ``file:line`` citations are relative to ``/root/reference``.
+
+Two flavours are kept on purpose:
+* ``*_loops`` functions do what the reference does per pixel in Python (string join per
+  pixel, nested x/y loops).  They are the reference-cost "port" that ``bench.py`` times.
+* the vectorised twins produce identical arrays fast, so tests can use bigger cases; the
+  test-suite checks loop == vectorised on small inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------- a0/a1
+
+
+def frame_ids(n_frames: int):
+    """Index tables of ``get_direct_indirect`` (scanner/grayCode/decode_codes.py:109-111).
+
+    The reference keeps ``pattern_len`` as a *float* here and truncates through a uint8
+    cast, so N=44 gives hid=[19,17,15,40,38,36] (survey D2/H7).  Indices are relative to
+    ``images[2:]``.
+    """
+    plf = (n_frames - 2) / 4
+    hid = np.array([2 * plf - 2, 2 * plf - 4, 2 * plf - 6,
+                    4 * plf - 2, 4 * plf - 4, 4 * plf - 6], dtype=np.uint8)
+    vid = np.array([1, 3, 5, 2 * plf + 1, 2 * plf + 3, 2 * plf + 5], dtype=np.uint8)
+    return hid, vid
+
+
+def code_len(n_frames: int) -> int:
+    """``int((N-2)/4)`` -- decode_codes.py:149."""
+    return int((n_frames - 2) / 4)
+
+
+def direct_indirect(stack: np.ndarray):
+    """decode_codes.py:90-122.  ``stack`` is [N,H,W]; computed in float64.
+
+    L_max runs over the six ``hid`` frames only, L_min over the six ``vid`` frames only
+    (asymmetric in the reference; reproduced).  0/0 -> NaN, silently.
+    """
+    st = np.asarray(stack, dtype=np.float64)
+    hid, vid = frame_ids(len(st))
+    black, white = st[0], st[1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        b_inv = white / (white + black)                      # :113
+    pat = st[2:]
+    l_max = pat[hid].max(axis=0)                             # :116
+    l_min = pat[vid].min(axis=0)                             # :117
+    l_d = (l_max - l_min) * b_inv                            # :119
+    l_g = 2.0 * (l_max - l_d) * b_inv                        # :120 -> (2*(..))*b_inv
+    return l_d, l_g
+
+
+# ----------------------------------------------------------------------------- a2
+
+
+def is_lit(stack: np.ndarray, l_d: np.ndarray, l_g: np.ndarray, eps=1, m=10):
+    """decode_codes.py:125-186 restated as a rule table, last matching rule wins.
+
+    Rule 0 (``L_d < m -> -1``, :169-170) writes the value the array already holds, so
+    ``m`` has no effect -- kept as an argument for signature parity only.
+    """
+    st = np.asarray(stack, dtype=np.float64)
+    L = code_len(len(st))
+    pat = st[2:]
+    normal, inverse = pat[:2 * L], pat[2 * L:]
+    out = []
+    d = l_d[None]
+    g = l_g[None]
+    with np.errstate(invalid="ignore"):
+        direct_dominates = d > (g + eps)
+        for parity in (0, 1):                     # 0: column code "h" (:154), 1: row code "v" (:155)
+            n = normal[parity:2 * L:2]
+            i = inverse[parity:2 * L:2]
+            c = np.full(n.shape, -1, dtype=np.int8)           # :162-163
+            c[direct_dominates & (n > (i + eps))] = 1         # :172-173
+            c[direct_dominates & ((n + eps) < i)] = 0         # :175-176
+            c[((n + eps) < d) & (i > (g + eps))] = 0          # :178-179
+            c[(n > (g + eps)) & ((i + eps) < d)] = 1          # :181-182
+            out.append(c)
+    return out[0], out[1]
+
+
+def get_codes(stack: np.ndarray):
+    """decode_codes.py:231-248."""
+    l_d, l_g = direct_indirect(stack)
+    return is_lit(stack, l_d, l_g)
+
+
+def merge_runs(code_runs):
+    """src/3-capture_decode.py:95-96 -- elementwise max over runs (1 > 0 > -1)."""
+    return np.max(np.asarray(code_runs), axis=0)
+
+
+# ----------------------------------------------------------------------------- a5
+
+
+def gray_decode(n: int) -> int:
+    """decode_codes.py:189-207: prefix XOR from the MSB."""
+    shift = n >> 1
+    while shift:
+        n ^= shift
+        shift >>= 1
+    return n
+
+
+def gray_to_decimal(seq) -> int:
+    """decode_codes.py:209-229: any -1 -> -1; else MSB-first bits -> Gray -> binary."""
+    text = "".join(str(seq[k]) for k in range(len(seq)))
+    if "-1" in text:
+        return -1
+    return gray_decode(int(text, 2))
+
+
+def codes_to_pixels_loops(h_codes, v_codes):
+    """src/3-capture_decode.py:99-100: per-pixel Python loops; v codes are flipped."""
+    L, H, W = h_codes.shape
+    hp = np.array([gray_to_decimal(h_codes[:, y, x]) for y in range(H) for x in range(W)]).reshape(H, W)
+    vp = np.array([gray_to_decimal(np.flip(v_codes[:, y, x])) for y in range(H) for x in range(W)]).reshape(H, W)
+    return hp, vp
+
+
+def codes_to_pixels(h_codes, v_codes):
+    """Vectorised twin of :func:`codes_to_pixels_loops` (int64 maps)."""
+    L = h_codes.shape[0]
+
+    def one(codes, msb_first):
+        bad = (codes < 0).any(axis=0)
+        word = np.zeros(codes.shape[1:], dtype=np.int64)
+        for k in range(L):
+            weight = (L - 1 - k) if msb_first else k
+            word |= (codes[k].astype(np.int64) & 1) << weight
+        s = 1
+        while s < 64:
+            word ^= word >> s
+            s <<= 1
+        word[bad] = -1
+        return word
+
+    return one(h_codes, True), one(v_codes, False)
+
+
+def decode(stack_or_runs, eps=1, m=10):
+    """Driver tail (src/3-capture_decode.py:75-100): runs -> codes -> max-merge -> maps."""
+    runs = np.asarray(stack_or_runs)
+    if runs.ndim == 3:
+        runs = runs[None]
+    hs, vs = [], []
+    for st in runs:
+        l_d, l_g = direct_indirect(st)
+        h, v = is_lit(st, l_d, l_g, eps, m)
+        hs.append(h)
+        vs.append(v)
+    return codes_to_pixels(merge_runs(hs), merge_runs(vs))
+
+
+# ----------------------------------------------------------------------------- a6/a7
+
+
+def scale_proj_mtx(proj_mtx, proj_size, proj_calib_size):
+    """triangulate.py:28-33 (returns a scaled copy; the reference mutates in place)."""
+    k = np.array(proj_mtx, dtype=np.float64, copy=True)
+    k[0, :] = k[0, :] * (proj_size[0] / proj_calib_size[0])
+    k[1, :] = k[1, :] * (proj_size[1] / proj_calib_size[1])
+    return k
+
+
+def cam_proj_pts_loops(h_pixels, v_pixels, cam_size, proj_size, img_white):
+    """triangulate.py:39-71: x-major scan, drop (-1), clamp to projector, gather colour."""
+    cam_w, cam_h = cam_size
+    proj_w, proj_h = proj_size
+    cam, proj, col = [], [], []
+    for x in range(cam_w):
+        for y in range(cam_h):
+            hv, vv = h_pixels[y, x], v_pixels[y, x]
+            if hv == -1 or vv == -1:
+                continue
+            cam.append([x, y])
+            proj.append([min(proj_w - 1, hv), min(proj_h - 1, vv)])
+            col.append(img_white[y, x, :])
+    return (np.array(cam, dtype=np.float32), np.array(proj, dtype=np.float32),
+            np.array(col).astype(np.float64) / 255.0)
+
+
+def cam_proj_pts(h_pixels, v_pixels, cam_size, proj_size, img_white=None, order="x"):
+    """Vectorised twin of :func:`cam_proj_pts_loops`.  ``order='x'`` is the reference's
+    column-major scan; ``order='row'`` is row-major (the build's multi-GPU band order)."""
+    cam_w, cam_h = cam_size
+    proj_w, proj_h = proj_size
+    h = np.asarray(h_pixels)[:cam_h, :cam_w]
+    v = np.asarray(v_pixels)[:cam_h, :cam_w]
+    ok = (h != -1) & (v != -1)
+    if order == "x":
+        xs, ys = np.nonzero(ok.T)
+    else:
+        ys, xs = np.nonzero(ok)
+    cam = np.stack([xs, ys], axis=1).astype(np.float32).reshape(-1, 2)
+    proj = np.stack([np.minimum(proj_w - 1, h[ys, xs]), np.minimum(proj_h - 1, v[ys, xs])],
+                    axis=1).astype(np.float32).reshape(-1, 2)
+    col = None
+    if img_white is not None:
+        col = img_white[ys, xs, :].astype(np.float64).reshape(-1, img_white.shape[2]) / 255.0
+    return cam, proj, col
+
+
+# ----------------------------------------------------------------------------- a8
+
+
+def undistort_points(pts, cam_mtx, dist, R=None):
+    """OpenCV 4.8 ``cv::undistortPoints(src, K, dist, R)`` restated (PARITY UNPINNED).
+
+    pts: float32 [M,2] (or [M,1,2]).  Returns float32 [M,1,2] like OpenCV.
+    Default TermCriteria(MAX_ITER, 5, 0.01): exactly five iterations, no EPS test.
+    """
+    p = np.asarray(pts, dtype=np.float32).reshape(-1, 2).astype(np.float64)
+    A = np.asarray(cam_mtx, dtype=np.float64)
+    k = np.zeros(14)
+    dk = np.asarray(dist, dtype=np.float64).ravel()
+    k[:dk.size] = dk
+    RR = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    fx, fy, cx, cy = A[0, 0], A[1, 1], A[0, 2], A[1, 2]
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    u, v = p[:, 0], p[:, 1]
+    x = (u - cx) * ifx
+    y = (v - cy) * ify
+    x0, y0 = x.copy(), y.copy()
+    live = np.ones(x.shape, dtype=bool)          # False once the icdist<0 bail-out fired
+    with np.errstate(all="ignore"):
+        for _ in range(5):
+            r2 = x * x + y * y
+            icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+            bail = live & (icdist < 0)
+            dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2
+            dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2
+            nx = (x0 - dx) * icdist
+            ny = (y0 - dy) * icdist
+            step = live & ~bail
+            x = np.where(step, nx, np.where(bail, (u - cx) * ifx, x))
+            y = np.where(step, ny, np.where(bail, (v - cy) * ify, y))
+            live = step
+        xx = RR[0, 0] * x + RR[0, 1] * y + RR[0, 2]
+        yy = RR[1, 0] * x + RR[1, 1] * y + RR[1, 2]
+        ww = 1.0 / (RR[2, 0] * x + RR[2, 1] * y + RR[2, 2])
+        out = np.stack([xx * ww, yy * ww], axis=1).astype(np.float32)
+    return out.reshape(-1, 1, 2)
+
+
+def to_homogeneous(pts):
+    """``cv2.convertPointsToHomogeneous``: append 1 (same dtype), shape [M,1,3]."""
+    p = np.asarray(pts)
+    p = p.reshape(-1, 1, p.shape[-1])
+    return np.concatenate([p, np.ones(p.shape[:2] + (1,), dtype=p.dtype)], axis=2)
+
+
+def triangulate(cam_pts, proj_pts, cam_mtx, cam_dist, proj_mtx, proj_dist, proj_R, proj_T):
+    """triangulate.py:73-97: undistort both sides, then angle-angle-side on the camera ray.
+
+    ``proj_mtx`` must already be scaled (:func:`scale_proj_mtx`).  Result float64 (3,M):
+    point relative to the camera centre, expressed in projector axes.
+    """
+    cam_h = to_homogeneous(undistort_points(cam_pts, cam_mtx, cam_dist, R=proj_R))[:, 0].T    # :84 f32 (3,M)
+    proj_h = to_homogeneous(undistort_points(proj_pts, proj_mtx, proj_dist))[:, 0].T          # :85
+    T = np.asarray(proj_T, dtype=np.float64)[:, 0]                                            # :86
+    with np.errstate(all="ignore"):
+        t_len = np.linalg.norm(T)
+        ray = cam_h / np.linalg.norm(cam_h, axis=0)                                           # :90 f32
+        alpha = np.arccos(np.dot(-T, ray) / t_len)                                            # :91
+        beta = np.arccos(np.dot(T, proj_h) / (t_len * np.linalg.norm(proj_h, axis=0)))        # :92
+        gamma = np.pi - alpha - beta                                                          # :93
+        rng = t_len * np.sin(beta) / np.sin(gamma)                                            # :94
+        return ray * rng                                                                      # :95
+
+
+def filter_3d_pts(pts, colors, threshold=0.5):
+    """triangulate.py:99-122: strict box filter on |X|,|Y|,|Z| (NaN drops)."""
+    with np.errstate(invalid="ignore"):
+        keep = ((pts[2] < threshold) & (pts[2] > -threshold) & (pts[1] < threshold) &
+                (pts[1] > -threshold) & (pts[0] < threshold) & (pts[0] > -threshold))
+    return pts[:, keep], (None if colors is None else colors[keep])
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+
+
+def gray_code_table(width: int, height: int):
+    """generate_codes.py:22-32: n_bits = ceil(log2(max(w,h))), g = i ^ (i>>1), MSB first."""
+    size = max(width, height)
+    n_bits = int(np.ceil(np.log2(size)))
+    i = np.arange(size, dtype=np.int64)
+    g = i ^ (i >> 1)
+    return ((g[:, None] >> np.arange(n_bits - 1, -1, -1)[None]) & 1).astype(np.uint8)
+
+
+def pattern_sequence(width: int, height: int):
+    """generate_codes.py:34-81 frame-order contract (survey a0), for width >= height.
+
+    images[0]=black, [1]=white; P[2k]=column-code bit k (MSB first); P[2k+1]=row-code bit
+    L-1-k; second half = inverses.  uint8 [4L+2, height, width] with 0/255.
+    """
+    codes = gray_code_table(width, height)
+    L = codes.shape[1]
+    seq = np.zeros((4 * L + 2, height, width), dtype=np.uint8)
+    seq[1] = 255
+    stripe = width // len(codes)                       # :60 (1 when width >= height)
+    for j in range(L):
+        col_bits = np.zeros(width, dtype=np.uint8)
+        n_cols = min(width, len(codes) * stripe)
+        col_bits[:n_cols] = np.repeat(codes[:, j], stripe)[:n_cols] * 255
+        seq[2 * j + 2] = col_bits[None, :]
+        seq[2 * j + 2 + 2 * L] = 255 - seq[2 * j + 2]
+        row_id = 2 * (L - (j + 1)) + 3
+        rows = min(height, len(codes)) * stripe
+        row_bits = np.zeros(height, dtype=np.uint8)
+        row_bits[:rows] = np.repeat(codes[:min(height, len(codes)), j], stripe)[:rows] * 255
+        seq[row_id, :rows, :] = row_bits[:rows, None]
+        seq[row_id + 2 * L, :rows, :] = 255 - seq[row_id, :rows, :]
+    return seq
+
+
+def synth_scene(n_frames: int, H: int, W: int, seed: int = 1, shadow: bool = True, noise: int = 3):
+    """S-scene synthetic capture of SURVEY.md section 8(d) (uint8 [N,H,W])."""
+    L = (n_frames - 2) // 4
+    yy, xx = np.mgrid[0:H, 0:W]
+    xs = (0.9 * xx + 5 * np.sin(yy / 50.0)).astype(np.int64) % (1 << L)
+    ys = (0.9 * yy + 5 * np.cos(xx / 50.0)).astype(np.int64) % (1 << L)
+    gx, gy = xs ^ (xs >> 1), ys ^ (ys >> 1)
+    img = np.full((n_frames, H, W), 15, dtype=np.int64)
+    img[1] = 195
+    for k in range(L):
+        bx = (gx >> (L - 1 - k)) & 1
+        by = (gy >> k) & 1
+        img[2 + 2 * k] = 15 + 180 * bx
+        img[3 + 2 * k] = 15 + 180 * by
+        img[2 + 2 * L + 2 * k] = 15 + 180 * (1 - bx)
+        img[3 + 2 * L + 2 * k] = 15 + 180 * (1 - by)
+    if shadow:
+        y0, y1 = int(0.30 * H), int(0.30 * H + 0.387 * H)
+        x0, x1 = int(0.55 * W), int(0.55 * W + 0.387 * W)
+        img[:, y0:y1, x0:x1] = 15
+    if noise:
+        img += np.random.default_rng(seed).integers(-noise, noise + 1, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
