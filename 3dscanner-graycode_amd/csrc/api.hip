@@ -1,0 +1,669 @@
+// api.hip -- the C-ABI of libslgc.so (declared in include/slgc.h): context, device memory, and the host-buffer
+// entry points that mirror the reference's Python functions.  No CPU fallback anywhere: every entry point runs HIP
+// kernels on the context's device or returns an error.
+#include <cmath>
+#include <new>
+
+#include "slgc_internal.h"
+
+// ------------------------------------------------------------------------------------------ helpers
+int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+int slgc_ws(slgc_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 8;
+        if (hipMalloc(&ctx->ws[slot], want) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "hipMalloc(%zu) failed", want);
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return SLGC_OK;
+}
+
+// Frame index tables, exactly as the reference computes them (decode_codes.py:109-111: float pattern_len, uint8
+// truncation; :149 int pattern_len).  N = 44 -> hid = 19,17,15,40,38,36 (+2).
+int slgc_make_geom(int N, int n_runs, DecodeGeom *g)
+{
+    if (N < 14 || N > 65 || n_runs < 1 || n_runs > SLGC_MAX_RUNS) return SLGC_EINVAL;
+    const double plf = (double)(N - 2) / 4.0;
+    const double h[6] = {2 * plf - 2, 2 * plf - 4, 2 * plf - 6, 4 * plf - 2, 4 * plf - 4, 4 * plf - 6};
+    const double v[6] = {1, 3, 5, 2 * plf + 1, 2 * plf + 3, 2 * plf + 5};
+    for (int k = 0; k < 6; ++k) {
+        g->hid[k] = 2 + (int)(uint8_t)h[k];
+        g->vid[k] = 2 + (int)(uint8_t)v[k];
+        if (g->hid[k] >= N || g->vid[k] >= N) return SLGC_EINVAL;
+    }
+    g->N = N;
+    g->L = (int)((double)(N - 2) / 4.0);
+    g->n_runs = n_runs;
+    return SLGC_OK;
+}
+
+namespace {
+
+int check_ctx(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "hipSetDevice(%d) failed", ctx->device);
+    return SLGC_OK;
+}
+
+size_t esize(int dtype) { return dtype == SLGC_F64 ? 8 : 1; }
+
+// Upload n_runs host stacks into workspace slot 0 back to back.
+int upload_runs(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, size_t npix, RunPtrs *out)
+{
+    const size_t run_bytes = (size_t)N * npix * esize(dtype);
+    void *d;
+    int rc = slgc_ws(ctx, 0, run_bytes * n_runs, &d);
+    if (rc) return rc;
+    for (int r = 0; r < n_runs; ++r) {
+        if (!stacks[r]) return slgc_fail(ctx, SLGC_EINVAL, "stack %d is null", r);
+        out->p[r] = (char *)d + (size_t)r * run_bytes;
+        if (run_bytes) HIP_TRY(ctx, hipMemcpyAsync((void *)out->p[r], stacks[r], run_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return SLGC_OK;
+}
+
+int check_dims(slgc_ctx *ctx, int dtype, int N, int H, int W)
+{
+    if (dtype != SLGC_U8 && dtype != SLGC_F64) return slgc_fail(ctx, SLGC_EINVAL, "dtype must be SLGC_U8 or SLGC_F64");
+    if (N < 14 || N > 65) return slgc_fail(ctx, SLGC_EINVAL, "N=%d outside [14, 65] (reference needs N >= 14; L <= 15)", N);
+    if (H < 0 || W < 0) return slgc_fail(ctx, SLGC_EINVAL, "negative image size");
+    return SLGC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ library / context
+extern "C" int slgc_version(void) { return SLGC_VERSION; }
+extern "C" const char *slgc_backend(void) { return "hip:gfx950"; }
+extern "C" const char *slgc_strerror(int s)
+{
+    switch (s) {
+    case SLGC_OK: return "ok";
+    case SLGC_EINVAL: return "invalid argument";
+    case SLGC_ENODEV: return "no HIP device";
+    case SLGC_EHIP: return "HIP runtime error";
+    case SLGC_ENOMEM: return "out of device memory";
+    case SLGC_ECOMM: return "RCCL error";
+    case SLGC_ESTATE: return "call order error";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int slgc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int slgc_create(int device, slgc_ctx **out)
+{
+    if (!out) return SLGC_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SLGC_ENODEV;
+    if (device < 0 || device >= n) return SLGC_EINVAL;
+    slgc_ctx *ctx = new (std::nothrow) slgc_ctx();
+    if (!ctx) return SLGC_ENOMEM;
+    memset(ctx, 0, sizeof *ctx);
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return SLGC_EHIP;
+    }
+    for (int i = 0; i < SLGC_MAX_EVENTS; ++i)
+        if (hipEventCreate(&ctx->events[i]) != hipSuccess) {
+            delete ctx;
+            return SLGC_EHIP;
+        }
+    *out = ctx;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_destroy(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    slgc_comm_destroy(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (int i = 0; i < SLGC_MAX_EVENTS; ++i)
+        if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
+    for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SLGC_OK;
+}
+
+extern "C" const char *slgc_last_error(slgc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int slgc_synchronize(slgc_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!buf || buflen < 2) return slgc_fail(ctx, SLGC_EINVAL, "bad buffer");
+    hipDeviceProp_t p;
+    HIP_TRY(ctx, hipGetDeviceProperties(&p, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return SLGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ decode, host buffers
+extern "C" int slgc_direct_indirect(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, double *L_d, double *L_g)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_dims(ctx, dtype, N, H, W))) return rc;
+    if (!stack || !L_d || !L_g) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    DecodeGeom g;
+    if (slgc_make_geom(N, 1, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d", N);
+    const size_t npix = (size_t)H * W;
+    RunPtrs runs{};
+    if ((rc = upload_runs(ctx, &stack, dtype, 1, N, npix, &runs))) return rc;
+    void *d_out;
+    if ((rc = slgc_ws(ctx, 1, npix * 16, &d_out))) return rc;
+    double *d_ld = (double *)d_out, *d_lg = d_ld + npix;
+    rc = launch_decode_generic(ctx, g, runs, dtype, npix, npix, 0.0, nullptr, nullptr, d_ld, d_lg, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr);
+    if (rc) return rc;
+    if (npix) {
+        HIP_TRY(ctx, hipMemcpyAsync(L_d, d_ld, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(L_g, d_lg, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+static int codes_common(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, const double *L_d, const double *L_g,
+                        double eps, int8_t *h_codes, int8_t *v_codes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_dims(ctx, dtype, N, H, W))) return rc;
+    if (!stack || !h_codes || !v_codes) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (std::isnan(eps)) return slgc_fail(ctx, SLGC_EINVAL, "eps is NaN");
+    DecodeGeom g;
+    if (slgc_make_geom(N, 1, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d", N);
+    const size_t npix = (size_t)H * W;
+    RunPtrs runs{};
+    if ((rc = upload_runs(ctx, &stack, dtype, 1, N, npix, &runs))) return rc;
+    double *d_ld = nullptr, *d_lg = nullptr;
+    if (L_d) {
+        void *d_in;
+        if ((rc = slgc_ws(ctx, 1, npix * 16, &d_in))) return rc;
+        d_ld = (double *)d_in;
+        d_lg = d_ld + npix;
+        if (npix) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_ld, L_d, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(d_lg, L_g, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
+    void *d_codes;
+    if ((rc = slgc_ws(ctx, 2, 2 * (size_t)g.L * npix, &d_codes))) return rc;
+    int8_t *d_hc = (int8_t *)d_codes, *d_vc = d_hc + (size_t)g.L * npix;
+    rc = launch_decode_generic(ctx, g, runs, dtype, npix, npix, eps, d_ld, d_lg, nullptr, nullptr, d_hc, d_vc, nullptr, nullptr, nullptr,
+                               nullptr);
+    if (rc) return rc;
+    if (npix) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_codes, d_hc, (size_t)g.L * npix, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v_codes, d_vc, (size_t)g.L * npix, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_is_lit(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, const double *L_d, const double *L_g,
+                           double eps, double m, int8_t *h_codes, int8_t *v_codes)
+{
+    (void)m;  // rule 0 of get_is_lit (decode_codes.py:169-170) rewrites the initial -1: m has no effect
+    if (!L_d || !L_g) return slgc_fail(ctx, SLGC_EINVAL, "L_d / L_g are required");
+    return codes_common(ctx, stack, dtype, N, H, W, L_d, L_g, eps, h_codes, v_codes);
+}
+
+extern "C" int slgc_codes(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, double eps, double m, int8_t *h_codes,
+                          int8_t *v_codes)
+{
+    (void)m;
+    return codes_common(ctx, stack, dtype, N, H, W, nullptr, nullptr, eps, h_codes, v_codes);
+}
+
+extern "C" int slgc_codes_to_pixels(slgc_ctx *ctx, const int8_t *h_codes, const int8_t *v_codes, int n_runs, int L, int H, int W,
+                                    int64_t *h_pixels, int64_t *v_pixels)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!h_codes || !v_codes || !h_pixels || !v_pixels) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (L < 1 || L > 15 || n_runs < 1 || H < 0 || W < 0) return slgc_fail(ctx, SLGC_EINVAL, "bad L / n_runs / size");
+    const size_t npix = (size_t)H * W, cb = (size_t)n_runs * L * npix;
+    void *d_codes, *d_maps;
+    if ((rc = slgc_ws(ctx, 2, 2 * cb, &d_codes))) return rc;
+    if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
+    int8_t *d_hc = (int8_t *)d_codes, *d_vc = d_hc + cb;
+    int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
+    if (cb) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_hc, h_codes, cb, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_vc, v_codes, cb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = launch_codes_to_pixels(ctx, d_hc, d_vc, n_runs, L, npix, d_h, d_v))) return rc;
+    if (npix) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_v, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_decode(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, int H, int W, double eps, double m,
+                           int64_t *h_pixels, int64_t *v_pixels)
+{
+    (void)m;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = check_dims(ctx, dtype, N, H, W))) return rc;
+    if (!stacks || !h_pixels || !v_pixels) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (std::isnan(eps)) return slgc_fail(ctx, SLGC_EINVAL, "eps is NaN");
+    DecodeGeom g;
+    if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d (max %d)", N, n_runs, SLGC_MAX_RUNS);
+    const size_t npix = (size_t)H * W;
+    RunPtrs runs{};
+    if ((rc = upload_runs(ctx, stacks, dtype, n_runs, N, npix, &runs))) return rc;
+    void *d_maps;
+    if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
+    int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
+    int e;
+    if (dtype == SLGC_U8 && decode_fast_eligible(eps, &e)) {
+        // product kernel (integer thresholds, int16 maps), widened to the reference's int64 on the device
+        void *d16;
+        if ((rc = slgc_ws(ctx, 2, npix * 4 + 128, &d16))) return rc;
+        int16_t *d_h16 = (int16_t *)d16, *d_v16 = d_h16 + ((npix + 31) & ~(size_t)31);
+        rc = launch_decode_fast(ctx, g, runs, npix, H, W, e, d_h16, d_v16, 0);
+        if (!rc) rc = launch_widen_maps(ctx, d_h16, d_v16, npix, d_h, d_v);
+    } else {
+        rc = launch_decode_generic(ctx, g, runs, dtype, npix, npix, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, d_h, d_v);
+    }
+    if (rc) return rc;
+    if (npix) {
+        HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_v, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ triangulation, host buffers
+extern "C" int slgc_set_calibration(slgc_ctx *ctx, const double cam_K[9], const double *cam_dist, int n_cam_dist,
+                                    const double proj_K[9], const double *proj_dist, int n_proj_dist, const double R[9],
+                                    const double T[3])
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!cam_K || !proj_K || !R || !T) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (n_cam_dist < 0 || n_cam_dist > 14 || n_proj_dist < 0 || n_proj_dist > 14 || (n_cam_dist && !cam_dist) || (n_proj_dist && !proj_dist))
+        return slgc_fail(ctx, SLGC_EINVAL, "distortion vectors must hold 0..14 coefficients");
+    for (int j = 12; j < 14; ++j)
+        if ((j < n_cam_dist && cam_dist[j] != 0.0) || (j < n_proj_dist && proj_dist[j] != 0.0))
+            return slgc_fail(ctx, SLGC_EINVAL, "tilted-sensor coefficients (tauX, tauY) are not supported");
+    Calib &c = ctx->calib;
+    memset(&c, 0, sizeof c);
+    c.cam_k[0] = cam_K[0]; c.cam_k[1] = cam_K[4]; c.cam_k[2] = cam_K[2]; c.cam_k[3] = cam_K[5];       // fx fy cx cy (skew ignored, as OpenCV)
+    c.proj_k[0] = proj_K[0]; c.proj_k[1] = proj_K[4]; c.proj_k[2] = proj_K[2]; c.proj_k[3] = proj_K[5];
+    for (int j = 0; j < n_cam_dist && j < 12; ++j) c.cam_d[j] = cam_dist[j];
+    for (int j = 0; j < n_proj_dist && j < 12; ++j) c.proj_d[j] = proj_dist[j];
+    memcpy(c.R, R, sizeof c.R);
+    memcpy(c.T, T, sizeof c.T);
+    c.t_len = sqrt(T[0] * T[0] + T[1] * T[1] + T[2] * T[2]);                                            // triangulate.py:89
+    ctx->have_calib = true;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_cam_proj_pts_count(slgc_ctx *ctx, const int64_t *h_pixels, const int64_t *v_pixels, int cam_w, int cam_h,
+                                       int proj_w, int proj_h, const uint8_t *white_rgb, int order, int64_t *M)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!h_pixels || !v_pixels || !M) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (cam_w < 0 || cam_h < 0 || (order != SLGC_ORDER_X && order != SLGC_ORDER_ROW)) return slgc_fail(ctx, SLGC_EINVAL, "bad size / order");
+    const size_t npix = (size_t)cam_w * cam_h;
+    ctx->pend_M = -1;
+    void *d_maps, *d_white = nullptr, *d_out, *d_total;
+    if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
+    if ((rc = slgc_ws(ctx, 6, npix * (8 + 8 + (white_rgb ? 24 : 0)) + 64, &d_out))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_total))) return rc;
+    int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
+    if (npix) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_h, h_pixels, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_v, v_pixels, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (white_rgb) {
+        if ((rc = slgc_ws(ctx, 1, npix * 3, &d_white))) return rc;
+        if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_white, white_rgb, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double *d_colors = (double *)d_out;  // colours first (8-byte aligned), then cam, then proj
+    float *d_cam = (float *)((char *)d_out + (white_rgb ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
+    rc = launch_correspond(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, (const uint8_t *)d_white, order, d_cam, d_proj, d_colors,
+                           (unsigned long long *)d_total);
+    if (rc) return rc;
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pend_M = (int64_t)total;
+    ctx->pend_npix = npix;
+    ctx->pend_colors = white_rgb != nullptr;
+    *M = (int64_t)total;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_cam_proj_pts_fetch(slgc_ctx *ctx, float *cam_pts, float *proj_pts, double *colors)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->pend_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending correspondence list (call slgc_cam_proj_pts_count first)");
+    const size_t npix = ctx->pend_npix, M = (size_t)ctx->pend_M;
+    char *d_out = (char *)ctx->ws[6];
+    const double *d_colors = (const double *)d_out;
+    const float *d_cam = (const float *)(d_out + (ctx->pend_colors ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
+    if (M) {
+        if (cam_pts) HIP_TRY(ctx, hipMemcpyAsync(cam_pts, d_cam, M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (proj_pts) HIP_TRY(ctx, hipMemcpyAsync(proj_pts, d_proj, M * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (colors && ctx->pend_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_colors, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float *proj_pts, int64_t M, int mode, double *xyz)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (M < 0 || (M && (!cam_pts || !proj_pts || !xyz))) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative M");
+    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    if (M == 0) return SLGC_OK;
+    void *d_in, *d_out;
+    if ((rc = slgc_ws(ctx, 1, (size_t)M * 16, &d_in))) return rc;
+    if ((rc = slgc_ws(ctx, 6, (size_t)M * 24, &d_out))) return rc;
+    float *d_cam = (float *)d_in, *d_proj = d_cam + 2 * (size_t)M;
+    HIP_TRY(ctx, hipMemcpyAsync(d_cam, cam_pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_proj, proj_pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_triangulate_list(ctx, d_cam, d_proj, M, mode, (double *)d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(xyz, d_out, (size_t)M * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pend_M = -1;  // slot 6 was reused
+    return SLGC_OK;
+}
+
+extern "C" int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (M < 0 || !kept || (M && !xyz)) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative M");
+    ctx->filt_M = -1;
+    void *d_in, *d_total;
+    if ((rc = slgc_ws(ctx, 1, (size_t)M * (24 + (colors ? 24 : 0)), &d_in))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_total))) return rc;
+    double *d_xyz = (double *)d_in, *d_col = colors ? d_xyz + 3 * (size_t)M : nullptr;
+    if (M) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_xyz, xyz, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+        if (colors) HIP_TRY(ctx, hipMemcpyAsync(d_col, colors, (size_t)M * 24, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = launch_filter(ctx, d_xyz, d_col, M, threshold, nullptr, nullptr, (unsigned long long *)d_total, 0))) return rc;
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    void *d_out;
+    if ((rc = slgc_ws(ctx, 6, (size_t)total * (24 + (colors ? 24 : 0)), &d_out))) return rc;
+    double *d_xo = (double *)d_out, *d_co = colors ? d_xo + 3 * (size_t)total : nullptr;
+    if ((rc = launch_filter(ctx, d_xyz, d_col, M, threshold, d_xo, d_co, (unsigned long long *)d_total, 1))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->filt_M = (int64_t)total;
+    ctx->filt_colors = colors != nullptr;
+    ctx->pend_M = -1;
+    *kept = (int64_t)total;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->filt_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending filter result (call slgc_filter_count first)");
+    const size_t K = (size_t)ctx->filt_M;
+    const double *d_xo = (const double *)ctx->ws[6], *d_co = d_xo + 3 * K;
+    if (K) {
+        if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, d_xo, K * 24, hipMemcpyDeviceToHost, ctx->stream));
+        if (colors_out && ctx->filt_colors) HIP_TRY(ctx, hipMemcpyAsync(colors_out, d_co, K * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ device-resident path
+extern "C" int slgc_dev_alloc(slgc_ctx *ctx, size_t bytes, void **dptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!dptr) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    return SLGC_OK;
+}
+
+extern "C" int slgc_dev_free(slgc_ctx *ctx, void *dptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (dptr) HIP_TRY(ctx, hipFree(dptr));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_h2d(slgc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_d2h(slgc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return SLGC_OK;
+}
+
+static int prof_mark(slgc_ctx *ctx, int phase)
+{
+    if (!ctx->prof_on) return SLGC_OK;
+    if (phase == 0 && ctx->prof_n >= ctx->prof_cap) return SLGC_OK;  // ring full: later launches are not sampled
+    if (phase == 1 && ctx->prof_n >= ctx->prof_cap) return SLGC_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + phase], ctx->stream));
+    if (phase == 1) ++ctx->prof_n;
+    return SLGC_OK;
+}
+
+static int decode_fast_timed(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, int rows, int W, int e,
+                             int16_t *d_h, int16_t *d_v, int variant)
+{
+    int rc = prof_mark(ctx, 0);
+    if (rc) return rc;
+    if ((rc = launch_decode_fast(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant))) return rc;
+    return prof_mark(ctx, 1);
+}
+
+extern "C" int slgc_prof_begin(slgc_ctx *ctx, int max_launches)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (max_launches < 1 || max_launches > 65536) return slgc_fail(ctx, SLGC_EINVAL, "max_launches out of range");
+    if (ctx->prof_cap < max_launches) {
+        hipEvent_t *ev = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
+        if (!ev) return slgc_fail(ctx, SLGC_ENOMEM, "event ring");
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i) ev[i] = ctx->prof_ev[i];
+        for (int i = 2 * ctx->prof_cap; i < 2 * max_launches; ++i) HIP_TRY(ctx, hipEventCreate(&ev[i]));
+        delete[] ctx->prof_ev;
+        ctx->prof_ev = ev;
+        ctx->prof_cap = max_launches;
+    }
+    ctx->prof_n = 0;
+    ctx->prof_on = true;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!total_ms || !launches) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    ctx->prof_on = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = ctx->prof_n;
+    return SLGC_OK;
+}
+
+static int dev_geom(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W,
+                    double eps, DecodeGeom *g, RunPtrs *runs, int *e)
+{
+    if (!d_stack) return slgc_fail(ctx, SLGC_EINVAL, "null stack");
+    if (rows < 0 || W < 0 || plane_stride < (size_t)rows * W) return slgc_fail(ctx, SLGC_EINVAL, "plane_stride smaller than the band");
+    if (slgc_make_geom(N, n_runs, g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d", N, n_runs);
+    if (!decode_fast_eligible(eps, e))
+        return slgc_fail(ctx, SLGC_EINVAL, "device-resident decode needs an integer eps in [0,255] (got %g); use slgc_decode", eps);
+    for (int r = 0; r < n_runs; ++r) runs->p[r] = d_stack + (size_t)r * run_stride;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
+                               int rows, int W, double eps, double m, int16_t *d_h, int16_t *d_v, int variant)
+{
+    (void)m;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_h || !d_v) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
+    return decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant);
+}
+
+extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
+                                         int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
+}
+
+extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
+                             int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
+                             int16_t *d_v, float *d_xyz, unsigned long long *d_count)
+{
+    (void)m;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
+    if (!d_h || !d_v) {
+        void *maps;
+        if ((rc = slgc_ws(ctx, 3, (size_t)rows * W * 4 + 64, &maps))) return rc;
+        d_h = (int16_t *)maps;
+        d_v = d_h + (((size_t)rows * W + 31) & ~(size_t)31);
+    }
+    if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, 0))) return rc;
+    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
+}
+
+extern "C" int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
+                                unsigned long long *d_count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_xyz || !d_points || !d_count) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    return launch_compact_dense(ctx, d_xyz, rows, W, row0, d_points, d_keys, d_count);
+}
+
+extern "C" int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
+                                    uint32_t seed, int noise, int shadow)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_stack || N < 14 || N > 65 || rows < 0 || row0 < 0 || row0 + rows > H || plane_stride < (size_t)rows * W)
+        return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments");
+    return launch_synth(ctx, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, shadow);
+}
+
+extern "C" int slgc_event_record(slgc_ctx *ctx, int id)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (id < 0 || id >= SLGC_MAX_EVENTS) return slgc_fail(ctx, SLGC_EINVAL, "event id out of range");
+    HIP_TRY(ctx, hipEventRecord(ctx->events[id], ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (id_start < 0 || id_start >= SLGC_MAX_EVENTS || id_stop < 0 || id_stop >= SLGC_MAX_EVENTS || !ms)
+        return slgc_fail(ctx, SLGC_EINVAL, "bad event arguments");
+    HIP_TRY(ctx, hipEventSynchronize(ctx->events[id_stop]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->events[id_start], ctx->events[id_stop]));
+    return SLGC_OK;
+}

@@ -1,0 +1,160 @@
+// comm.cpp -- RCCL (over xGMI) exchange step of the row-sharded scan.
+//
+// The reference is single-process; this exchange exists only because the build shards a
+// scan by image rows across the GPUs of one node.  One context = one rank = one GPU.  RCCL is loaded lazily with
+// dlopen so single-GPU users never pay for it.  RCCL has no all-gatherv: it is a grouped ncclBroadcast, one per
+// contributing rank, which on xGMI's point-to-point links lets every rank push its shard to all peers at once
+// instead of walking a ring.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "slgc_internal.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) return x;
+#define LOAD(sym) x.sym = reinterpret_cast<decltype(x.sym)>(dlsym(x.handle, "nccl" #sym))
+        LOAD(GetUniqueId); LOAD(CommInitRank); LOAD(CommDestroy); LOAD(AllReduce); LOAD(AllGather);
+        LOAD(Broadcast); LOAD(GroupStart); LOAD(GroupEnd); LOAD(GetErrorString);
+#undef LOAD
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather && x.Broadcast &&
+               x.GroupStart && x.GroupEnd && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+
+#define NCCL_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t r__ = (expr);                                                                           \
+        if (r__ != ncclSuccess) return slgc_fail((ctx), SLGC_ECOMM, "%s: %s", #expr, rccl().GetErrorString(r__)); \
+    } while (0)
+
+int need_comm(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (!ctx->comm) return slgc_fail(ctx, SLGC_ECOMM, "communicator not initialised (call slgc_comm_init)");
+    return SLGC_OK;
+}
+
+}  // namespace
+
+extern "C" int slgc_comm_unique_id(void *id128)
+{
+    if (!id128) return SLGC_EINVAL;
+    if (!rccl().ok) return SLGC_ECOMM;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return SLGC_ECOMM;
+    static_assert(sizeof(id) == SLGC_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id128, &id, sizeof id);
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_init(slgc_ctx *ctx, int rank, int nranks, const void *id128)
+{
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return slgc_fail(ctx, SLGC_EINVAL, "bad rank/nranks");
+    if (ctx->comm) return slgc_fail(ctx, SLGC_ESTATE, "communicator already initialised");
+    if (!rccl().ok) return slgc_fail(ctx, SLGC_ECOMM, "librccl.so not loadable: %s", dlerror());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm;
+    NCCL_TRY(ctx, rccl().CommInitRank(&comm, nranks, id, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    HIP_TRY(ctx, hipMalloc(&ctx->comm_scratch, 8 * (size_t)(nranks + 1)));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_destroy(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        rccl().CommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    if (ctx->comm_scratch) {
+        (void)hipFree(ctx->comm_scratch);
+        ctx->comm_scratch = nullptr;
+    }
+    ctx->nranks = 0;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_allreduce_max_f64(slgc_ctx *ctx, double *value)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!value) return slgc_fail(ctx, SLGC_EINVAL, "null value");
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_scratch, value, 8, hipMemcpyHostToDevice, ctx->stream));
+    NCCL_TRY(ctx, rccl().AllReduce(ctx->comm_scratch, ctx->comm_scratch, 1, ncclFloat64, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(value, ctx->comm_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_barrier(slgc_ctx *ctx)
+{
+    double one = 1.0;
+    return slgc_comm_allreduce_max_f64(ctx, &one);
+}
+
+extern "C" int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!all) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    int64_t *scratch = (int64_t *)ctx->comm_scratch;  // [0] = mine, [1..nranks] = gathered
+    HIP_TRY(ctx, hipMemcpyAsync(scratch, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+    NCCL_TRY(ctx, rccl().AllGather(scratch, scratch + 1, 1, ncclInt64, (ncclComm_t)ctx->comm, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(all, scratch + 1, 8 * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!d_recv || !counts || !displs) return slgc_fail(ctx, SLGC_EINVAL, "null argument");
+    for (int r = 0; r < ctx->nranks; ++r)
+        if (counts[r] < 0 || displs[r] < 0) return slgc_fail(ctx, SLGC_EINVAL, "negative count/displacement");
+    NCCL_TRY(ctx, rccl().GroupStart());
+    for (int r = 0; r < ctx->nranks; ++r) {
+        if (counts[r] == 0) continue;  // same decision on every rank (counts are global)
+        char *dst = (char *)d_recv + displs[r];
+        const void *src = (r == ctx->rank) ? d_send : dst;
+        ncclResult_t e = rccl().Broadcast(src, dst, (size_t)counts[r], ncclUint8, r, (ncclComm_t)ctx->comm, ctx->stream);
+        if (e != ncclSuccess) {
+            rccl().GroupEnd();
+            return slgc_fail(ctx, SLGC_ECOMM, "ncclBroadcast(root %d): %s", r, rccl().GetErrorString(e));
+        }
+    }
+    NCCL_TRY(ctx, rccl().GroupEnd());
+    return SLGC_OK;
+}

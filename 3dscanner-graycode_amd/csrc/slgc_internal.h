@@ -1,0 +1,103 @@
+// Internal declarations shared by the HIP translation units of libslgc.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "slgc.h"
+
+#define SLGC_MAX_RUNS 8
+#define SLGC_MAX_EVENTS 16
+
+// Frame bookkeeping of one decode call; the index arithmetic follows the reference exactly
+// (decode_codes.py:109-111 float pattern_len + uint8 truncation; :149 int pattern_len).
+struct DecodeGeom {
+    int N;        // frames per run
+    int L;        // code length int((N-2)/4)
+    int hid[6];   // absolute frame indices (already +2) feeding L_max
+    int vid[6];   // absolute frame indices feeding L_min
+    int n_runs;
+};
+
+struct RunPtrs {
+    const void *p[SLGC_MAX_RUNS];
+};
+
+// Calibration block in constant form for kernels (filled by slgc_set_calibration).
+struct Calib {
+    double cam_k[4];   // fx, fy, cx, cy
+    double cam_d[12];  // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+    double proj_k[4];
+    double proj_d[12];
+    double R[9];
+    double T[3];
+    double t_len;
+};
+
+struct slgc_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t events[SLGC_MAX_EVENTS];
+    char err[512];
+    // workspace (grown on demand, reused across calls)
+    void *ws[8];
+    size_t ws_bytes[8];
+    // calibration
+    bool have_calib;
+    Calib calib;
+    // results kept on the device between *_count and *_fetch
+    int64_t pend_M;
+    size_t pend_npix;
+    bool pend_colors;
+    int64_t filt_M;
+    bool filt_colors;
+    // per-launch HIP-event timing of the decode kernel (slgc_prof_*), recorded on the launch stream
+    bool prof_on;
+    hipEvent_t *prof_ev;   // pairs: [2i] before, [2i+1] after the decode launch
+    int prof_cap, prof_n;
+    // communicator (comm.cpp)
+    void *comm;
+    int rank, nranks;
+    void *comm_scratch;  // device scratch for small collectives
+};
+
+int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...);
+int slgc_ws(slgc_ctx *ctx, int slot, size_t bytes, void **out);
+int slgc_make_geom(int N, int n_runs, DecodeGeom *g);
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) return slgc_fail((ctx), SLGC_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- launchers (each enqueues on ctx->stream; no sync) ----
+// decode.hip
+int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, int rows, int W, int e,
+                       int16_t *d_h, int16_t *d_v, int variant);
+int launch_decode_generic(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, int dtype, size_t plane_stride_elems,
+                          size_t npix, double eps, const double *d_Ld_in, const double *d_Lg_in, double *d_Ld_out,
+                          double *d_Lg_out, int8_t *d_hc, int8_t *d_vc, int16_t *d_h16, int16_t *d_v16, int64_t *d_h64,
+                          int64_t *d_v64);
+int launch_codes_to_pixels(slgc_ctx *ctx, const int8_t *d_hc, const int8_t *d_vc, int n_runs, int L, size_t npix,
+                           int64_t *d_h, int64_t *d_v);
+bool decode_fast_eligible(double eps, int *e_out);
+int launch_widen_maps(slgc_ctx *ctx, const int16_t *d_h16, const int16_t *d_v16, size_t npix, int64_t *d_h, int64_t *d_v);
+// correspond.hip
+int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,
+                      const uint8_t *d_white, int order, float *d_cam, float *d_proj, double *d_colors,
+                      unsigned long long *d_total);
+int launch_filter(slgc_ctx *ctx, const double *d_xyz, const double *d_colors, int64_t M, double thr, double *d_xyz_out,
+                  double *d_colors_out, unsigned long long *d_total, int pass);
+int launch_compact_dense(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
+                         unsigned long long *d_count);
+// triangulate.hip
+int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz);
+int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
+                            int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
+// synth.hip
+int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
+                 int noise, int shadow);

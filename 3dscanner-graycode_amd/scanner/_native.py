@@ -1,0 +1,399 @@
+"""ctypes binding of libslgc.so (C-ABI in include/slgc.h) -- the only door to the HIP kernels.
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, every compute
+entry point raises.  No torch, no numpy-side arithmetic on the data path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("SLGC_LIB", os.path.join(_PKG_ROOT, "lib", "libslgc.so"))
+
+U8, F64 = 0, 1
+ORDER_X, ORDER_ROW = 0, 1
+TRI_EXACT, TRI_ALGEBRAIC = 0, 1
+UNIQUE_ID_BYTES = 128
+
+
+class SlgcError(RuntimeError):
+    pass
+
+
+_vp, _i, _i64, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/slgc.h declares
+SIGNATURES = {
+    "slgc_version": (_i, []),
+    "slgc_backend": (C.c_char_p, []),
+    "slgc_strerror": (C.c_char_p, [_i]),
+    "slgc_device_count": (_i, []),
+    "slgc_create": (_i, [_i, C.POINTER(_vp)]),
+    "slgc_destroy": (_i, [_vp]),
+    "slgc_last_error": (C.c_char_p, [_vp]),
+    "slgc_synchronize": (_i, [_vp]),
+    "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
+    "slgc_direct_indirect": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "slgc_is_lit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _d, _d, _vp, _vp]),
+    "slgc_codes": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _vp, _vp]),
+    "slgc_codes_to_pixels": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "slgc_decode": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _vp, _vp]),
+    "slgc_set_calibration": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "slgc_cam_proj_pts_count": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, C.POINTER(_i64)]),
+    "slgc_cam_proj_pts_fetch": (_i, [_vp, _vp, _vp, _vp]),
+    "slgc_triangulate": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "slgc_filter_count": (_i, [_vp, _vp, _vp, _i64, _d, C.POINTER(_i64)]),
+    "slgc_filter_fetch": (_i, [_vp, _vp, _vp]),
+    "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "slgc_dev_free": (_i, [_vp, _vp]),
+    "slgc_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "slgc_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "slgc_dev_memset": (_i, [_vp, _vp, _i, _sz]),
+    "slgc_decode_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _d, _d, _vp, _vp, _i]),
+    "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
+    "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
+    "slgc_event_record": (_i, [_vp, _i]),
+    "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
+    "slgc_prof_begin": (_i, [_vp, _i]),
+    "slgc_prof_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
+    "slgc_comm_unique_id": (_i, [_vp]),
+    "slgc_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "slgc_comm_destroy": (_i, [_vp]),
+    "slgc_comm_barrier": (_i, [_vp]),
+    "slgc_comm_allreduce_max_f64": (_i, [_vp, C.POINTER(_d)]),
+    "slgc_comm_allgather_i64": (_i, [_vp, _i64, C.POINTER(_i64)]),
+    "slgc_comm_allgatherv": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libslgc.so once; raise (loudly) if it is not there."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise SlgcError(
+                    f"HIP library not found at {LIB_PATH}: build it with `make -C 3dscanner-graycode_amd` "
+                    "(or __graft_entry__.build()).  There is no CPU fallback.")
+            handle = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().slgc_device_count())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """Device allocation owned by a Context (freed with it or by .free())."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._ck(lib().slgc_dev_alloc(ctx._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        ctx._buffers.append(self)
+
+    def at(self, byte_offset: int) -> int:
+        assert 0 <= byte_offset <= self.nbytes
+        return self.ptr + int(byte_offset)
+
+    def upload(self, arr: np.ndarray, byte_offset: int = 0):
+        a = np.ascontiguousarray(arr)
+        assert byte_offset + a.nbytes <= self.nbytes
+        self.ctx._ck(lib().slgc_h2d(self.ctx._h, self.at(byte_offset), _ptr(a), a.nbytes))
+        return self
+
+    def download(self, shape, dtype, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert byte_offset + out.nbytes <= self.nbytes
+        self.ctx._ck(lib().slgc_d2h(self.ctx._h, _ptr(out), self.at(byte_offset), out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._ck(lib().slgc_dev_memset(self.ctx._h, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().slgc_dev_free(self.ctx._h, self.ptr)
+            self.ptr = None
+            if self in self.ctx._buffers:
+                self.ctx._buffers.remove(self)
+
+
+class Context:
+    """(device, HIP stream, workspace).  One per thread; calls on one context are serialised by the caller."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        rc = lib().slgc_create(int(device), C.byref(h))
+        if rc:
+            raise SlgcError(f"slgc_create(device={device}) failed: {lib().slgc_strerror(rc).decode()} "
+                            "(an MI355X / HIP device is required; there is no CPU fallback)")
+        self._h = h
+        self.device = device
+        self._buffers = []
+
+    # ---- plumbing
+    def _ck(self, rc: int):
+        if rc:
+            msg = lib().slgc_last_error(self._h).decode(errors="replace")
+            text = f"{lib().slgc_strerror(rc).decode()}: {msg}"
+            raise (ValueError if rc == -1 else SlgcError)(text)
+
+    def close(self):
+        if self._h:
+            for b in list(self._buffers):
+                b.free()
+            lib().slgc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        self._ck(lib().slgc_synchronize(self._h))
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._ck(lib().slgc_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def event_record(self, idx: int):
+        self._ck(lib().slgc_event_record(self._h, idx))
+
+    def event_elapsed_ms(self, a: int, b: int) -> float:
+        ms = C.c_float()
+        self._ck(lib().slgc_event_elapsed_ms(self._h, a, b, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- host-buffer entry points (reference-shaped)
+    @staticmethod
+    def _stack(images):
+        st = np.asarray(images)
+        if st.ndim != 3:
+            raise ValueError("image stack must be [N,H,W]")
+        if st.dtype == np.uint8:
+            return np.ascontiguousarray(st), U8
+        return np.ascontiguousarray(st, dtype=np.float64), F64
+
+    def direct_indirect(self, images):
+        st, dt = self._stack(images)
+        N, H, W = st.shape
+        ld, lg = np.empty((H, W)), np.empty((H, W))
+        self._ck(lib().slgc_direct_indirect(self._h, _ptr(st), dt, N, H, W, _ptr(ld), _ptr(lg)))
+        return ld, lg
+
+    def is_lit(self, images, L_d, L_g, eps=1, m=10):
+        st, dt = self._stack(images)
+        N, H, W = st.shape
+        L = int((N - 2) / 4)
+        ld = np.ascontiguousarray(L_d, dtype=np.float64)
+        lg = np.ascontiguousarray(L_g, dtype=np.float64)
+        if ld.shape != (H, W) or lg.shape != (H, W):
+            raise ValueError("L_d / L_g must be [H,W]")
+        hc, vc = np.empty((L, H, W), np.int8), np.empty((L, H, W), np.int8)
+        self._ck(lib().slgc_is_lit(self._h, _ptr(st), dt, N, H, W, _ptr(ld), _ptr(lg), float(eps), float(m), _ptr(hc), _ptr(vc)))
+        return hc, vc
+
+    def codes(self, images, eps=1, m=10):
+        st, dt = self._stack(images)
+        N, H, W = st.shape
+        L = int((N - 2) / 4)
+        hc, vc = np.empty((max(L, 0), H, W), np.int8), np.empty((max(L, 0), H, W), np.int8)
+        self._ck(lib().slgc_codes(self._h, _ptr(st), dt, N, H, W, float(eps), float(m), _ptr(hc), _ptr(vc)))
+        return hc, vc
+
+    def codes_to_pixels(self, h_codes, v_codes):
+        hc = np.ascontiguousarray(h_codes, dtype=np.int8)
+        vc = np.ascontiguousarray(v_codes, dtype=np.int8)
+        if hc.ndim == 3:
+            hc, vc = hc[None], vc[None]
+        if hc.shape != vc.shape or hc.ndim != 4:
+            raise ValueError("codes must be [L,H,W] or [R,L,H,W], same shape for h and v")
+        R, L, H, W = hc.shape
+        hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+        self._ck(lib().slgc_codes_to_pixels(self._h, _ptr(hc), _ptr(vc), R, L, H, W, _ptr(hp), _ptr(vp)))
+        return hp, vp
+
+    def decode(self, runs, eps=1, m=10):
+        """runs: [N,H,W] or a sequence / [R,N,H,W] array of runs (uint8 or float64)."""
+        arr = runs if isinstance(runs, np.ndarray) else None
+        if arr is not None and arr.ndim == 3:
+            stacks = [arr]
+        else:
+            stacks = list(runs)
+        prepared = [self._stack(s) for s in stacks]
+        dts = {dt for _, dt in prepared}
+        if len(dts) != 1 or len({s.shape for s, _ in prepared}) != 1:
+            raise ValueError("all runs must share dtype and shape")
+        dt = dts.pop()
+        N, H, W = prepared[0][0].shape
+        ptrs = (C.c_void_p * len(prepared))(*[s.ctypes.data for s, _ in prepared])
+        hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+        self._ck(lib().slgc_decode(self._h, ptrs, dt, len(prepared), N, H, W, float(eps), float(m), _ptr(hp), _ptr(vp)))
+        return hp, vp
+
+    def set_calibration(self, cam_mtx, cam_dist, proj_mtx, proj_dist, proj_R, proj_T):
+        def vec(a, n=None):
+            v = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+            if n is not None and v.size != n:
+                raise ValueError(f"expected {n} values, got {v.size}")
+            return v
+        ck, pk, r, t = vec(cam_mtx, 9), vec(proj_mtx, 9), vec(proj_R, 9), vec(proj_T, 3)
+        cd = vec(cam_dist if cam_dist is not None else [])
+        pd = vec(proj_dist if proj_dist is not None else [])
+        self._ck(lib().slgc_set_calibration(self._h, _ptr(ck), _ptr(cd), cd.size, _ptr(pk), _ptr(pd), pd.size, _ptr(r), _ptr(t)))
+
+    def cam_proj_pts(self, h_pixels, v_pixels, cam_size, proj_size, img_white=None, order=ORDER_X):
+        cw, ch = int(cam_size[0]), int(cam_size[1])
+        h = np.ascontiguousarray(np.asarray(h_pixels)[:ch, :cw], dtype=np.int64)
+        v = np.ascontiguousarray(np.asarray(v_pixels)[:ch, :cw], dtype=np.int64)
+        if h.shape != (ch, cw) or v.shape != (ch, cw):
+            raise ValueError("h_pixels / v_pixels smaller than cam_size")
+        wh = None
+        if img_white is not None:
+            wh = np.ascontiguousarray(np.asarray(img_white)[:ch, :cw, :3], dtype=np.uint8)
+            if wh.shape != (ch, cw, 3):
+                raise ValueError("img_white must be [H,W,3]")
+        M = C.c_int64()
+        self._ck(lib().slgc_cam_proj_pts_count(self._h, _ptr(h), _ptr(v), cw, ch, int(proj_size[0]), int(proj_size[1]),
+                                               _ptr(wh), int(order), C.byref(M)))
+        n = M.value
+        cam, proj = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32)
+        col = np.empty((n, 3), np.float64) if wh is not None else None
+        self._ck(lib().slgc_cam_proj_pts_fetch(self._h, _ptr(cam), _ptr(proj), _ptr(col)))
+        return cam, proj, col
+
+    def triangulate(self, cam_pts, proj_pts, mode=TRI_EXACT):
+        a = np.ascontiguousarray(np.asarray(cam_pts, dtype=np.float32).reshape(-1, 2))
+        b = np.ascontiguousarray(np.asarray(proj_pts, dtype=np.float32).reshape(-1, 2))
+        if a.shape != b.shape:
+            raise ValueError("cam_pts and proj_pts must have the same length")
+        xyz = np.empty((3, len(a)), np.float64)
+        self._ck(lib().slgc_triangulate(self._h, _ptr(a), _ptr(b), len(a), int(mode), _ptr(xyz)))
+        return xyz
+
+    def filter_3d_pts(self, pts, colors, threshold=0.5):
+        x = np.ascontiguousarray(pts, dtype=np.float64)
+        if x.ndim != 2 or x.shape[0] != 3:
+            raise ValueError("Pts must be (3,M)")
+        M = x.shape[1]
+        c = None if colors is None else np.ascontiguousarray(colors, dtype=np.float64)
+        if c is not None and c.shape != (M, 3):
+            raise ValueError("colors must be (M,3)")
+        kept = C.c_int64()
+        self._ck(lib().slgc_filter_count(self._h, _ptr(x), _ptr(c), M, float(threshold), C.byref(kept)))
+        xo = np.empty((3, kept.value), np.float64)
+        co = None if c is None else np.empty((kept.value, 3), np.float64)
+        self._ck(lib().slgc_filter_fetch(self._h, _ptr(xo), _ptr(co)))
+        return xo, co
+
+    # ---- device-resident entry points (enqueue only)
+    def decode_dev(self, d_stack: int, n_runs, run_stride, plane_stride, N, rows, W, d_h: int, d_v: int, eps=1, m=10, variant=0):
+        self._ck(lib().slgc_decode_dev(self._h, d_stack, n_runs, run_stride, plane_stride, N, rows, W, float(eps), float(m),
+                                       d_h, d_v, int(variant)))
+
+    def scan_dev(self, d_stack: int, n_runs, run_stride, plane_stride, N, rows, W, row0, proj_size, d_xyz: int, d_count=None,
+                 d_h=None, d_v=None, eps=1, m=10, mode=TRI_ALGEBRAIC):
+        self._ck(lib().slgc_scan_dev(self._h, d_stack, n_runs, run_stride, plane_stride, N, rows, W, row0, int(proj_size[0]),
+                                     int(proj_size[1]), float(eps), float(m), int(mode), d_h, d_v, d_xyz, d_count))
+
+    def triangulate_maps_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_xyz: int, d_count=None, mode=TRI_ALGEBRAIC):
+        self._ck(lib().slgc_triangulate_maps_dev(self._h, d_h, d_v, rows, W, row0, int(proj_size[0]), int(proj_size[1]),
+                                                 int(mode), d_xyz, d_count))
+
+    def compact_dev(self, d_xyz: int, rows, W, row0, d_points: int, d_keys, d_count: int):
+        self._ck(lib().slgc_compact_dev(self._h, d_xyz, rows, W, row0, d_points, d_keys, d_count))
+
+    def synth_scene_dev(self, d_stack: int, plane_stride, N, H, W, row0=0, rows=None, seed=1, noise=3, shadow=True):
+        rows = H if rows is None else rows
+        self._ck(lib().slgc_synth_scene_dev(self._h, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, int(bool(shadow))))
+
+    def prof_begin(self, max_launches: int = 4096):
+        self._ck(lib().slgc_prof_begin(self._h, int(max_launches)))
+
+    def prof_end(self):
+        """-> (summed decode-kernel milliseconds, launches sampled)"""
+        ms, n = C.c_double(), C.c_int()
+        self._ck(lib().slgc_prof_end(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    # ---- RCCL
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib().slgc_comm_unique_id(buf)
+        if rc:
+            raise SlgcError("slgc_comm_unique_id failed (librccl.so not loadable?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, uid: bytes):
+        assert len(uid) == UNIQUE_ID_BYTES
+        self._ck(lib().slgc_comm_init(self._h, rank, nranks, C.create_string_buffer(uid, UNIQUE_ID_BYTES)))
+        self.rank, self.nranks = rank, nranks
+
+    def comm_destroy(self):
+        self._ck(lib().slgc_comm_destroy(self._h))
+
+    def comm_barrier(self):
+        self._ck(lib().slgc_comm_barrier(self._h))
+
+    def comm_allreduce_max(self, value: float) -> float:
+        v = C.c_double(value)
+        self._ck(lib().slgc_comm_allreduce_max_f64(self._h, C.byref(v)))
+        return float(v.value)
+
+    def comm_allgather_i64(self, mine: int):
+        out = (C.c_int64 * self.nranks)()
+        self._ck(lib().slgc_comm_allgather_i64(self._h, int(mine), out))
+        return [int(x) for x in out]
+
+    def comm_allgatherv(self, d_send: int, d_recv: int, counts, displs):
+        n = self.nranks
+        c = (C.c_int64 * n)(*[int(x) for x in counts])
+        d = (C.c_int64 * n)(*[int(x) for x in displs])
+        self._ck(lib().slgc_comm_allgatherv(self._h, d_send, d_recv, c, d))
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context() -> Context:
+    """Process-wide context on device SLGC_DEVICE (default 0) for the reference-shaped module functions."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context(int(os.environ.get("SLGC_DEVICE", "0")))
+        return _default_ctx

@@ -1,0 +1,164 @@
+/*
+ * slgc.h -- C-ABI of libslgc.so: MI355X (gfx950) structured-light Gray-code decode + triangulation.
+ *
+ * This is the drop-in boundary for the hot path of guillaume-charron/3DScanner-GrayCode.  The
+ * reference has no FFI layer (it is in-process Python on NumPy arrays), so each entry point below
+ * is what a ctypes binding of the corresponding reference function binds; the Python package
+ * `3dscanner-graycode_amd/scanner` is that binding.  Citations are
+ * file:line under the reference checkout.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns an int status (0 = SLGC_OK, <0 = error)
+ *    and never throws.  slgc_last_error(ctx) gives the text of the last failure on that context.
+ *  - "host" entry points take caller-owned host buffers (NumPy arrays) and do H2D / kernels / D2H.
+ *    "_dev" entry points take device pointers obtained from slgc_dev_alloc and only enqueue work on
+ *    the context's HIP stream (no sync) -- they are what bench.py times.
+ *  - a context = (device, HIP stream, workspace).  Calls on one context are serialised by the
+ *    caller; separate contexts may be used from separate threads (ctypes releases the GIL).
+ *  - image stacks are frame-major [N][H][W] (src/3-capture_decode.py:68-70), dtype SLGC_U8 or
+ *    SLGC_F64 (the reference's own float64 stack).  14 <= N <= 65 (code length L=int((N-2)/4) <= 15).
+ *  - there is NO CPU fallback: without a HIP device slgc_create fails with SLGC_ENODEV.
+ */
+#ifndef SLGC_H
+#define SLGC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLGC_VERSION 100 /* 0.1.0 */
+
+enum {
+    SLGC_OK = 0,
+    SLGC_EINVAL = -1, /* bad argument (N out of range, null pointer, misaligned band, ...) */
+    SLGC_ENODEV = -2, /* no usable HIP device */
+    SLGC_EHIP = -3,   /* HIP runtime error (text in slgc_last_error) */
+    SLGC_ENOMEM = -4,
+    SLGC_ECOMM = -5,  /* RCCL error / communicator not initialised */
+    SLGC_ESTATE = -6  /* call order error (e.g. triangulate before set_calibration) */
+};
+
+enum { SLGC_U8 = 0, SLGC_F64 = 1 };
+enum { SLGC_ORDER_X = 0 /* reference scan order, triangulate.py:52-53 */, SLGC_ORDER_ROW = 1 };
+enum { SLGC_TRI_EXACT = 0 /* acos/sin as triangulate.py:91-94 */, SLGC_TRI_ALGEBRAIC = 1 /* sqrt form */ };
+
+typedef struct slgc_ctx slgc_ctx;
+
+/* ------------------------------------------------------------------ library / context */
+int slgc_version(void);
+const char *slgc_backend(void); /* "hip:gfx950" */
+const char *slgc_strerror(int status);
+int slgc_device_count(void);    /* number of HIP devices, 0 if none / runtime unusable */
+int slgc_create(int device, slgc_ctx **out);
+int slgc_destroy(slgc_ctx *ctx);
+const char *slgc_last_error(slgc_ctx *ctx);
+int slgc_synchronize(slgc_ctx *ctx);
+int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
+
+/* ------------------------------------------------------------------ decode, host buffers */
+
+/* get_direct_indirect(images) -- scanner/grayCode/decode_codes.py:90-122.  L_d, L_g: float64 [H][W]. */
+int slgc_direct_indirect(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, double *L_d, double *L_g);
+
+/* get_is_lit(images, L_d, L_g, eps, m) -- decode_codes.py:125-186.  codes: int8 [L][H][W] in {-1,0,1}. */
+int slgc_is_lit(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, const double *L_d, const double *L_g,
+                double eps, double m, int8_t *h_codes, int8_t *v_codes);
+
+/* get_codes(images) -- decode_codes.py:231-248 (eps=1, m=10 are the reference defaults). */
+int slgc_codes(slgc_ctx *ctx, const void *stack, int dtype, int N, int H, int W, double eps, double m, int8_t *h_codes,
+               int8_t *v_codes);
+
+/* Driver tail src/3-capture_decode.py:95-100: max-merge n_runs code stacks ([n_runs][L][H][W] int8), then
+ * gray_to_decimal per pixel (decode_codes.py:209-229; v codes flipped).  Maps: int64 [H][W], -1 = undecodable. */
+int slgc_codes_to_pixels(slgc_ctx *ctx, const int8_t *h_codes, const int8_t *v_codes, int n_runs, int L, int H, int W,
+                         int64_t *h_pixels, int64_t *v_pixels);
+
+/* Fused get_codes per run -> merge -> maps (src/3-capture_decode.py:75-100).  stacks: n_runs pointers. */
+int slgc_decode(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, int H, int W, double eps, double m,
+                int64_t *h_pixels, int64_t *v_pixels);
+
+/* ------------------------------------------------------------------ triangulation, host buffers */
+
+/* Calibration as held by Triangulate.__init__ (scanner/triangulation/triangulate.py:5-37).  proj_K must already
+ * carry the row scaling of :28-33 (the Python class applies it, mutating the caller's array like the reference).
+ * dist: k1,k2,p1,p2[,k3[,k4,k5,k6[,s1..s4]]] (5x1 and 1x5 both occur in the reference's data files). */
+int slgc_set_calibration(slgc_ctx *ctx, const double cam_K[9], const double *cam_dist, int n_cam_dist,
+                         const double proj_K[9], const double *proj_dist, int n_proj_dist, const double R[9],
+                         const double T[3]);
+
+/* get_cam_proj_pts(img_white) -- triangulate.py:39-71.  Two calls: _count runs the kernels and leaves the
+ * lists on the device, _fetch copies them out (cam/proj: float32 [M][2]; colors: float64 [M][3] = rgb/255,
+ * may be NULL when white was NULL). */
+int slgc_cam_proj_pts_count(slgc_ctx *ctx, const int64_t *h_pixels, const int64_t *v_pixels, int cam_w, int cam_h,
+                            int proj_w, int proj_h, const uint8_t *white_rgb, int order, int64_t *M);
+int slgc_cam_proj_pts_fetch(slgc_ctx *ctx, float *cam_pts, float *proj_pts, double *colors);
+
+/* triangulate(cam_pts, proj_pts) -- triangulate.py:73-97.  xyz: float64 (3,M) row-major. */
+int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float *proj_pts, int64_t M, int mode, double *xyz);
+
+/* filter_3d_pts(Pts, colors, threshold) -- triangulate.py:99-122.  _count then _fetch (order preserved). */
+int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept);
+int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_out);
+
+/* ------------------------------------------------------------------ device-resident path (what bench.py times) */
+int slgc_dev_alloc(slgc_ctx *ctx, size_t bytes, void **dptr);
+int slgc_dev_free(slgc_ctx *ctx, void *dptr);
+int slgc_h2d(slgc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int slgc_d2h(slgc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t bytes);
+
+/* Decode n_runs uint8 stacks resident in HBM into int16 maps [rows][W] (-1 = undecodable).
+ * Run r, frame f starts at d_stack + r*run_stride + f*plane_stride (bytes); `rows` rows of W pixels are
+ * decoded from each frame (a row band of a taller image when plane_stride > rows*W).  variant: 0 = auto. */
+int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
+                    int rows, int W, double eps, double m, int16_t *d_h, int16_t *d_v, int variant);
+
+/* Fused decode -> clamp -> triangulate on a row band: dense float32 XYZ [rows][W][3] (NaN where undecodable),
+ * optional int16 maps (may be NULL), and *d_count += number of valid pixels.  row0 = first row of the band in the
+ * full image (camera y of local row 0). */
+int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
+                  int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
+                  int16_t *d_v, float *d_xyz, unsigned long long *d_count);
+
+/* Triangulate dense int16 maps (as written by slgc_decode_dev) into dense XYZ; same outputs as slgc_scan_dev. */
+int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
+                              int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
+
+/* Row-major compaction of a dense band: keeps pixels with finite XYZ; writes float32 [M][3] points and uint32
+ * linear pixel keys ((row0+y)*W + x); *d_count (device) receives M.  Capacity of outputs: rows*W records. */
+int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
+                     unsigned long long *d_count);
+
+/* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
+int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
+                         uint32_t seed, int noise, int shadow);
+
+/* HIP-event timing on the context's stream: id in [0,16). */
+int slgc_event_record(slgc_ctx *ctx, int id);
+int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms);
+
+/* Per-launch timing of the decode kernel: between _begin and _end every decode launch made through slgc_decode_dev /
+ * slgc_scan_dev is bracketed by a HIP event pair on the context's stream (up to max_launches); _end synchronises and
+ * returns the summed kernel time and the number of launches sampled. */
+int slgc_prof_begin(slgc_ctx *ctx, int max_launches);
+int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
+#define SLGC_UNIQUE_ID_BYTES 128
+int slgc_comm_unique_id(void *id128);                                          /* rank 0 creates, host shares */
+int slgc_comm_init(slgc_ctx *ctx, int rank, int nranks, const void *id128);    /* one context = one rank = one GPU */
+int slgc_comm_destroy(slgc_ctx *ctx);
+int slgc_comm_barrier(slgc_ctx *ctx);                                          /* all-reduce of one word + stream sync */
+int slgc_comm_allreduce_max_f64(slgc_ctx *ctx, double *value);                 /* in place, host scalar */
+int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all);        /* all: host int64[nranks] */
+/* all-gatherv of byte records: rank r contributes counts[r] bytes from d_send; every rank receives all of them at
+ * d_recv + displs[r].  Grouped ncclBroadcast (RCCL has no native all-gatherv). */
+int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLGC_H */

@@ -362,3 +362,47 @@ def synth_scene(n_frames: int, H: int, W: int, seed: int = 1, shadow: bool = Tru
     if noise:
         img += np.random.default_rng(seed).integers(-noise, noise + 1, size=img.shape)
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_scene_int(n_frames: int, H: int, W: int, seed: int = 1, noise: int = 3, shadow: bool = True,
+                    row0: int = 0, rows=None):
+    """Bit-identical NumPy twin of the device generator csrc/synth.hip (all-integer warp, hash
+    noise).  Returns (stack uint8 [N,rows,W], xs, ys) where xs/ys are the projector coordinates
+    encoded at each pixel (mod 2^L)."""
+    rows = H - row0 if rows is None else rows
+    L = (n_frames - 2) // 4
+    yy, xx = np.mgrid[row0:row0 + rows, 0:W].astype(np.int64)
+
+    def tri(t):
+        return np.abs(((t >> 2) % 20) - 10)
+
+    msk = (1 << L) - 1
+    xs = (((29 * xx) >> 5) + tri(yy)) & msk
+    ys = (((29 * yy) >> 5) + tri(xx)) & msk
+    gx, gy = xs ^ (xs >> 1), ys ^ (ys >> 1)
+    img = np.full((n_frames, rows, W), 15, dtype=np.int64)
+    img[1] = 195
+    for k in range(L):
+        bx = (gx >> (L - 1 - k)) & 1
+        by = (gy >> k) & 1
+        img[2 + 2 * k] = 15 + 180 * bx
+        img[3 + 2 * k] = 15 + 180 * by
+        img[2 + 2 * L + 2 * k] = 15 + 180 * (1 - bx)
+        img[3 + 2 * L + 2 * k] = 15 + 180 * (1 - by)
+    if shadow:
+        sy0, sy1 = int(0.30 * H), int(0.30 * H + 0.387 * H)
+        sx0, sx1 = int(0.55 * W), int(0.55 * W + 0.387 * W)
+        inside = (yy >= sy0) & (yy < sy1) & (xx >= sx0) & (xx < sx1)
+        img[:, inside] = 15
+    if noise > 0:
+        gp = (yy * W + xx).astype(np.uint32)
+        f = np.arange(n_frames, dtype=np.uint32)[:, None, None]
+        with np.errstate(over="ignore"):
+            x = gp[None] * np.uint32(0x9E3779B1) + f * np.uint32(0x85EBCA77) + np.uint32(seed)
+            x ^= x >> np.uint32(16)
+            x *= np.uint32(0x7FEB352D)
+            x ^= x >> np.uint32(15)
+            x *= np.uint32(0x846CA68B)
+            x ^= x >> np.uint32(16)
+        img += (x % np.uint32(2 * noise + 1)).astype(np.int64) - noise
+    return np.clip(img, 0, 255).astype(np.uint8), xs, ys

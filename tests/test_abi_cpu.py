@@ -1,0 +1,109 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/slgc.h declares; the Python mirror exposes the reference's names; the product path has no
+CPU fallback and never imports the oracle."""
+import ast
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "slgc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slgc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scanner import _native
+    lib = _native.lib()
+    declared = header_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in slgc.h but not exported"
+    assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with slgc.h"
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (slgc_[a-z0-9_]+)", out)))
+    assert exported == declared
+
+
+def test_library_identity_no_gpu_needed():
+    from scanner import _native
+    lib = _native.lib()
+    assert lib.slgc_backend() == b"hip:gfx950"
+    assert lib.slgc_version() == 100
+    assert lib.slgc_strerror(-2) == b"no HIP device"
+    assert lib.slgc_device_count() >= 0
+
+
+def test_fails_loudly_without_device():
+    from scanner import _native
+    if _native.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_native.SlgcError, match="no CPU fallback"):
+        _native.Context(0)
+    from scanner.grayCode.decode_codes import get_codes
+    with pytest.raises(_native.SlgcError):
+        get_codes(np.zeros((14, 4, 4), np.uint8))
+
+
+def test_python_surface_matches_reference_names():
+    import inspect
+    from scanner.grayCode import decode_codes as dc, generate_codes as gc
+    from scanner.triangulation import Triangulate, Triangulation
+    for fn in ("get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal", "decode"):
+        assert callable(getattr(dc, fn))
+    assert list(inspect.signature(dc.get_is_lit).parameters)[:5] == ["images", "L_d", "L_g", "eps", "m"]
+    assert inspect.signature(dc.get_is_lit).parameters["eps"].default == 1
+    assert inspect.signature(dc.get_is_lit).parameters["m"].default == 10
+    params = list(inspect.signature(Triangulate.__init__).parameters)
+    assert params[1:13] == ["h_pixels", "v_pixels", "cam_size", "cam_mtx", "cam_dist", "proj_size", "proj_calib_size",
+                            "proj_mtx", "proj_dist", "proj_R", "proj_T", "image_folder"]
+    assert inspect.signature(Triangulate.filter_3d_pts).parameters["threshold"].default == .5
+    assert issubclass(Triangulation, Triangulate) and callable(Triangulation.compute)
+    assert callable(gc.get_gray_codes) and callable(gc.get_image_sequence)
+
+
+def test_host_helpers_match_golden():
+    from conftest import GOLDEN
+    from scanner.grayCode import decode_codes as dc, generate_codes as gc
+    z = np.load(os.path.join(GOLDEN, "gray_kat.npz"))
+    assert [dc.gray_decode(n) for n in range(4096)] == list(z["gray_decode"])
+    assert [dc.gray_to_decimal(s) for s in z["g2d_in"]] == list(z["g2d_out"])
+    g = np.load(os.path.join(GOLDEN, "generator.npz"))
+    for (w, h) in ((64, 32), (40, 24), (16, 16)):
+        codes = gc.get_gray_codes(w, h)
+        assert np.array_equal(codes, g[f"codes_{w}x{h}"])
+        assert np.array_equal(gc.get_image_sequence(codes, w, h), g[f"seq_{w}x{h}"])
+
+
+def test_triangulate_ctor_scales_proj_mtx_in_place(calib):
+    from scanner.triangulation import Triangulate
+    pm = calib["proj_mtx"].copy()
+    Triangulate(None, None, (1920, 1080), calib["cam_mtx"], calib["cam_dist"], (1280, 800), (1920, 1080), pm,
+                calib["proj_dist"], np.eye(3), np.ones((3, 1)), None)
+    assert np.isclose(pm[0, 0], calib["proj_mtx"][0, 0] * 1280 / 1920) and np.isclose(pm[1, 2], calib["proj_mtx"][1, 2] * 800 / 1080)
+
+
+def test_product_never_touches_oracle_or_torch():
+    """The shipped package must not import oracle/, torch, or any CPU compute fallback."""
+    for dirpath, _, files in os.walk(os.path.join(PKG, "scanner")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    names = [node.module]
+                for n in names:
+                    assert not n.startswith(("oracle", "torch", "cv2")), f"{f} imports {n}"
+    for f in os.listdir(os.path.join(PKG, "csrc")):
+        text = open(os.path.join(PKG, "csrc", f)).read()
+        assert "slgc_oracle" not in text and "orc_" not in text, f

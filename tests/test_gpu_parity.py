@@ -1,0 +1,368 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C-ABI of libslgc.so
+(via the ctypes mirror) and is compared with the golden vectors produced by the reference itself and
+with the CPU oracle on seeded inputs.  Integer/byte/index outputs must be bit-exact; XYZ within
+1e-4 relative (BASELINE.json north_star), in practice ~1e-12."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c as oc
+import oracle_np as onp
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+XYZ_RTOL = 1e-4  # tolerance stated by BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scanner import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def rot_y(deg):
+    th = np.deg2rad(deg)
+    return np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+
+
+# ----------------------------------------------------------------------------------------- decode vs golden
+def test_golden_decode_cases(ctx, decode_cases):
+    for name, c in decode_cases.items():
+        st = c["stack"]
+        for view in (st, st.astype(np.float64)):
+            ld, lg = ctx.direct_indirect(view)
+            assert np.array_equal(ld, c["L_d"], equal_nan=True), name
+            assert np.array_equal(lg, c["L_g"], equal_nan=True), name
+            hc, vc = ctx.codes(view)
+            assert hc.dtype == np.int8 and np.array_equal(hc, c["h_codes"]) and np.array_equal(vc, c["v_codes"]), name
+            hc2, vc2 = ctx.is_lit(view, c["L_d"], c["L_g"])
+            assert np.array_equal(hc2, c["h_codes"]) and np.array_equal(vc2, c["v_codes"]), name
+            hp, vp = ctx.decode(view)                      # uint8 -> integer-threshold kernel; float64 -> literal kernel
+            assert hp.dtype == np.int64
+            assert np.array_equal(hp, c["h_pixels"]) and np.array_equal(vp, c["v_pixels"]), name
+        hp, vp = ctx.codes_to_pixels(c["h_codes"], c["v_codes"])
+        assert np.array_equal(hp, c["h_pixels"]) and np.array_equal(vp, c["v_pixels"]), name
+        if "stack2" in c:
+            for cast in (np.uint8, np.float64):
+                hp, vp = ctx.decode([st.astype(cast), c["stack2"].astype(cast)])
+                assert np.array_equal(hp, c["merged_h_pixels"]) and np.array_equal(vp, c["merged_v_pixels"]), name
+
+
+def test_module_level_api_matches_golden(decode_cases):
+    from scanner.grayCode.decode_codes import decode, get_codes, get_direct_indirect, get_is_lit
+    c = decode_cases["scene_N44_24x40"]
+    st = c["stack"].astype(np.float64)                      # the reference's own stack dtype
+    ld, lg = get_direct_indirect(st)
+    hc, vc = get_is_lit(st, ld, lg)
+    hc2, vc2 = get_codes(st)
+    assert np.array_equal(hc, c["h_codes"]) and np.array_equal(vc2, c["v_codes"]) and np.array_equal(hc, hc2)
+    hp, vp = decode(st)
+    assert np.array_equal(hp, c["h_pixels"]) and np.array_equal(vp, c["v_pixels"])
+
+
+def test_rule_known_answers(ctx):
+    kat = np.load(os.path.join(GOLDEN, "rule_kat.npz"))["kat"]
+    for eps in np.unique(kat[:, 0]):
+        rows = kat[kat[:, 0] == eps]
+        n = len(rows)
+        st = np.zeros((14, 1, n))
+        st[2, 0], st[8, 0] = rows[:, 3], rows[:, 4]
+        hc, _ = ctx.is_lit(st, rows[:, 1].reshape(1, n), rows[:, 2].reshape(1, n), eps=eps)
+        assert np.array_equal(hc[0, 0], rows[:, 5].astype(np.int8)), eps
+
+
+def test_identity_scan(ctx):
+    from scanner.grayCode import generate_codes as gc
+    for (w, h) in ((64, 32), (128, 96)):
+        seq = gc.get_image_sequence(gc.get_gray_codes(w, h), w, h)
+        cap = (20 + 0.7 * seq.astype(np.float64)).astype(np.uint8)
+        hp, vp = ctx.decode(cap)
+        yy, xx = np.mgrid[0:h, 0:w]
+        assert np.array_equal(hp, xx) and np.array_equal(vp, yy)
+
+
+# ----------------------------------------------------------------------------------------- decode vs oracle, bigger seeded inputs
+@pytest.mark.parametrize("N", [14, 17, 26, 42, 44, 46, 62])
+def test_decode_random_vs_oracle(ctx, N):
+    rng = np.random.default_rng(N)
+    for (H, W) in ((67, 131), (120, 256)):                 # ragged (not a multiple of 16) and aligned
+        st = rng.integers(0, 256, (N, H, W), dtype=np.uint8)
+        st[:, :7, :9] = 0                                   # NaN pixels
+        st2 = rng.integers(0, 256, (N, H, W), dtype=np.uint8)
+        ref = oc.decode(st)
+        for view in (st, st.astype(np.float64)):
+            hp, vp = ctx.decode(view)
+            assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1])
+        ref2 = oc.decode(np.stack([st, st2]))
+        hp, vp = ctx.decode([st, st2])
+        assert np.array_equal(hp, ref2[0]) and np.array_equal(vp, ref2[1])
+
+
+@pytest.mark.parametrize("eps", [0, 1, 2, 5, 0.5, 1.0 - 2.0 ** -60, 3.75, -1])
+def test_decode_eps_variants_vs_oracle(ctx, eps):
+    rng = np.random.default_rng(3)
+    st = rng.integers(0, 256, (26, 50, 64), dtype=np.uint8)
+    # near-tie pairs so eps matters
+    st[8:14] = np.clip(st[2:8].astype(int) + rng.integers(-3, 4, st[2:8].shape), 0, 255).astype(np.uint8)
+    ref = oc.decode(st, eps=eps)
+    hp, vp = ctx.decode(st, eps=eps)
+    assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1])
+    ld, lg = oc.direct_indirect(st)
+    hc, vc = ctx.is_lit(st, ld, lg, eps=eps)
+    rhc, rvc = oc.is_lit(st, ld, lg, eps=eps)
+    assert np.array_equal(hc, rhc) and np.array_equal(vc, rvc)
+
+
+def test_decode_f64_non_integer_stack(ctx):
+    rng = np.random.default_rng(5)
+    st = rng.uniform(0, 255, (18, 33, 47))
+    st[0, :3] = np.nan
+    ref = oc.decode(st)
+    hp, vp = ctx.decode(st)
+    assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1])
+    a, b = ctx.direct_indirect(st)
+    ra, rb = oc.direct_indirect(st)
+    assert np.array_equal(a, ra, equal_nan=True) and np.array_equal(b, rb, equal_nan=True)
+
+
+def test_bad_arguments(ctx):
+    with pytest.raises(ValueError):
+        ctx.decode(np.zeros((10, 4, 4), np.uint8))          # the reference raises for N < 14 too
+    with pytest.raises(ValueError):
+        ctx.decode(np.zeros((70, 4, 4), np.uint8))
+    with pytest.raises(ValueError):
+        ctx.decode(np.zeros((14, 4), np.uint8))
+    hp, vp = ctx.decode(np.zeros((14, 0, 5), np.uint8))    # empty image
+    assert hp.shape == (0, 5)
+
+
+# ----------------------------------------------------------------------------------------- device-resident decode
+def dev_decode(ctx, st_runs, variant=0, band=None, eps=1):
+    R, N, H, W = st_runs.shape
+    buf = ctx.alloc(st_runs.nbytes).upload(st_runs)
+    r0, r1 = band or (0, H)
+    rows = r1 - r0
+    out = ctx.alloc(rows * W * 2 * 2 + 64)
+    voff = (rows * W * 2 + 31) // 32 * 32
+    ctx.decode_dev(buf.at(r0 * W), R, N * H * W, H * W, N, rows, W, out.at(0), out.at(voff), eps=eps, variant=variant)
+    ctx.synchronize()
+    h = out.download((rows, W), np.int16)
+    v = out.download((rows, W), np.int16, voff)
+    buf.free()
+    out.free()
+    return h, v
+
+
+@pytest.mark.parametrize("variant", [0, 16256, 16128, 16064, 8256, 8128, 8064, 4256, 4128, 4064, 1256])
+def test_decode_dev_variants(ctx, variant):
+    rng = np.random.default_rng(9)
+    st = rng.integers(0, 256, (2, 44, 96, 256), dtype=np.uint8)
+    st[1] = onp.synth_scene(44, 96, 256, seed=3)
+    ref = oc.decode(st)
+    h, v = dev_decode(ctx, st, variant)
+    assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1])
+    # row band of a taller image (multi-GPU sharding): rows 32..80
+    rb = oc.decode(st[:, :, 32:80])
+    h, v = dev_decode(ctx, st, variant, band=(32, 80))
+    assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
+
+
+def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
+    rng = np.random.default_rng(10)
+    st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
+    ref = oc.decode(st[:, :, 5:30])
+    h, v = dev_decode(ctx, st, 0, band=(5, 30))
+    assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1])
+    with pytest.raises(ValueError):
+        dev_decode(ctx, st, 16256, band=(5, 30))
+
+
+def test_synth_matches_numpy_twin(ctx):
+    for (N, H, W, noise, shadow) in ((44, 64, 200, 3, True), (46, 37, 101, 0, False), (14, 16, 40, 9, True)):
+        buf = ctx.alloc(N * H * W)
+        ctx.synth_scene_dev(buf.ptr, H * W, N, H, W, seed=7, noise=noise, shadow=shadow)
+        ctx.synchronize()
+        got = buf.download((N, H, W), np.uint8)
+        ref, _, _ = onp.synth_scene_int(N, H, W, seed=7, noise=noise, shadow=shadow)
+        assert np.array_equal(got, ref)
+        buf.free()
+
+
+@pytest.mark.parametrize("N,W,H", [(44, 4096, 3000), (46, 1920, 1080)])
+def test_full_size_round_trip_properties(ctx, N, W, H):
+    """BASELINE.json full sizes: encode (device generator) -> decode must return the encoded projector
+    coordinates wherever a pixel is decodable; shadowed pixels must be undecodable; and a band of the result
+    must equal the CPU oracle bit for bit."""
+    L = (N - 2) // 4
+    stack = ctx.alloc(N * H * W)
+    ctx.synth_scene_dev(stack.ptr, H * W, N, H, W, seed=1, noise=3, shadow=True)
+    out = ctx.alloc(H * W * 4)
+    ctx.decode_dev(stack.ptr, 1, N * H * W, H * W, N, H, W, out.at(0), out.at(H * W * 2))
+    ctx.synchronize()
+    h = out.download((H, W), np.int16).astype(np.int64)
+    v = out.download((H, W), np.int16, H * W * 2).astype(np.int64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    msk = (1 << L) - 1
+    tri = lambda t: np.abs(((t >> 2) % 20) - 10)           # noqa: E731
+    xs, ys = (((29 * xx) >> 5) + tri(yy)) & msk, (((29 * yy) >> 5) + tri(xx)) & msk
+    okh, okv = h != -1, v != -1
+    assert okh.mean() > 0.5 and okv.mean() > 0.5
+    assert np.array_equal(h[okh], xs[okh]) and np.array_equal(v[okv], ys[okv])
+    sy0, sy1, sx0, sx1 = int(0.30 * H), int(0.30 * H + 0.387 * H), int(0.55 * W), int(0.55 * W + 0.387 * W)
+    assert not okh[sy0:sy1, sx0:sx1].any() and not okv[sy0:sy1, sx0:sx1].any()
+    assert h.min() >= -1 and h.max() <= msk
+    # oracle on a band that crosses the shadow edge
+    r0, r1 = sy0 - 8, sy0 + 8
+    band = stack.download((N, H, W), np.uint8)[:, r0:r1]
+    ref = oc.decode(band)
+    assert np.array_equal(h[r0:r1], ref[0]) and np.array_equal(v[r0:r1], ref[1])
+    # idempotence: a second launch gives the same bytes
+    ctx.decode_dev(stack.ptr, 1, N * H * W, H * W, N, H, W, out.at(0), out.at(H * W * 2))
+    ctx.synchronize()
+    assert np.array_equal(out.download((H, W), np.int16), h.astype(np.int16))
+    stack.free()
+    out.free()
+
+
+# ----------------------------------------------------------------------------------------- correspondences / triangulation
+def test_golden_triangulate_cases(ctx, tri_cases):
+    from scanner.triangulation import Triangulate
+    for name, c in tri_cases.items():
+        pm = c["proj_mtx"].copy()
+        t = Triangulate(c["h"], c["v"], tuple(int(x) for x in c["cam_size"]), c["cam_mtx"], c["cam_dist"],
+                        tuple(int(x) for x in c["proj_size"]), tuple(int(x) for x in c["proj_calib_size"]), pm,
+                        c["proj_dist"], c["R"], c["T"], None, ctx=ctx)
+        assert np.array_equal(pm, c["proj_mtx_scaled"])                        # in-place scaling, like the reference
+        cam, proj, col = t.get_cam_proj_pts(c["white"])
+        assert cam.dtype == np.float32 and proj.dtype == np.float32 and col.dtype == np.float64
+        assert np.array_equal(cam, c["cam_pts"]) and np.array_equal(proj, c["proj_pts"]) and np.array_equal(col, c["colors"])
+        pts = t.triangulate(cam, proj)
+        assert pts.dtype == np.float64 and pts.shape == c["pts"].shape
+        np.testing.assert_allclose(pts, c["pts"], rtol=XYZ_RTOL, atol=0)
+        np.testing.assert_allclose(pts, c["pts"], rtol=1e-9, atol=1e-12)       # what the kernel actually achieves
+        alg = t.triangulate(cam, proj, exact=False)
+        np.testing.assert_allclose(alg, c["pts"], rtol=XYZ_RTOL, atol=0)
+        fp, fc = t.filter_3d_pts(c["pts"], c["colors"], threshold=0.5)
+        assert np.array_equal(fp, c["filt_pts"]) and np.array_equal(fc, c["filt_colors"])
+        cam_r, proj_r, col_r = t.get_cam_proj_pts(c["white"], order="row")
+        ref_r = oc.cam_proj_pts(c["h"], c["v"], c["cam_size"], c["proj_size"], c["white"], order="row")
+        assert np.array_equal(cam_r, ref_r[0]) and np.array_equal(proj_r, ref_r[1]) and np.array_equal(col_r, ref_r[2])
+        cam_n, proj_n, col_n = t.get_cam_proj_pts(None)
+        assert col_n is None and np.array_equal(cam_n, c["cam_pts"])
+
+
+def test_cam_proj_pts_large_vs_oracle(ctx):
+    rng = np.random.default_rng(12)
+    H, W = 301, 517
+    h = rng.integers(-1, 1500, (H, W)).astype(np.int64)
+    v = rng.integers(-1, 900, (H, W)).astype(np.int64)
+    h[rng.random((H, W)) < 0.3] = -1
+    h[:, 100:140] = -1                                      # empty columns
+    v[50:90] = -1                                           # empty rows
+    white = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    for order, o in (("x", 0), ("row", 1)):
+        ref = oc.cam_proj_pts(h, v, (W, H), (1280, 800), white, order=order)
+        got = ctx.cam_proj_pts(h, v, (W, H), (1280, 800), white, order=o)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+    none = ctx.cam_proj_pts(np.full((H, W), -1), v, (W, H), (1280, 800), white)
+    assert none[0].shape == (0, 2) and none[2].shape == (0, 3)
+    full = ctx.cam_proj_pts(np.zeros((H, W), np.int64), np.zeros((H, W), np.int64), (W, H), (1280, 800), None)
+    assert full[0].shape == (H * W, 2) and np.array_equal(full[0][:3], [[0, 0], [0, 1], [0, 2]])   # x-major
+
+
+def test_triangulate_random_vs_oracle(ctx, calib):
+    rng = np.random.default_rng(13)
+    M = 200_003
+    cam = np.stack([rng.integers(0, 1920, M), rng.integers(0, 1080, M)], 1).astype(np.float32)
+    proj = np.stack([rng.integers(0, 1920, M), rng.integers(0, 1080, M)], 1).astype(np.float32)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], (1920, 1080), (1920, 1080))
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    ctx.set_calibration(calib["cam_mtx"], calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    ref = oc.triangulate(cam, proj, calib["cam_mtx"], calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    got = ctx.triangulate(cam, proj)
+    fin = np.isfinite(ref).all(axis=0)
+    assert fin.mean() > 0.99 and np.array_equal(np.isfinite(got).all(axis=0), fin)
+    np.testing.assert_allclose(got[:, fin], ref[:, fin], rtol=XYZ_RTOL, atol=0)
+    rel = np.abs(got[:, fin] - ref[:, fin]) / np.maximum(np.abs(ref[:, fin]), 1e-12)
+    assert np.median(rel) < 1e-12
+    # the sqrt form agrees except where rays are nearly parallel to the baseline (ill-conditioned in both forms)
+    alg = ctx.triangulate(cam, proj, mode=1)
+    rel = np.abs(alg[:, fin] - ref[:, fin]) / np.maximum(np.abs(ref[:, fin]), 1e-12)
+    assert np.quantile(rel, 0.999) < XYZ_RTOL
+    # filter
+    col = rng.random((M, 3))
+    fp, fc = ctx.filter_3d_pts(ref, col, 0.5)
+    rp, rc = oc.filter_3d_pts(ref, col, 0.5)
+    assert np.array_equal(fp, rp) and np.array_equal(fc, rc)
+    e = ctx.filter_3d_pts(np.zeros((3, 0)), np.zeros((0, 3)), 0.5)
+    assert e[0].shape == (3, 0)
+
+
+def test_scan_dev_vs_oracle(ctx, calib):
+    N, H, W = 44, 96, 256
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=2)
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2] = W / 2, H / 2
+    K[0, 0] = K[1, 1] = 300.0
+    psize = (300, 200)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    hp, vp, ref = oc.scan_dense(st, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    stack = ctx.alloc(st.nbytes).upload(st)
+    xyz = ctx.alloc(H * W * 12)
+    cnt = ctx.alloc(8).zero()
+    maps = ctx.alloc(H * W * 4)
+    for mode in (0, 1):
+        cnt.zero()
+        ctx.scan_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, 0, psize, xyz.ptr, cnt.ptr, maps.at(0), maps.at(H * W * 2), mode=mode)
+        ctx.synchronize()
+        got = xyz.download((H, W, 3), np.float32)
+        ok = (hp != -1) & (vp != -1)
+        assert int(cnt.download((1,), np.uint64)[0]) == ok.sum() > 1000
+        assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, H * W * 2), vp)
+        assert np.isnan(got[~ok]).all() and np.isfinite(got[ok]).all()
+        np.testing.assert_allclose(got[ok], np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+    # band with row0 (multi-GPU shard): rows 32..64
+    cnt.zero()
+    ctx.scan_dev(stack.at(32 * W), 1, st.nbytes, H * W, N, 32, W, 32, psize, xyz.ptr, cnt.ptr, mode=0)
+    ctx.synchronize()
+    got = xyz.download((32, W, 3), np.float32)
+    okb = ok[32:64]
+    np.testing.assert_allclose(got[okb], np.moveaxis(ref, 0, -1)[32:64][okb], rtol=XYZ_RTOL, atol=0)
+    # row-major compaction of the dense band, keyed by linear pixel index
+    pts = ctx.alloc(32 * W * 12)
+    keys = ctx.alloc(32 * W * 4)
+    ctx.compact_dev(xyz.ptr, 32, W, 32, pts.ptr, keys.ptr, cnt.ptr)
+    ctx.synchronize()
+    m = int(cnt.download((1,), np.uint64)[0])
+    assert m == okb.sum()
+    k = keys.download((m,), np.uint32)
+    yy, xx = np.nonzero(okb)
+    assert np.array_equal(k, (yy + 32) * W + xx)
+    assert np.array_equal(pts.download((m, 3), np.float32), got[okb])
+    for b in (stack, xyz, cnt, maps, pts, keys):
+        b.free()
+
+
+def test_rccl_single_rank(ctx):
+    """nranks = 1 exercises library loading, communicator creation and every collective wrapper."""
+    from scanner import _native
+    uid = _native.Context.comm_unique_id()
+    ctx.comm_init(0, 1, uid)
+    try:
+        ctx.comm_barrier()
+        assert ctx.comm_allreduce_max(3.5) == 3.5
+        assert ctx.comm_allgather_i64(42) == [42]
+        src = ctx.alloc(1000).upload(np.arange(1000, dtype=np.uint8))
+        dst = ctx.alloc(1000).zero()
+        ctx.comm_allgatherv(src.ptr, dst.ptr, [1000], [0])
+        ctx.synchronize()
+        assert np.array_equal(dst.download((1000,), np.uint8), np.arange(1000, dtype=np.uint8))
+    finally:
+        ctx.comm_destroy()
