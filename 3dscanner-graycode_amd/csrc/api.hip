@@ -147,6 +147,9 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 8; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
+    if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
+    if (ctx->count_slots) (void)hipFree(ctx->count_slots);
     for (int i = 0; i < SLGC_MAX_EVENTS; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
@@ -343,6 +346,7 @@ extern "C" int slgc_set_calibration(slgc_ctx *ctx, const double cam_K[9], const 
     memcpy(c.T, T, sizeof c.T);
     c.t_len = sqrt(T[0] * T[0] + T[1] * T[1] + T[2] * T[2]);                                            // triangulate.py:89
     ctx->have_calib = true;
+    ++ctx->calib_ver;
     return SLGC_OK;
 }
 
@@ -601,7 +605,7 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     if (rc) return rc;
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
-    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 
@@ -614,7 +618,7 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     if (rc) return rc;
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null output");
-    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     DecodeGeom g;
     RunPtrs runs{};
     int e;

@@ -87,17 +87,11 @@ __device__ __forceinline__ void pixel_thresholds(int black, int white, int lmax,
     const double lg = t2 * b_inv;                            //       ... * b_inv
     const double ge = lg + (double)e;                        // L_g + eps (:172-182)
     const bool direct = ld > ge;
-    int tg;
-    if (!(ge < 255.0)) tg = 256;                             // also NaN
-    else if (ge < 0.0) tg = 0;
-    else tg = (int)ge + 1;
-    int tnd;
-    if (!(ld > 0.0)) tnd = 0;                                // also NaN
-    else if (ld > 1024.0) tnd = 256;
-    else {
-        tnd = (int)ceil(ld) - e;
-        tnd = tnd < 0 ? 0 : (tnd > 256 ? 256 : tnd);
-    }
+    // straight-line (no divergent branches): clamp in fp64, convert, fix the NaN case with a select
+    int tg = (int)fmin(fmax(floor(ge), -1.0), 255.0) + 1;     // floor(ge)+1 in [0, 256]
+    tg = (ge != ge) ? 256 : tg;                               // NaN: no x satisfies x > NaN
+    int tnd = (int)fmin(fmax(ceil(ld), 0.0), 1024.0) - e;     // NaN -> fmax(NaN, 0) = 0: no x satisfies x + e < NaN
+    tnd = min(max(tnd, 0), 256);
     tt = tnd | (tg << 16);
     cA = direct ? (e + 1) : kUnreachable;
 }
@@ -211,6 +205,359 @@ __global__ void __launch_bounds__(BLOCK) k_decode_fast(const FastArgs a)
     }
     store_i16<PX>(a.h + off, hv);
     store_i16<PX>(a.v + off, vv);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a-pk: the same integer-threshold algorithm, two pixels per 32-bit register (packed 16-bit lanes), branch-free,
+// all boolean work on the VALU (no lane-mask logic on the scalar unit).
+// ------------------------------------------------------------------------------------------
+//
+// A dword of a frame holds pixels p0..p3.  It is split into the pairs E = [p0, p2] and O = [p1, p3] (one v_perm /
+// v_and each), so every later instruction handles two pixels.  For a pair register X (values 0..255 per half):
+//     X + (0x8000 - t)   has bit 15 of a half set   <=>  x >= t          (threshold tests, t in 0..256)
+//     D = N - I          (v_pk_sub_i16)             ;    sign(D - c) = !r1 ;  sign(D + c - 1) = r2
+// and the rule table is evaluated on bit 15 / bit 31 with three-input boolean ops (v_bitop3_b32):
+//     bit   = (Nb & ~Ia) | (~S1 & (Na | ~Ib))                 (r4 | (r1 & ~r3))
+//     valid = (~S1 | (~Na & Ib)) | (S2 | (Nb & ~Ia))          (r1 | r3 | r2 | r4)
+// Code bits are shifted in LSB-first (acc = (acc >> 1) | bit15), so the column code walks k = L-1 .. 0 and the row
+// code k = 0 .. L-1.  Frames are fetched with buffer loads: per-lane 32-bit offset in a VGPR, per-frame offset in an
+// SGPR, hardware bounds check instead of a tail branch.
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+typedef short v2ss __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+struct PkArgs {
+    const uint8_t *run[SLGC_MAX_RUNS];
+    uint32_t plane_stride;   // bytes between frames (< 2^32 / N)
+    uint32_t npix;           // pixels in the band (multiple of PX handled here; ragged tail by the byte-wide kernel)
+    uint32_t run_bytes;      // (N-1)*plane_stride + npix : bounds of the read descriptor
+    int16_t *h;
+    int16_t *v;
+    DecodeGeom g;
+    int e;
+};
+
+__device__ __forceinline__ v2us as_us(uint32_t x) { return __builtin_bit_cast(v2us, x); }
+__device__ __forceinline__ v2ss as_ss(uint32_t x) { return __builtin_bit_cast(v2ss, x); }
+__device__ __forceinline__ uint32_t as_u(v2us x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t as_u(v2ss x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_us(a) + as_us(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_us(a) - as_us(b)); }
+__device__ __forceinline__ uint32_t pk_shr1(uint32_t a) { return as_u(as_us(a) >> (unsigned short)1); }
+__device__ __forceinline__ uint32_t even_pair(uint32_t w) { return w & 0x00ff00ffu; }                                  // [p0, p2]
+__device__ __forceinline__ uint32_t odd_pair(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c01u); }        // [p1, p3]
+
+template <int NW, int NT>
+struct Frame {
+    uint32_t w[NW];
+};
+
+template <int NW, int NT>
+__device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    Frame<NW, NT> f;
+    constexpr int aux = NT ? 2 : 0;
+    if constexpr (NW == 1) {
+        f.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux);
+    } else if constexpr (NW == 2) {
+        const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux);
+        f.w[0] = t.x; f.w[1] = t.y;
+    } else {
+        const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux);
+        f.w[0] = t.x; f.w[1] = t.y; f.w[2] = t.z; f.w[3] = t.w;
+    }
+    return f;
+}
+
+// One (normal, inverse) pair register through the rule table; updates the code-bit and validity accumulators.
+template <bool MULTI>
+__device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t C1, uint32_t C2,
+                                            uint32_t &accB, uint32_t &accV)
+{
+    const uint32_t Na = pk_add(N, KA), Nb = pk_add(N, KB), Ia = pk_add(I, KA), Ib = pk_add(I, KB);
+    const uint32_t D = pk_sub(N, I);
+    const uint32_t S1 = pk_sub(D, C1), S2 = pk_add(D, C2);
+    const uint32_t bit = (Nb & ~Ia) | (~S1 & (Na | ~Ib));
+    const uint32_t y = ~S1 | (~Na & Ib), z = S2 | (Nb & ~Ia);
+    accB = pk_shr1(accB) | (bit & 0x80008000u);
+    if constexpr (MULTI) accV = pk_shr1(accV) | ((y | z) & 0x80008000u);
+    else accV &= (y | z);
+}
+
+// ABL (timing-only diagnostic builds, results are wrong): 0 = real kernel; 1 = skip the 14 threshold-frame loads;
+// 2 = loads only (no classification arithmetic).
+template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0>
+__global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
+{
+    constexpr int NW = PX / 4;      // dwords per lane per frame
+    constexpr int NP = PX / 2;      // pixel-pair registers per lane
+    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
+    const uint32_t ps = a.plane_stride;
+    const int L = a.g.L;
+    uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { mB_h[p] = mB_v[p] = 0u; mV_h[p] = mV_v[p] = MULTI ? 0u : 0xffffffffu; }
+
+    for (int r = 0; r < a.g.n_runs; ++r) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[r], 0, a.run_bytes, 0x00020000);
+        uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
+        if constexpr (ABL != 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
+        } else {
+            const Frame<NW, 0> bl = load_frame<NW, 0>(rs, off, 0), wh = load_frame<NW, 0>(rs, off, ps);
+            Frame<NW, 0> hm[6], vm[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                hm[k] = load_frame<NW, 0>(rs, off, (uint32_t)a.g.hid[k] * ps);
+                vm[k] = load_frame<NW, 0>(rs, off, (uint32_t)a.g.vid[k] * ps);
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                uint32_t mx = hm[0].w[q], mn = vm[0].w[q];
+                uint32_t mxe = even_pair(mx), mxo = odd_pair(mx), mne = even_pair(mn), mno = odd_pair(mn);
+#pragma unroll
+                for (int k = 1; k < 6; ++k) {
+                    const uint32_t hw = hm[k].w[q], vw = vm[k].w[q];
+                    mxe = as_u(__builtin_elementwise_max(as_us(mxe), as_us(even_pair(hw))));      // :116
+                    mxo = as_u(__builtin_elementwise_max(as_us(mxo), as_us(odd_pair(hw))));
+                    mne = as_u(__builtin_elementwise_min(as_us(mne), as_us(even_pair(vw))));      // :117
+                    mno = as_u(__builtin_elementwise_min(as_us(mno), as_us(odd_pair(vw))));
+                }
+                int tt[4], cc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t mxp = (j & 1) ? mxo : mxe, mnp = (j & 1) ? mno : mne;
+                    const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
+                    const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
+                    const int black = (int)((bl.w[q] >> (8 * j)) & 0xffu), white = (int)((wh.w[q] >> (8 * j)) & 0xffu);
+                    pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
+                }
+                // pair registers: even = pixels (0, 2), odd = pixels (1, 3) of this dword
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int lo = par, hi = par + 2, p = 2 * q + par;
+                    const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
+                    const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
+                    KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
+                    KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
+                    C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
+                    C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
+                }
+            }
+        }
+        uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
+        // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
+        uint32_t s_hn = (uint32_t)(2 + 2 * (L - 1)) * ps, s_hi = (uint32_t)(2 + 2 * L + 2 * (L - 1)) * ps;
+        uint32_t s_vn = 3u * ps, s_vi = (uint32_t)(3 + 2 * L) * ps;
+#pragma unroll 2
+        for (int t = 0; t < L; ++t) {
+            const Frame<NW, NT> hn = load_frame<NW, NT>(rs, off, s_hn), hi = load_frame<NW, NT>(rs, off, s_hi);
+            const Frame<NW, NT> vn = load_frame<NW, NT>(rs, off, s_vn), vi = load_frame<NW, NT>(rs, off, s_vi);
+            s_hn -= 2 * ps; s_hi -= 2 * ps; s_vn += 2 * ps; s_vi += 2 * ps;
+            if constexpr (ABL == 2) {
+#pragma unroll
+                for (int q = 0; q < NW; ++q) { aB_h[2 * q] ^= hn.w[q] + hi.w[q]; aB_v[2 * q] ^= vn.w[q] + vi.w[q]; }
+            } else
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                classify_pk<MULTI>(even_pair(hn.w[q]), even_pair(hi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_h[2 * q], aV_h[2 * q]);
+                classify_pk<MULTI>(odd_pair(hn.w[q]), odd_pair(hi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_h[2 * q + 1], aV_h[2 * q + 1]);
+                classify_pk<MULTI>(even_pair(vn.w[q]), even_pair(vi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_v[2 * q], aV_v[2 * q]);
+                classify_pk<MULTI>(odd_pair(vn.w[q]), odd_pair(vi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_v[2 * q + 1], aV_v[2 * q + 1]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            mB_h[p] |= aB_h[p]; mB_v[p] |= aB_v[p];
+            if constexpr (MULTI) { mV_h[p] |= aV_h[p]; mV_v[p] |= aV_v[p]; }
+            else { mV_h[p] = aV_h[p]; mV_v[p] = aV_v[p]; }
+        }
+    }
+
+    // accumulators hold the L code bits in the top L bits of each half
+    const unsigned short sh = (unsigned short)(16 - L);
+    const uint32_t full = ((1u << L) - 1u) * 0x00010001u;
+    uint32_t oh[NP], ov[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t gh = as_u(as_us(mB_h[p]) >> sh), gv = as_u(as_us(mB_v[p]) >> sh);
+        uint32_t okh, okv;  // 0xffff per half where every code was classified
+        if constexpr (MULTI) {
+            const uint32_t vh = as_u(as_us(mV_h[p]) >> sh), vv = as_u(as_us(mV_v[p]) >> sh);
+            okh = as_u(as_ss(pk_add(vh ^ full, 0x7fff7fffu) ) >> (short)15);   // half != 0 -> bit15 set -> 0xffff = NOT ok
+            okv = as_u(as_ss(pk_add(vv ^ full, 0x7fff7fffu) ) >> (short)15);
+            okh = ~okh; okv = ~okv;
+        } else {
+            okh = as_u(as_ss(mV_h[p]) >> (short)15);
+            okv = as_u(as_ss(mV_v[p]) >> (short)15);
+        }
+        oh[p] = gray_to_binary_2x16(gh) | ~okh;     // undecodable -> 0xffff = -1 (:225-226)
+        ov[p] = gray_to_binary_2x16(gv) | ~okv;
+    }
+    // pairs back to pixel order: E = [p0, p2], O = [p1, p3]  ->  dwords [p0, p1], [p2, p3]
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
+    uint32_t wh_[2 * NW], wv_[2 * NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        wh_[2 * q] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x05040100u);
+        wh_[2 * q + 1] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x07060302u);
+        wv_[2 * q] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x05040100u);
+        wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
+    }
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW; q += 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wh_[2 * q], wh_[2 * q + 1], wh_[2 * q + 2], wh_[2 * q + 3]}, rh, off * 2u + 8u * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a-pks: K1a-pk specialised on the frame count at compile time (single run).  Every frame is read from HBM exactly
+// once: the 12 L_max/L_min frames stay in registers after the threshold phase and are classified from there, the
+// remaining frames are streamed (non-temporal), and the whole schedule is straight-line code.
+// ------------------------------------------------------------------------------------------
+template <int NF>
+struct StaticGeom {
+    static constexpr int L = (int)((double)(NF - 2) / 4.0);                 // decode_codes.py:149
+    static constexpr double plf = (double)(NF - 2) / 4.0;                   // decode_codes.py:109
+    static constexpr int thr[12] = {                                        // absolute frame ids (:110-111, +2)
+        2 + (int)(unsigned char)(2 * plf - 2), 2 + (int)(unsigned char)(2 * plf - 4), 2 + (int)(unsigned char)(2 * plf - 6),
+        2 + (int)(unsigned char)(4 * plf - 2), 2 + (int)(unsigned char)(4 * plf - 4), 2 + (int)(unsigned char)(4 * plf - 6),
+        2 + 1, 2 + 3, 2 + 5,
+        2 + (int)(unsigned char)(2 * plf + 1), 2 + (int)(unsigned char)(2 * plf + 3), 2 + (int)(unsigned char)(2 * plf + 5)};
+    static constexpr int slot(int f)
+    {
+        for (int s = 0; s < 12; ++s)
+            if (thr[s] == f) return s;
+        return -1;
+    }
+};
+
+template <int NF, int PX, int BLOCK, int NT>
+__global__ void __launch_bounds__(BLOCK) k_decode_pks(const PkArgs a)
+{
+    using G = StaticGeom<NF>;
+    constexpr int L = G::L;
+    constexpr int NW = PX / 4, NP = PX / 2;
+    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
+    const uint32_t ps = a.plane_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[0], 0, a.run_bytes, 0x00020000);
+
+    Frame<NW, NT> kept[12];
+    const Frame<NW, NT> bl = load_frame<NW, NT>(rs, off, 0), wh = load_frame<NW, NT>(rs, off, ps);
+#pragma unroll
+    for (int s = 0; s < 12; ++s) kept[s] = load_frame<NW, NT>(rs, off, (uint32_t)G::thr[s] * ps);
+
+    uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        uint32_t mxe = even_pair(kept[0].w[q]), mxo = odd_pair(kept[0].w[q]);
+        uint32_t mne = even_pair(kept[6].w[q]), mno = odd_pair(kept[6].w[q]);
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            mxe = as_u(__builtin_elementwise_max(as_us(mxe), as_us(even_pair(kept[k].w[q]))));          // :116
+            mxo = as_u(__builtin_elementwise_max(as_us(mxo), as_us(odd_pair(kept[k].w[q]))));
+            mne = as_u(__builtin_elementwise_min(as_us(mne), as_us(even_pair(kept[6 + k].w[q]))));      // :117
+            mno = as_u(__builtin_elementwise_min(as_us(mno), as_us(odd_pair(kept[6 + k].w[q]))));
+        }
+        int tt[4], cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t mxp = (j & 1) ? mxo : mxe, mnp = (j & 1) ? mno : mne;
+            const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
+            const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
+            const int black = (int)((bl.w[q] >> (8 * j)) & 0xffu), white = (int)((wh.w[q] >> (8 * j)) & 0xffu);
+            pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
+        }
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int lo = par, hi = par + 2, p = 2 * q + par;
+            const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
+            const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
+            KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
+            KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
+            C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
+            C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
+        }
+    }
+
+    uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = 0xffffffffu; }
+
+    // pass 0: pairs with an operand still in registers (frees them early); pass 1: streamed pairs
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+#pragma unroll
+            for (int code = 0; code < 2; ++code) {
+                // column code (0): bit k = L-1-t ; row code (1): bit k = t ; either way its weight is 2^t
+                const int k = code == 0 ? (L - 1 - t) : t;
+                const int fn = 2 + 2 * k + code, fi = fn + 2 * L;
+                const int sn = G::slot(fn), si = G::slot(fi);
+                if (((sn >= 0) || (si >= 0)) != (pass == 0)) continue;
+                Frame<NW, NT> nf, inf;
+                if (sn >= 0) nf = kept[sn]; else nf = load_frame<NW, NT>(rs, off, (uint32_t)fn * ps);
+                if (si >= 0) inf = kept[si]; else inf = load_frame<NW, NT>(rs, off, (uint32_t)fi * ps);
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        const int p = 2 * q + par;
+                        const uint32_t Nn = par ? odd_pair(nf.w[q]) : even_pair(nf.w[q]);
+                        const uint32_t Ii = par ? odd_pair(inf.w[q]) : even_pair(inf.w[q]);
+                        const uint32_t Na = pk_add(Nn, KA[p]), Nb = pk_add(Nn, KB[p]), Ia = pk_add(Ii, KA[p]), Ib = pk_add(Ii, KB[p]);
+                        const uint32_t D = pk_sub(Nn, Ii);
+                        const uint32_t S1 = pk_sub(D, C1[p]), S2 = pk_add(D, C2[p]);
+                        const uint32_t bit = (Nb & ~Ia) | (~S1 & (Na | ~Ib));
+                        const uint32_t y = ~S1 | (~Na & Ib), z = S2 | (Nb & ~Ia);
+                        const uint32_t placed = as_u(as_us(bit & 0x80008000u) >> (unsigned short)(15 - t));   // weight 2^t
+                        if (code == 0) { aB_h[p] |= placed; aV_h[p] &= (y | z); }
+                        else { aB_v[p] |= placed; aV_v[p] &= (y | z); }
+                    }
+                }
+            }
+        }
+    }
+
+    uint32_t oh[NP], ov[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t okh = as_u(as_ss(aV_h[p]) >> (short)15), okv = as_u(as_ss(aV_v[p]) >> (short)15);
+        oh[p] = gray_to_binary_2x16(aB_h[p]) | ~okh;
+        ov[p] = gray_to_binary_2x16(aB_v[p]) | ~okv;
+    }
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
+    uint32_t wh_[2 * NW], wv_[2 * NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        wh_[2 * q] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x05040100u);
+        wh_[2 * q + 1] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x07060302u);
+        wv_[2 * q] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x05040100u);
+        wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
+    }
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW; q += 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wh_[2 * q], wh_[2 * q + 1], wh_[2 * q + 2], wh_[2 * q + 3]}, rh, off * 2u + 8u * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,7 +709,38 @@ bool decode_fast_eligible(double eps, int *e_out)
     return true;
 }
 
-// variant: 0 = auto; otherwise PX*1000 + BLOCK (e.g. 16256, 8064) for sweeps.
+template <int PX, int BLOCK, int NT>
+static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
+{
+    const uint32_t groups = a.npix / PX;
+    if (groups == 0) return SLGC_OK;
+    const unsigned blocks = (groups + BLOCK - 1) / BLOCK;
+    if (abl == 1)
+        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+    else if (abl == 2)
+        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+    else if (a.g.n_runs > 1)
+        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+template <int NF, int PX, int BLOCK, int NT>
+static int launch_pks_t(slgc_ctx *ctx, const PkArgs &a)
+{
+    const uint32_t groups = a.npix / PX;
+    if (groups == 0) return SLGC_OK;
+    hipLaunchKernelGGL((k_decode_pks<NF, PX, BLOCK, NT>), dim3((groups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+static bool pks_built(int N) { return N == 42 || N == 44 || N == 46; }
+
+// variant: 0 = library default; otherwise ABL*10000000 + NT*1000000 + ALG*100000 + PX*1000 + BLOCK, e.g. 104128 = packed-16 kernel,
+// 4 pixels per lane, 128-thread workgroups; ALG 0 = lane-mask (v_cmp) kernel, 1 = packed-16 kernel; NT = non-temporal loads.
 int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, int rows, int W, int e,
                        int16_t *d_h, int16_t *d_v, int variant)
 {
@@ -378,26 +756,50 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
         a.run[r] = (const uint8_t *)runs.p[r];
         align_or |= (uintptr_t)runs.p[r];
     }
-    int px = (align_or % 16 == 0) ? 16 : (align_or % 8 == 0) ? 8 : (align_or % 4 == 0) ? 4 : 1;
-    int block = 256;
-    if (variant > 0) {
-        const int want_px = variant / 1000;
-        if (want_px != 16 && want_px != 8 && want_px != 4 && want_px != 1) return slgc_fail(ctx, SLGC_EINVAL, "bad variant %d", variant);
-        if (want_px > px) return slgc_fail(ctx, SLGC_EINVAL, "variant %d needs %d-byte alignment", variant, want_px);
-        px = want_px;
-        block = variant % 1000;
-        if (block != 64 && block != 128 && block != 256) return slgc_fail(ctx, SLGC_EINVAL, "bad variant %d", variant);
-    } else if (px == 16) {
-        px = 8;  // measured default, see DESIGN.md (sweep in profiles/)
+    const int max_px = (align_or % 16 == 0) ? 16 : (align_or % 8 == 0) ? 8 : (align_or % 4 == 0) ? 4 : 1;
+    const bool fits32 = (uint64_t)g.N * plane_stride + npix < 0xfffffff0ull && npix < 0x7fffffffull;
+    if (variant == 0) {
+        if (max_px >= 4 && fits32) variant = 1104128;   // packed-16 kernel, NT loads, 4 px/lane, 128-thread WGs: measured best
+        else variant = max_px * 1000 + 256;
     }
+    const int abl = variant / 10000000;
+    variant %= 10000000;
+    const int nt = variant / 1000000, alg = (variant / 100000) % 10, px = (variant / 1000) % 100, block = variant % 1000;
+    if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 2 || nt > 1)
+        return slgc_fail(ctx, SLGC_EINVAL, "bad variant %d", variant);
+    if (px > max_px) return slgc_fail(ctx, SLGC_EINVAL, "variant %d needs %d-byte alignment", variant, px);
+    if (alg >= 1 && (!fits32 || px == 1)) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: band too large for 32-bit offsets or px=1", variant);
     const size_t main_pix = npix / px * px;
-    int rc;
-#define SLGC_CASE(P, B) \
-    if (px == P && block == B) { rc = launch_fast_t<P, B>(ctx, a, main_pix); } else
-    SLGC_CASE(16, 256) SLGC_CASE(16, 128) SLGC_CASE(16, 64) SLGC_CASE(8, 256) SLGC_CASE(8, 128) SLGC_CASE(8, 64)
-    SLGC_CASE(4, 256) SLGC_CASE(4, 128) SLGC_CASE(4, 64) SLGC_CASE(1, 256) { rc = launch_fast_t<1, 256>(ctx, a, main_pix); }
+    int rc = SLGC_EINVAL;
+    if (alg == 2 && (g.n_runs != 1 || !pks_built(g.N)))
+        return slgc_fail(ctx, SLGC_EINVAL, "variant %d: the frame-count-specialised kernel is built for single runs of 42/44/46 frames", variant);
+    if (alg >= 1) {
+        PkArgs b{};
+        for (int r = 0; r < g.n_runs; ++r) b.run[r] = a.run[r];
+        b.plane_stride = (uint32_t)plane_stride;
+        b.npix = (uint32_t)main_pix;
+        b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + main_pix);
+        b.h = d_h; b.v = d_v; b.g = g; b.e = e;
+#define SLGC_PKS(NF, P, B, T) if (alg == 2 && g.N == NF && px == P && block == B && nt == T) rc = launch_pks_t<NF, P, B, T>(ctx, b);
+#define SLGC_PKS3(P, B, T) SLGC_PKS(42, P, B, T) SLGC_PKS(44, P, B, T) SLGC_PKS(46, P, B, T)
+        SLGC_PKS3(4, 128, 1) SLGC_PKS3(4, 256, 1) SLGC_PKS3(8, 128, 1) SLGC_PKS3(8, 256, 1) SLGC_PKS3(4, 256, 0) SLGC_PKS3(8, 256, 0)
+        SLGC_PKS3(4, 64, 1) SLGC_PKS3(8, 64, 1)
+#undef SLGC_PKS3
+#undef SLGC_PKS
+#define SLGC_PK(P, B, T) if (alg == 1 && px == P && block == B && nt == T) rc = launch_pk_t<P, B, T>(ctx, b, abl);
+        SLGC_PK(4, 64, 0) SLGC_PK(4, 128, 0) SLGC_PK(4, 256, 0) SLGC_PK(8, 64, 0) SLGC_PK(8, 128, 0) SLGC_PK(8, 256, 0)
+        SLGC_PK(16, 64, 0) SLGC_PK(16, 128, 0) SLGC_PK(16, 256, 0)
+        SLGC_PK(4, 64, 1) SLGC_PK(4, 128, 1) SLGC_PK(4, 256, 1) SLGC_PK(8, 64, 1) SLGC_PK(8, 128, 1) SLGC_PK(8, 256, 1)
+        SLGC_PK(16, 64, 1) SLGC_PK(16, 128, 1) SLGC_PK(16, 256, 1)
+#undef SLGC_PK
+    } else {
+        if (nt) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: NT only with the packed kernel", variant);
+#define SLGC_CASE(P, B) if (px == P && block == B) rc = launch_fast_t<P, B>(ctx, a, main_pix);
+        SLGC_CASE(16, 256) SLGC_CASE(16, 128) SLGC_CASE(16, 64) SLGC_CASE(8, 256) SLGC_CASE(8, 128) SLGC_CASE(8, 64)
+        SLGC_CASE(4, 256) SLGC_CASE(4, 128) SLGC_CASE(4, 64) SLGC_CASE(1, 256)
 #undef SLGC_CASE
-    if (rc) return rc;
+    }
+    if (rc) return rc == SLGC_EINVAL ? slgc_fail(ctx, SLGC_EINVAL, "variant %d not built", variant) : rc;
     if (main_pix < npix) {  // ragged tail (< px pixels): byte-wide groups
         FastArgs t = a;
         for (int r = 0; r < g.n_runs; ++r) t.run[r] = a.run[r] + main_pix;

@@ -48,6 +48,12 @@ struct slgc_ctx {
     // calibration
     bool have_calib;
     Calib calib;
+    unsigned calib_ver;
+    // ray tables (triangulate.hip), rebuilt when the calibration or the geometry changes
+    void *lut_cam, *lut_proj;
+    void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
+    unsigned lut_cam_ver, lut_proj_ver;
+    int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h;
     // results kept on the device between *_count and *_fetch
     int64_t pend_M;
     size_t pend_npix;

@@ -15,6 +15,11 @@
 // NumPy performs (:90 and the norm in :92) are reproduced bit for bit.
 #include "slgc_internal.h"
 
+int launch_triangulate_maps_direct(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, size_t first, int W, int row0,
+                                   int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
+static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int W, int row0, int rows,
+                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count);
+
 namespace {
 
 struct Ray2 {
@@ -62,6 +67,34 @@ struct Xyz {
     double x, y, z;
 };
 
+// Valid-pixel counting: a single counter word serialises at the memory side (~11 ns per atomic, 48k waves = 0.5 ms),
+// so each workgroup adds once into one of kCountSlots words on separate 128-byte lines; k_count_finish folds them.
+constexpr int kCountSlots = 256;
+constexpr int kCountStride = 16;  // in 8-byte words
+
+__device__ __forceinline__ void block_count_add(unsigned long long *slots, unsigned n)
+{
+    __shared__ unsigned wsum[4];
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(slots + (size_t)(blockIdx.x % kCountSlots) * kCountStride, (unsigned long long)t);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_count_finish(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long v = slots[(size_t)threadIdx.x * kCountStride];
+    slots[(size_t)threadIdx.x * kCountStride] = 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *total += part[0] + part[1] + part[2] + part[3];
+}
+
 // triangulate.py:86-95 for one correspondence (cam/proj are the float32 normalised points).
 template <int MODE>
 __device__ __forceinline__ Xyz law_of_sines(Ray2 cam, Ray2 prj, const double (&T)[3], double t_len)
@@ -102,7 +135,7 @@ __global__ void __launch_bounds__(256) k_triangulate_list(const Calib c_calib, c
 // One pixel per lane, lanes along x.  XYZ is staged through LDS so the 12-byte records leave as whole dwords.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_triangulate_maps(const Calib c_calib, const int16_t *__restrict__ h,
-                                                          const int16_t *__restrict__ v, size_t npix,
+                                                          const int16_t *__restrict__ v, size_t npix, size_t first,
                                                           int W, int row0, int proj_w, int proj_h, float *__restrict__ xyz,
                                                           unsigned long long *__restrict__ count)
 {
@@ -115,7 +148,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps(const Calib c_calib, c
         const int hv = h[p], vv = v[p];
         ok = !(hv == -1 || vv == -1);                                         // triangulate.py:56
         if (ok) {
-            const int x = (int)(p % (size_t)W), y = row0 + (int)(p / (size_t)W);
+            const int x = (int)((first + p) % (size_t)W), y = row0 + (int)((first + p) / (size_t)W);
             const float pu = (float)min(proj_w - 1, hv), pv = (float)min(proj_h - 1, vv);   // :60-61
             const Ray2 a = undistort_point((float)x, (float)y, c_calib.cam_k, c_calib.cam_d, c_calib.R);
             const Ray2 b = undistort_point(pu, pv, c_calib.proj_k, c_calib.proj_d, nullptr);
@@ -126,11 +159,77 @@ __global__ void __launch_bounds__(256) k_triangulate_maps(const Calib c_calib, c
     stage[3 * threadIdx.x] = X;
     stage[3 * threadIdx.x + 1] = Y;
     stage[3 * threadIdx.x + 2] = Z;
-    const unsigned long long m = __ballot(ok);
-    if (count && (threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+    if (count) block_count_add(count, ok ? 1u : 0u);
     __syncthreads();
     const size_t nfl = min((size_t)768, (npix - base) * 3);
     for (size_t i = threadIdx.x; i < nfl; i += 256) xyz[base * 3 + i] = stage[i];
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ray tables.  Both undistortPoints calls of triangulate.py:84-85 see only integer pixel coordinates on the dense
+// path (camera pixel (x, y); projector pixel (min(w-1,h), min(h-1,v))), and their float32 results depend only on the
+// calibration -- not on the scan.  They are therefore evaluated once per calibration with the exact fp64 routine above
+// and kept in HBM: cam table [rows][W] float2 (8 B/pixel, streamed), projector table [proj_h][proj_w] float2 (gathered,
+// L2 / Infinity-Cache resident).  The per-scan kernel is then bandwidth-shaped instead of fp64-divide-shaped, and the
+// float32 ray components are bit-identical to computing them in place.
+__global__ void __launch_bounds__(256) k_build_cam_lut(const Calib c, float2 *__restrict__ lut, int W, int row0, size_t npix)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const Ray2 a = undistort_point((float)(int)(p % (size_t)W), (float)(row0 + (int)(p / (size_t)W)), c.cam_k, c.cam_d, c.R);
+    lut[p] = make_float2(a.x, a.y);
+}
+
+__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, size_t npix)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const Ray2 b = undistort_point((float)(int)(p % (size_t)proj_w), (float)(int)(p / (size_t)proj_w), c.proj_k, c.proj_d, nullptr);
+    lut[p] = make_float2(b.x, b.y);
+}
+
+struct TriConst {
+    double T[3];
+    double t_len;
+};
+
+// Four pixels per lane (8-byte map loads, 32-byte ray loads, 48-byte XYZ stores).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc, const int16_t *__restrict__ h,
+                                                              const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
+                                                              const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
+                                                              int proj_h, float *__restrict__ xyz,
+                                                              unsigned long long *__restrict__ count)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned nvalid = 0;
+    if (g < ngroups) {
+        const uint2 hw = reinterpret_cast<const uint2 *>(h)[g], vw = reinterpret_cast<const uint2 *>(v)[g];
+        const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
+        const float cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+        const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
+        float out[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hv = (int)(short)(hq[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vq[j >> 1] >> (16 * (j & 1)));
+            const bool ok = !(hv == -1 || vv == -1);                                  // triangulate.py:56
+            float X = __builtin_nanf(""), Y = X, Z = X;
+            if (ok) {
+                const int pu = min(proj_w - 1, hv), pv = min(proj_h - 1, vv);         // :60-61
+                const float2 pr = proj_lut[(size_t)pv * proj_w + pu];
+                const Xyz r = law_of_sines<MODE>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
+                X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
+                ++nvalid;
+            }
+            out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * g;
+        dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+        dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+    }
+    if (count) block_count_add(count, nvalid);
 }
 
 }  // namespace
@@ -147,18 +246,103 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
     return SLGC_OK;
 }
 
+// Build (or reuse) the ray tables for this calibration / geometry.
+static int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
+{
+    const size_t npix = (size_t)rows * W, nproj = (size_t)proj_w * proj_h;
+    if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows)) {
+        if (ctx->lut_cam) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->lut_cam));
+            ctx->lut_cam = nullptr;
+        }
+        if (hipMalloc(&ctx->lut_cam, npix * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera ray table");
+        hipLaunchKernelGGL(k_build_cam_lut, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)ctx->lut_cam, W,
+                           row0, npix);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
+    }
+    if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h)) {
+        if (ctx->lut_proj) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->lut_proj));
+            ctx->lut_proj = nullptr;
+        }
+        if (hipMalloc(&ctx->lut_proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
+        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib,
+                           (float2 *)ctx->lut_proj, proj_w, nproj);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h;
+    }
+    return SLGC_OK;
+}
+
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
                             int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
 {
     const size_t npix = (size_t)rows * W;
     if (npix == 0) return SLGC_OK;
+    if (proj_w < 1 || proj_h < 1) return slgc_fail(ctx, SLGC_EINVAL, "bad projector size");
+    unsigned long long *slots = nullptr;
+    if (d_count) {
+        if (!ctx->count_slots) {
+            HIP_TRY(ctx, hipMalloc(&ctx->count_slots, (size_t)kCountSlots * kCountStride * 8));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->count_slots, 0, (size_t)kCountSlots * kCountStride * 8, ctx->stream));
+        }
+        slots = (unsigned long long *)ctx->count_slots;
+    }
+    const bool direct = (mode & SLGC_TRI_DIRECT) != 0;
+    mode &= 1;
+    int rc = launch_triangulate_maps_body(ctx, d_h, d_v, npix, W, row0, rows, proj_w, proj_h, mode, direct, d_xyz, slots);
+    if (rc) return rc;
+    if (d_count) {
+        hipLaunchKernelGGL(k_count_finish, dim3(1), dim3(256), 0, ctx->stream, slots, d_count);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return SLGC_OK;
+}
+
+static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int W, int row0, int rows,
+                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count)
+{
+    const bool vec_ok = !direct && (((uintptr_t)d_h | (uintptr_t)d_v) % 8 == 0) && ((uintptr_t)d_xyz % 16 == 0) && (size_t)proj_w * proj_h < (1u << 28);
+    if (vec_ok && npix >= 4) {
+        int rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
+        if (rc) return rc;
+        TriConst tc;
+        memcpy(tc.T, ctx->calib.T, sizeof tc.T);
+        tc.t_len = ctx->calib.t_len;
+        const size_t groups = npix / 4;
+        const unsigned blocks = (unsigned)((groups + 255) / 256);
+        if (mode == SLGC_TRI_EXACT)
+            hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, d_xyz, d_count);
+        else
+            hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, d_xyz, d_count);
+        HIP_TRY(ctx, hipGetLastError());
+        const size_t done = groups * 4;
+        if (done == npix) return SLGC_OK;
+        // ragged tail (< 4 pixels): direct-evaluation kernel on the remainder
+        const int x0 = (int)(done % (size_t)W);
+        (void)x0;
+        return launch_triangulate_maps_direct(ctx, d_h + done, d_v + done, npix - done, done, W, row0, proj_w, proj_h, mode, d_xyz + 3 * done, d_count);
+    }
+    return launch_triangulate_maps_direct(ctx, d_h, d_v, npix, 0, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
+}
+
+// Direct evaluation (no tables): used for misaligned buffers and ragged tails.  first = linear index of d_h[0] in the band.
+int launch_triangulate_maps_direct(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, size_t first, int W, int row0,
+                                   int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
+{
+    if (npix == 0) return SLGC_OK;
     const unsigned blocks = (unsigned)((npix + 255) / 256);
     if (mode == SLGC_TRI_EXACT)
-        hipLaunchKernelGGL(k_triangulate_maps<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->calib, d_h, d_v, npix, W, row0, proj_w,
-                           proj_h, d_xyz, d_count);
-    else
-        hipLaunchKernelGGL(k_triangulate_maps<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->calib, d_h, d_v, npix, W, row0,
+        hipLaunchKernelGGL(k_triangulate_maps<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->calib, d_h, d_v, npix, first, W, row0,
                            proj_w, proj_h, d_xyz, d_count);
+    else
+        hipLaunchKernelGGL(k_triangulate_maps<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->calib, d_h, d_v, npix, first, W,
+                           row0, proj_w, proj_h, d_xyz, d_count);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

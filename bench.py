@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_4096x3000x44", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="algebraic", choices=["algebraic", "exact"])
+    ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input stacks rotated between steps")
@@ -128,7 +129,7 @@ def main():
         sys.exit(f"image height {cam_h} not divisible by {G} GPUs")
     rows = cam_h // G
     row0 = rank * rows
-    mode = _native.TRI_ALGEBRAIC if args.mode == "algebraic" else _native.TRI_EXACT
+    mode = (_native.TRI_ALGEBRAIC if args.mode == "algebraic" else _native.TRI_EXACT) | (2 if args.tri == "direct" else 0)
 
     ctx = _native.Context(local_rank)
     calib = calibration(cam_w, cam_h, proj_w, proj_h)
@@ -212,7 +213,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
                                    + ("" if G == 1 else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
-                       "rows_per_gpu": rows, "triangulation": args.mode, "input_buffers_rotated": len(stacks),
+                       "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks),
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
                                   + ("" if G == 1 else "; compacted XYZ+key all-gathered to every rank")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

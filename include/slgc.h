@@ -43,7 +43,11 @@ enum {
 
 enum { SLGC_U8 = 0, SLGC_F64 = 1 };
 enum { SLGC_ORDER_X = 0 /* reference scan order, triangulate.py:52-53 */, SLGC_ORDER_ROW = 1 };
-enum { SLGC_TRI_EXACT = 0 /* acos/sin as triangulate.py:91-94 */, SLGC_TRI_ALGEBRAIC = 1 /* sqrt form */ };
+enum {
+    SLGC_TRI_EXACT = 0,     /* acos/sin as triangulate.py:91-94 */
+    SLGC_TRI_ALGEBRAIC = 1, /* algebraically identical sqrt form */
+    SLGC_TRI_DIRECT = 2     /* flag for the dense (_dev) path: evaluate undistortPoints per pixel instead of the ray tables */
+};
 
 typedef struct slgc_ctx slgc_ctx;
 

@@ -157,7 +157,8 @@ def dev_decode(ctx, st_runs, variant=0, band=None, eps=1):
     return h, v
 
 
-@pytest.mark.parametrize("variant", [0, 16256, 16128, 16064, 8256, 8128, 8064, 4256, 4128, 4064, 1256])
+@pytest.mark.parametrize("variant", [0, 16256, 16128, 16064, 8256, 8128, 8064, 4256, 4128, 4064, 1256,
+                                     104064, 104128, 104256, 108064, 108128, 108256, 116128, 1104128, 1108256, 1116256])
 def test_decode_dev_variants(ctx, variant):
     rng = np.random.default_rng(9)
     st = rng.integers(0, 256, (2, 44, 96, 256), dtype=np.uint8)
@@ -169,6 +170,23 @@ def test_decode_dev_variants(ctx, variant):
     rb = oc.decode(st[:, :, 32:80])
     h, v = dev_decode(ctx, st, variant, band=(32, 80))
     assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
+
+
+@pytest.mark.parametrize("N", [42, 44, 46])
+@pytest.mark.parametrize("variant", [1204064, 1204128, 1204256, 1208064, 1208128, 1208256, 204256, 208256])
+def test_decode_dev_frame_count_specialised(ctx, N, variant):
+    """K1a-pks: one HBM read per byte, frame count fixed at compile time (single run)."""
+    rng = np.random.default_rng(N)
+    for st in (rng.integers(0, 256, (1, N, 72, 200), dtype=np.uint8), onp.synth_scene(N, 72, 200, seed=5)[None]):
+        st[0, :, :5, :11] = 0
+        ref = oc.decode(st)
+        h, v = dev_decode(ctx, st, variant)
+        assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1])
+        rb = oc.decode(st[:, :, 16:56])
+        h, v = dev_decode(ctx, st, variant, band=(16, 56))
+        assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
+    with pytest.raises(ValueError):
+        dev_decode(ctx, np.zeros((2, N, 8, 64), np.uint8), variant)          # multi-run goes to the generic packed kernel
 
 
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
