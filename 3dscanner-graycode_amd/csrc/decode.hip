@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
     for (int r = 0; r < a.g.n_runs; ++r) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[r], 0, a.run_bytes, 0x00020000);
         uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
-        if constexpr (ABL != 0) {
+        if constexpr (ABL == 1 || ABL == 2) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
         } else {
@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
                     const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
                     const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
                     const int black = (int)((bl.w[q] >> (8 * j)) & 0xffu), white = (int)((wh.w[q] >> (8 * j)) & 0xffu);
-                    pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
+                    if constexpr (ABL == 3) { tt[j] = ((lmax - lmin) & 0xff) | ((black + white) << 15 & 0xff0000); cc[j] = a.e + 1; }
+                    else pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
                 }
                 // pair registers: even = pixels (0, 2), odd = pixels (1, 3) of this dword
 #pragma unroll
@@ -561,6 +562,111 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pks(const PkArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// K1a-pkr: frame count fixed at compile time, the whole pixel column register-resident.  All NF frame loads of a lane are
+// issued back to back (NF x PX bytes in flight per lane), then thresholds and classification run out of registers.  Each
+// byte is read from HBM exactly once and nothing is re-read through L2.  MINW = __launch_bounds__ waves/SIMD hint.
+// ------------------------------------------------------------------------------------------
+template <int NF, int PX, int BLOCK, int NT, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_decode_pkr(const PkArgs a)
+{
+    using G = StaticGeom<NF>;
+    constexpr int L = G::L;
+    constexpr int NW = PX / 4, NP = PX / 2;
+    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
+    const uint32_t ps = a.plane_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[0], 0, a.run_bytes, 0x00020000);
+
+    Frame<NW, NT> fr[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fr[f] = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
+
+    uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        uint32_t mxe = even_pair(fr[G::thr[0]].w[q]), mxo = odd_pair(fr[G::thr[0]].w[q]);
+        uint32_t mne = even_pair(fr[G::thr[6]].w[q]), mno = odd_pair(fr[G::thr[6]].w[q]);
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            mxe = as_u(__builtin_elementwise_max(as_us(mxe), as_us(even_pair(fr[G::thr[k]].w[q]))));          // :116
+            mxo = as_u(__builtin_elementwise_max(as_us(mxo), as_us(odd_pair(fr[G::thr[k]].w[q]))));
+            mne = as_u(__builtin_elementwise_min(as_us(mne), as_us(even_pair(fr[G::thr[6 + k]].w[q]))));      // :117
+            mno = as_u(__builtin_elementwise_min(as_us(mno), as_us(odd_pair(fr[G::thr[6 + k]].w[q]))));
+        }
+        int tt[4], cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t mxp = (j & 1) ? mxo : mxe, mnp = (j & 1) ? mno : mne;
+            const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
+            const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
+            const int black = (int)((fr[0].w[q] >> (8 * j)) & 0xffu), white = (int)((fr[1].w[q] >> (8 * j)) & 0xffu);
+            pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
+        }
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int lo = par, hi = par + 2, p = 2 * q + par;
+            const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
+            const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
+            KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
+            KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
+            C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
+            C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
+        }
+    }
+
+    uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = 0xffffffffu; }
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+#pragma unroll
+        for (int code = 0; code < 2; ++code) {
+            const int k = code == 0 ? (L - 1 - t) : t;            // either way the bit's weight is 2^t
+            const int fn = 2 + 2 * k + code, fi = fn + 2 * L;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int p = 2 * q + par;
+                    const uint32_t Nn = par ? odd_pair(fr[fn].w[q]) : even_pair(fr[fn].w[q]);
+                    const uint32_t Ii = par ? odd_pair(fr[fi].w[q]) : even_pair(fr[fi].w[q]);
+                    if (code == 0) classify_pk<false>(Nn, Ii, KA[p], KB[p], C1[p], C2[p], aB_h[p], aV_h[p]);
+                    else classify_pk<false>(Nn, Ii, KA[p], KB[p], C1[p], C2[p], aB_v[p], aV_v[p]);
+                }
+            }
+        }
+    }
+
+    const unsigned short sh = (unsigned short)(16 - L);
+    uint32_t oh[NP], ov[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t okh = as_u(as_ss(aV_h[p]) >> (short)15), okv = as_u(as_ss(aV_v[p]) >> (short)15);
+        oh[p] = gray_to_binary_2x16(as_u(as_us(aB_h[p]) >> sh)) | ~okh;
+        ov[p] = gray_to_binary_2x16(as_u(as_us(aB_v[p]) >> sh)) | ~okv;
+    }
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
+    uint32_t wh_[2 * NW], wv_[2 * NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        wh_[2 * q] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x05040100u);
+        wh_[2 * q + 1] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x07060302u);
+        wv_[2 * q] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x05040100u);
+        wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
+    }
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW; q += 2) {
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wh_[2 * q], wh_[2 * q + 1], wh_[2 * q + 2], wh_[2 * q + 3]}, rh, off * 2u + 8u * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K1b: literal fp64 kernel (API parity)
 // ------------------------------------------------------------------------------------------
 
@@ -719,6 +825,8 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
         hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
     else if (abl == 2)
         hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+    else if (abl == 3)
+        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
     else if (a.g.n_runs > 1)
         hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
     else
@@ -733,6 +841,16 @@ static int launch_pks_t(slgc_ctx *ctx, const PkArgs &a)
     const uint32_t groups = a.npix / PX;
     if (groups == 0) return SLGC_OK;
     hipLaunchKernelGGL((k_decode_pks<NF, PX, BLOCK, NT>), dim3((groups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+template <int NF, int PX, int BLOCK, int NT, int MINW>
+static int launch_pkr_t(slgc_ctx *ctx, const PkArgs &a)
+{
+    const uint32_t groups = a.npix / PX;
+    if (groups == 0) return SLGC_OK;
+    hipLaunchKernelGGL((k_decode_pkr<NF, PX, BLOCK, NT, MINW>), dim3((groups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -765,13 +883,13 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
     const int abl = variant / 10000000;
     variant %= 10000000;
     const int nt = variant / 1000000, alg = (variant / 100000) % 10, px = (variant / 1000) % 100, block = variant % 1000;
-    if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 2 || nt > 1)
+    if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 4 || nt > 1)
         return slgc_fail(ctx, SLGC_EINVAL, "bad variant %d", variant);
     if (px > max_px) return slgc_fail(ctx, SLGC_EINVAL, "variant %d needs %d-byte alignment", variant, px);
     if (alg >= 1 && (!fits32 || px == 1)) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: band too large for 32-bit offsets or px=1", variant);
     const size_t main_pix = npix / px * px;
     int rc = SLGC_EINVAL;
-    if (alg == 2 && (g.n_runs != 1 || !pks_built(g.N)))
+    if (alg >= 2 && (g.n_runs != 1 || !pks_built(g.N)))
         return slgc_fail(ctx, SLGC_EINVAL, "variant %d: the frame-count-specialised kernel is built for single runs of 42/44/46 frames", variant);
     if (alg >= 1) {
         PkArgs b{};
@@ -786,6 +904,13 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
         SLGC_PKS3(4, 64, 1) SLGC_PKS3(8, 64, 1)
 #undef SLGC_PKS3
 #undef SLGC_PKS
+        // ALG 3 = register-resident column (default occupancy), ALG 4 = same with an 8 waves/SIMD register cap
+#define SLGC_PKR(NF, P, B, T) if (alg == 3 && g.N == NF && px == P && block == B && nt == T) rc = launch_pkr_t<NF, P, B, T, 1>(ctx, b); \
+                              if (alg == 4 && g.N == NF && px == P && block == B && nt == T) rc = launch_pkr_t<NF, P, B, T, 5>(ctx, b);
+#define SLGC_PKR3(P, B, T) SLGC_PKR(42, P, B, T) SLGC_PKR(44, P, B, T) SLGC_PKR(46, P, B, T)
+        SLGC_PKR3(4, 128, 1) SLGC_PKR3(4, 256, 1) SLGC_PKR3(4, 64, 1) SLGC_PKR3(8, 256, 1) SLGC_PKR3(8, 128, 1) SLGC_PKR3(4, 256, 0)
+#undef SLGC_PKR3
+#undef SLGC_PKR
 #define SLGC_PK(P, B, T) if (alg == 1 && px == P && block == B && nt == T) rc = launch_pk_t<P, B, T>(ctx, b, abl);
         SLGC_PK(4, 64, 0) SLGC_PK(4, 128, 0) SLGC_PK(4, 256, 0) SLGC_PK(8, 64, 0) SLGC_PK(8, 128, 0) SLGC_PK(8, 256, 0)
         SLGC_PK(16, 64, 0) SLGC_PK(16, 128, 0) SLGC_PK(16, 256, 0)

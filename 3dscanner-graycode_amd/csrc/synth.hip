@@ -2,7 +2,7 @@
 //
 // Follows the frame-order contract of scanner/grayCode/generate_codes.py:53-79 (black, white, then column-code
 // bit k MSB-first at frame 2+2k, row-code bit k LSB-first at 3+2k, inverses 2L frames later) on a warped scene:
-//     xs = ((29*x) >> 5) + tri(y),  ys = ((29*y) >> 5) + tri(x),  tri(t) = |((t >> 2) % 20) - 10|     (mod 2^L)
+//     xs = ((29*x) >> 5) + tri(y),  ys = ((29*y) >> 5) + tri(x),  tri(t) = |((t >> 5) % 10) - 5|      (mod 2^L)
 // an all-integer stand-in for SURVEY.md 8(d)'s 0.9*x + 5*sin(y/50) so the NumPy twin
 // (oracle/oracle_np.py: synth_scene_int) is bit-identical.  Ambient 15, gain 180, hash noise in [-noise, noise],
 // one shadow rectangle (all frames = ambient) to exercise the validity mask.
@@ -16,7 +16,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 
-__device__ __forceinline__ int tri(int t) { return abs(((t >> 2) % 20) - 10); }
+__device__ __forceinline__ int tri(int t) { return abs(((t >> 5) % 10) - 5); }
 
 struct SynthArgs {
     uint8_t *stack;

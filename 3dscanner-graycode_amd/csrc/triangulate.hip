@@ -117,6 +117,44 @@ __device__ __forceinline__ Xyz law_of_sines(Ray2 cam, Ray2 prj, const double (&T
     return Xyz{(double)rx * len, (double)ry * len, (double)rz * len};                                        // :95
 }
 
+// ~1e-16-accurate fp64 reciprocal / square root from the hardware seeds plus Newton steps (no IEEE divide expansion).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    return x > 0.0 ? g : 0.0;
+}
+
+// Algebraic form of triangulate.py:86-95 with the normalisations cancelled (c = camera ray [cx, cy, 1], p = projector ray):
+//   A = -T.c, B = T.p, Sa = sqrt(|T|^2 |c|^2 - A^2) = |T||c| sin(alpha), Sb likewise for beta,
+//   sin(gamma) = sin(alpha + beta)   =>   Pts = c * |T|^2 * Sb / (Sa*B + A*Sb).
+// Two square roots and one reciprocal per point; agrees with the acos/sin form to ~1e-13 relative away from degenerate
+// geometry (rays parallel to the baseline), far inside the 1e-4 tolerance of the build's north star.
+__device__ __forceinline__ Xyz law_of_sines_fast(Ray2 cam, Ray2 prj, const double (&T)[3], double t_len)
+{
+    const double cx = cam.x, cy = cam.y, px = prj.x, py = prj.y;
+    const double tl2 = t_len * t_len;
+    const double A = -fma(T[0], cx, fma(T[1], cy, T[2]));
+    const double B = fma(T[0], px, fma(T[1], py, T[2]));
+    const double cn2 = fma(cx, cx, fma(cy, cy, 1.0)), pn2 = fma(px, px, fma(py, py, 1.0));
+    const double Sa = fast_sqrt(fma(tl2, cn2, -A * A)), Sb = fast_sqrt(fma(tl2, pn2, -B * B));
+    const double s = tl2 * Sb * fast_rcp(fma(Sa, B, A * Sb));
+    return Xyz{cx * s, cy * s, s};
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_triangulate_list(const Calib c_calib, const float *__restrict__ cam,
                                                           const float *__restrict__ proj, size_t M, double *__restrict__ xyz)
@@ -181,12 +219,26 @@ __global__ void __launch_bounds__(256) k_build_cam_lut(const Calib c, float2 *__
     lut[p] = make_float2(a.x, a.y);
 }
 
-__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, size_t npix)
+// The projector table is stored in 8x8-pixel tiles (512 B) so that a wave's gather stays within a few cache lines
+// whichever way the decoded projector coordinates drift along a camera row.
+__device__ __forceinline__ uint32_t proj_lut_index(int pu, int pv, int tiles_x)
+{
+    return (((uint32_t)(pv >> 3) * (uint32_t)tiles_x + (uint32_t)(pu >> 3)) << 6) | (uint32_t)((pv & 7) << 3) | (uint32_t)(pu & 7);
+}
+
+__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
+                                                        size_t nslots)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
-    const Ray2 b = undistort_point((float)(int)(p % (size_t)proj_w), (float)(int)(p / (size_t)proj_w), c.proj_k, c.proj_d, nullptr);
-    lut[p] = make_float2(b.x, b.y);
+    if (p >= nslots) return;
+    const int tile = (int)(p >> 6), in = (int)(p & 63);
+    const int pu = (tile % tiles_x) * 8 + (in & 7), pv = (tile / tiles_x) * 8 + (in >> 3);
+    float2 o = make_float2(0.f, 0.f);
+    if (pu < proj_w && pv < proj_h) {
+        const Ray2 b = undistort_point((float)pu, (float)pv, c.proj_k, c.proj_d, nullptr);
+        o = make_float2(b.x, b.y);
+    }
+    lut[p] = o;
 }
 
 struct TriConst {
@@ -199,7 +251,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc, const int16_t *__restrict__ h,
                                                               const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
-                                                              int proj_h, float *__restrict__ xyz,
+                                                              int proj_h, int tiles_x, float *__restrict__ xyz,
                                                               unsigned long long *__restrict__ count)
 {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -217,8 +269,9 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc,
             float X = __builtin_nanf(""), Y = X, Z = X;
             if (ok) {
                 const int pu = min(proj_w - 1, hv), pv = min(proj_h - 1, vv);         // :60-61
-                const float2 pr = proj_lut[(size_t)pv * proj_w + pu];
-                const Xyz r = law_of_sines<MODE>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
+                const float2 pr = proj_lut[proj_lut_index(pu, pv, tiles_x)];
+                const Xyz r = MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len)
+                                                     : law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
                 X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
                 ++nvalid;
             }
@@ -249,7 +302,8 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
 // Build (or reuse) the ray tables for this calibration / geometry.
 static int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
 {
-    const size_t npix = (size_t)rows * W, nproj = (size_t)proj_w * proj_h;
+    const int tiles_x = (proj_w + 7) / 8, tiles_y = (proj_h + 7) / 8;
+    const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * 64;
     if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows)) {
         if (ctx->lut_cam) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -270,7 +324,7 @@ static int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int
         }
         if (hipMalloc(&ctx->lut_proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
         hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib,
-                           (float2 *)ctx->lut_proj, proj_w, nproj);
+                           (float2 *)ctx->lut_proj, proj_w, proj_h, tiles_x, nproj);
         HIP_TRY(ctx, hipGetLastError());
         ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h;
     }
@@ -316,10 +370,10 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, d_xyz, d_count);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
         else
             hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, d_xyz, d_count);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;

@@ -161,9 +161,9 @@ def main():
         recv_pts, recv_keys = ctx.alloc(cam_w * cam_h * 12), ctx.alloc(cam_w * cam_h * 4)
     ctx.synchronize()
 
-    def step(i):
+    def step(i, counted=False):
         s = stacks[i % len(stacks)]
-        ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr,
+        ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
                      maps.at(0), maps.at(band_px * 2), mode=mode)
         if G > 1:
             ctx.compact_dev(xyz.ptr, rows, cam_w, row0, pts.ptr, keys.ptr, count.ptr)
@@ -197,7 +197,10 @@ def main():
         dec_ms = ctx.comm_allreduce_max(dec_ms)
 
     if G == 1:
-        valid = int(count.download((1,), np.uint64)[0]) / max(1, args.steps)
+        count.zero()
+        step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
+        ctx.synchronize()
+        valid = int(count.download((1,), np.uint64)[0])
     else:
         valid = float(total_pts)
     if rank == 0:

@@ -374,7 +374,7 @@ def synth_scene_int(n_frames: int, H: int, W: int, seed: int = 1, noise: int = 3
     yy, xx = np.mgrid[row0:row0 + rows, 0:W].astype(np.int64)
 
     def tri(t):
-        return np.abs(((t >> 2) % 20) - 10)
+        return np.abs(((t >> 5) % 10) - 5)
 
     msk = (1 << L) - 1
     xs = (((29 * xx) >> 5) + tri(yy)) & msk

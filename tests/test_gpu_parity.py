@@ -225,7 +225,7 @@ def test_full_size_round_trip_properties(ctx, N, W, H):
     v = out.download((H, W), np.int16, H * W * 2).astype(np.int64)
     yy, xx = np.mgrid[0:H, 0:W]
     msk = (1 << L) - 1
-    tri = lambda t: np.abs(((t >> 2) % 20) - 10)           # noqa: E731
+    tri = lambda t: np.abs(((t >> 5) % 10) - 5)           # noqa: E731
     xs, ys = (((29 * xx) >> 5) + tri(yy)) & msk, (((29 * yy) >> 5) + tri(xx)) & msk
     okh, okv = h != -1, v != -1
     assert okh.mean() > 0.5 and okv.mean() > 0.5
