@@ -2,6 +2,7 @@
 // entry points that mirror the reference's Python functions.  No CPU fallback anywhere: every entry point runs HIP
 // kernels on the context's device or returns an error.
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "slgc_internal.h"
@@ -618,7 +619,9 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     if (rc) return rc;
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null output");
-    if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    if (mode < 0 || mode > 7) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    const bool want_split = (mode & SLGC_TRI_SPLIT) != 0;
+    mode &= 3;
     DecodeGeom g;
     RunPtrs runs{};
     int e;
@@ -628,6 +631,15 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
         if ((rc = slgc_ws(ctx, 3, (size_t)rows * W * 4 + 64, &maps))) return rc;
         d_h = (int16_t *)maps;
         d_v = d_h + (((size_t)rows * W + 31) & ~(size_t)31);
+    }
+    const size_t npix = (size_t)rows * W;
+    if (mode == SLGC_TRI_ALGEBRAIC && !d_count && npix % 4 == 0 && scan_fused_eligible(g, runs, plane_stride, npix, d_h, d_v, d_xyz) &&
+        proj_w >= 1 && proj_h >= 1 && (size_t)proj_w * proj_h < (1u << 28) && !want_split) {
+        // one kernel: decode with the triangulation tail (maps never re-read from HBM)
+        if ((rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h))) return rc;
+        if ((rc = prof_mark(ctx, 0))) return rc;
+        if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h))) return rc;
+        return prof_mark(ctx, 1);
     }
     if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, 0))) return rc;
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);

@@ -17,6 +17,7 @@
 // Compiled with -ffp-contract=off: the reference's fp64 rounding sequence is part of its
 // behaviour (L_max - D*b_inv must not become an FMA).
 #include "slgc_internal.h"
+#include "tri_math.h"
 
 namespace {
 
@@ -227,7 +228,16 @@ typedef short v2ss __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+struct FuseArgs {            // triangulation appended to the decode kernel (slgc_scan_dev)
+    const float2 *cam_lut;    // [npix] camera rays of this band
+    const float2 *proj_lut;   // 8x8-tiled projector rays
+    float *xyz;               // [npix][3]
+    int proj_w, proj_h, tiles_x;
+    double T[3], t_len;
+};
+
 struct PkArgs {
+    FuseArgs f;
     const uint8_t *run[SLGC_MAX_RUNS];
     uint32_t plane_stride;   // bytes between frames (< 2^32 / N)
     uint32_t npix;           // pixels in the band (multiple of PX handled here; ragged tail by the byte-wide kernel)
@@ -287,7 +297,7 @@ __device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA,
 
 // ABL (timing-only diagnostic builds, results are wrong): 0 = real kernel; 1 = skip the 14 threshold-frame loads;
 // 2 = loads only (no classification arithmetic).
-template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0>
+template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, bool FUSE = false>
 __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
@@ -420,249 +430,61 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
             __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1a-pks: K1a-pk specialised on the frame count at compile time (single run).  Every frame is read from HBM exactly
-// once: the 12 L_max/L_min frames stay in registers after the threshold phase and are classified from there, the
-// remaining frames are streamed (non-temporal), and the whole schedule is straight-line code.
-// ------------------------------------------------------------------------------------------
-template <int NF>
-struct StaticGeom {
-    static constexpr int L = (int)((double)(NF - 2) / 4.0);                 // decode_codes.py:149
-    static constexpr double plf = (double)(NF - 2) / 4.0;                   // decode_codes.py:109
-    static constexpr int thr[12] = {                                        // absolute frame ids (:110-111, +2)
-        2 + (int)(unsigned char)(2 * plf - 2), 2 + (int)(unsigned char)(2 * plf - 4), 2 + (int)(unsigned char)(2 * plf - 6),
-        2 + (int)(unsigned char)(4 * plf - 2), 2 + (int)(unsigned char)(4 * plf - 4), 2 + (int)(unsigned char)(4 * plf - 6),
-        2 + 1, 2 + 3, 2 + 5,
-        2 + (int)(unsigned char)(2 * plf + 1), 2 + (int)(unsigned char)(2 * plf + 3), 2 + (int)(unsigned char)(2 * plf + 5)};
-    static constexpr int slot(int f)
-    {
-        for (int s = 0; s < 12; ++s)
-            if (thr[s] == f) return s;
-        return -1;
-    }
-};
-
-template <int NF, int PX, int BLOCK, int NT>
-__global__ void __launch_bounds__(BLOCK) k_decode_pks(const PkArgs a)
-{
-    using G = StaticGeom<NF>;
-    constexpr int L = G::L;
-    constexpr int NW = PX / 4, NP = PX / 2;
-    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
-    const uint32_t ps = a.plane_stride;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[0], 0, a.run_bytes, 0x00020000);
-
-    Frame<NW, NT> kept[12];
-    const Frame<NW, NT> bl = load_frame<NW, NT>(rs, off, 0), wh = load_frame<NW, NT>(rs, off, ps);
+    if constexpr (FUSE) {
+        // K3 appended: the maps never leave registers before they are triangulated (triangulate.py:56-61, 86-95 in the
+        // cancelled algebraic form; rays from the per-calibration tables).  Same LDS exchange as k_triangulate_maps_lds:
+        // indices -> pixel-per-lane gathers -> per-lane triangulation -> wave-contiguous XYZ stores.
+        static_assert(!FUSE || NW == 1, "fused tail is written for 4 pixels per lane");
+        __shared__ uint4 s_idx[BLOCK];
+        __shared__ float4 s_buf[3 * BLOCK];
+        const int tid = threadIdx.x;
+        const bool live = off < a.npix;
+        uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + off);
+            const float4 c01 = cl[0], c23 = cl[1];
+            cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+            const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
 #pragma unroll
-    for (int s = 0; s < 12; ++s) kept[s] = load_frame<NW, NT>(rs, off, (uint32_t)G::thr[s] * ps);
-
-    uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        uint32_t mxe = even_pair(kept[0].w[q]), mxo = odd_pair(kept[0].w[q]);
-        uint32_t mne = even_pair(kept[6].w[q]), mno = odd_pair(kept[6].w[q]);
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            mxe = as_u(__builtin_elementwise_max(as_us(mxe), as_us(even_pair(kept[k].w[q]))));          // :116
-            mxo = as_u(__builtin_elementwise_max(as_us(mxo), as_us(odd_pair(kept[k].w[q]))));
-            mne = as_u(__builtin_elementwise_min(as_us(mne), as_us(even_pair(kept[6 + k].w[q]))));      // :117
-            mno = as_u(__builtin_elementwise_min(as_us(mno), as_us(odd_pair(kept[6 + k].w[q]))));
-        }
-        int tt[4], cc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t mxp = (j & 1) ? mxo : mxe, mnp = (j & 1) ? mno : mne;
-            const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
-            const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
-            const int black = (int)((bl.w[q] >> (8 * j)) & 0xffu), white = (int)((wh.w[q] >> (8 * j)) & 0xffu);
-            pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
-        }
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int lo = par, hi = par + 2, p = 2 * q + par;
-            const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
-            const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
-            KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
-            KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
-            C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
-            C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
-        }
-    }
-
-    uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = 0xffffffffu; }
-
-    // pass 0: pairs with an operand still in registers (frees them early); pass 1: streamed pairs
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-#pragma unroll
-            for (int code = 0; code < 2; ++code) {
-                // column code (0): bit k = L-1-t ; row code (1): bit k = t ; either way its weight is 2^t
-                const int k = code == 0 ? (L - 1 - t) : t;
-                const int fn = 2 + 2 * k + code, fi = fn + 2 * L;
-                const int sn = G::slot(fn), si = G::slot(fi);
-                if (((sn >= 0) || (si >= 0)) != (pass == 0)) continue;
-                Frame<NW, NT> nf, inf;
-                if (sn >= 0) nf = kept[sn]; else nf = load_frame<NW, NT>(rs, off, (uint32_t)fn * ps);
-                if (si >= 0) inf = kept[si]; else inf = load_frame<NW, NT>(rs, off, (uint32_t)fi * ps);
-#pragma unroll
-                for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                    for (int par = 0; par < 2; ++par) {
-                        const int p = 2 * q + par;
-                        const uint32_t Nn = par ? odd_pair(nf.w[q]) : even_pair(nf.w[q]);
-                        const uint32_t Ii = par ? odd_pair(inf.w[q]) : even_pair(inf.w[q]);
-                        const uint32_t Na = pk_add(Nn, KA[p]), Nb = pk_add(Nn, KB[p]), Ia = pk_add(Ii, KA[p]), Ib = pk_add(Ii, KB[p]);
-                        const uint32_t D = pk_sub(Nn, Ii);
-                        const uint32_t S1 = pk_sub(D, C1[p]), S2 = pk_add(D, C2[p]);
-                        const uint32_t bit = (Nb & ~Ia) | (~S1 & (Na | ~Ib));
-                        const uint32_t y = ~S1 | (~Na & Ib), z = S2 | (Nb & ~Ia);
-                        const uint32_t placed = as_u(as_us(bit & 0x80008000u) >> (unsigned short)(15 - t));   // weight 2^t
-                        if (code == 0) { aB_h[p] |= placed; aV_h[p] &= (y | z); }
-                        else { aB_v[p] |= placed; aV_v[p] &= (y | z); }
-                    }
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int hv = (int)(short)(hw2[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vw2[j >> 1] >> (16 * (j & 1)));
+                if (!(hv == -1 || vv == -1)) idx[j] = proj_lut_index(min(a.f.proj_w - 1, hv), min(a.f.proj_h - 1, vv), a.f.tiles_x);
             }
         }
-    }
-
-    uint32_t oh[NP], ov[NP];
+        s_idx[tid] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+        __syncthreads();
+        float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
+        const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const uint32_t okh = as_u(as_ss(aV_h[p]) >> (short)15), okv = as_u(as_ss(aV_v[p]) >> (short)15);
-        oh[p] = gray_to_binary_2x16(aB_h[p]) | ~okh;
-        ov[p] = gray_to_binary_2x16(aB_v[p]) | ~okv;
-    }
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
-    uint32_t wh_[2 * NW], wv_[2 * NW];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        wh_[2 * q] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x05040100u);
-        wh_[2 * q + 1] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x07060302u);
-        wv_[2 * q] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x05040100u);
-        wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
-    }
-    if constexpr (NW == 1) {
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
-    } else {
-#pragma unroll
-        for (int q = 0; q < NW; q += 2) {
-            __builtin_amdgcn_raw_buffer_store_b128(v4u{wh_[2 * q], wh_[2 * q + 1], wh_[2 * q + 2], wh_[2 * q + 3]}, rh, off * 2u + 8u * q, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = s_idx1[it * BLOCK + tid];
+            s_ray[it * BLOCK + tid] = (i != 0xffffffffu) ? a.f.proj_lut[i] : make_float2(0.f, 0.f);
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1a-pkr: frame count fixed at compile time, the whole pixel column register-resident.  All NF frame loads of a lane are
-// issued back to back (NF x PX bytes in flight per lane), then thresholds and classification run out of registers.  Each
-// byte is read from HBM exactly once and nothing is re-read through L2.  MINW = __launch_bounds__ waves/SIMD hint.
-// ------------------------------------------------------------------------------------------
-template <int NF, int PX, int BLOCK, int NT, int MINW>
-__global__ void __launch_bounds__(BLOCK, MINW) k_decode_pkr(const PkArgs a)
-{
-    using G = StaticGeom<NF>;
-    constexpr int L = G::L;
-    constexpr int NW = PX / 4, NP = PX / 2;
-    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
-    const uint32_t ps = a.plane_stride;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[0], 0, a.run_bytes, 0x00020000);
-
-    Frame<NW, NT> fr[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) fr[f] = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
-
-    uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        uint32_t mxe = even_pair(fr[G::thr[0]].w[q]), mxo = odd_pair(fr[G::thr[0]].w[q]);
-        uint32_t mne = even_pair(fr[G::thr[6]].w[q]), mno = odd_pair(fr[G::thr[6]].w[q]);
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            mxe = as_u(__builtin_elementwise_max(as_us(mxe), as_us(even_pair(fr[G::thr[k]].w[q]))));          // :116
-            mxo = as_u(__builtin_elementwise_max(as_us(mxo), as_us(odd_pair(fr[G::thr[k]].w[q]))));
-            mne = as_u(__builtin_elementwise_min(as_us(mne), as_us(even_pair(fr[G::thr[6 + k]].w[q]))));      // :117
-            mno = as_u(__builtin_elementwise_min(as_us(mno), as_us(odd_pair(fr[G::thr[6 + k]].w[q]))));
-        }
-        int tt[4], cc[4];
+        __syncthreads();
+        const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
+        __syncthreads();
+        const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
+        float out[12];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t mxp = (j & 1) ? mxo : mxe, mnp = (j & 1) ? mno : mne;
-            const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
-            const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
-            const int black = (int)((fr[0].w[q] >> (8 * j)) & 0xffu), white = (int)((fr[1].w[q] >> (8 * j)) & 0xffu);
-            pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
-        }
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int lo = par, hi = par + 2, p = 2 * q + par;
-            const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
-            const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
-            KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
-            KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
-            C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
-            C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
-        }
-    }
-
-    uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = 0xffffffffu; }
-#pragma unroll
-    for (int t = 0; t < L; ++t) {
-#pragma unroll
-        for (int code = 0; code < 2; ++code) {
-            const int k = code == 0 ? (L - 1 - t) : t;            // either way the bit's weight is 2^t
-            const int fn = 2 + 2 * k + code, fi = fn + 2 * L;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) {
-#pragma unroll
-                for (int par = 0; par < 2; ++par) {
-                    const int p = 2 * q + par;
-                    const uint32_t Nn = par ? odd_pair(fr[fn].w[q]) : even_pair(fr[fn].w[q]);
-                    const uint32_t Ii = par ? odd_pair(fr[fi].w[q]) : even_pair(fr[fi].w[q]);
-                    if (code == 0) classify_pk<false>(Nn, Ii, KA[p], KB[p], C1[p], C2[p], aB_h[p], aV_h[p]);
-                    else classify_pk<false>(Nn, Ii, KA[p], KB[p], C1[p], C2[p], aB_v[p], aV_v[p]);
-                }
+            float X = __builtin_nanf(""), Y = X, Z = X;
+            if (idx[j] != 0xffffffffu) {
+                const Xyz r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, a.f.T, a.f.t_len);
+                X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
             }
+            out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
-    }
-
-    const unsigned short sh = (unsigned short)(16 - L);
-    uint32_t oh[NP], ov[NP];
+        s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
+        s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
+        s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
+        __syncthreads();
+        const uint32_t first = blockIdx.x * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
+        const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)BLOCK ? ngroups - first : (uint32_t)BLOCK) * 3u) : 0u;
+        float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const uint32_t okh = as_u(as_ss(aV_h[p]) >> (short)15), okv = as_u(as_ss(aV_v[p]) >> (short)15);
-        oh[p] = gray_to_binary_2x16(as_u(as_us(aB_h[p]) >> sh)) | ~okh;
-        ov[p] = gray_to_binary_2x16(as_u(as_us(aB_v[p]) >> sh)) | ~okv;
-    }
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
-    uint32_t wh_[2 * NW], wv_[2 * NW];
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        wh_[2 * q] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x05040100u);
-        wh_[2 * q + 1] = __builtin_amdgcn_perm(oh[2 * q + 1], oh[2 * q], 0x07060302u);
-        wv_[2 * q] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x05040100u);
-        wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
-    }
-    if constexpr (NW == 1) {
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
-    } else {
-#pragma unroll
-        for (int q = 0; q < NW; q += 2) {
-            __builtin_amdgcn_raw_buffer_store_b128(v4u{wh_[2 * q], wh_[2 * q + 1], wh_[2 * q + 2], wh_[2 * q + 3]}, rh, off * 2u + 8u * q, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
-        }
+        for (int it = 0; it < 3; ++it)
+            if ((uint32_t)(it * BLOCK + tid) < nvec) dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
     }
 }
 
@@ -835,27 +657,39 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
     return SLGC_OK;
 }
 
-template <int NF, int PX, int BLOCK, int NT>
-static int launch_pks_t(slgc_ctx *ctx, const PkArgs &a)
+// Fused decode + triangulate (K1a-pk + K3 tail), 4 px/lane, 128-thread workgroups, NT loads.  Preconditions are checked by the caller.
+int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h)
 {
-    const uint32_t groups = a.npix / PX;
+    PkArgs b{};
+    for (int r = 0; r < g.n_runs; ++r) b.run[r] = (const uint8_t *)runs.p[r];
+    b.plane_stride = (uint32_t)plane_stride;
+    b.npix = (uint32_t)npix4;
+    b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + npix4);
+    b.h = d_h; b.v = d_v; b.g = g; b.e = e;
+    b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
+    b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = (proj_w + 7) / 8;
+    memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
+    b.f.t_len = ctx->calib.t_len;
+    const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
-    hipLaunchKernelGGL((k_decode_pks<NF, PX, BLOCK, NT>), dim3((groups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, a);
+    const unsigned blocks = (groups + 127) / 128;
+    if (g.n_runs > 1)
+        hipLaunchKernelGGL((k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+    else
+        hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
 
-template <int NF, int PX, int BLOCK, int NT, int MINW>
-static int launch_pkr_t(slgc_ctx *ctx, const PkArgs &a)
+bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
+                         const float *d_xyz)
 {
-    const uint32_t groups = a.npix / PX;
-    if (groups == 0) return SLGC_OK;
-    hipLaunchKernelGGL((k_decode_pkr<NF, PX, BLOCK, NT, MINW>), dim3((groups + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, a);
-    HIP_TRY(ctx, hipGetLastError());
-    return SLGC_OK;
+    uintptr_t align_or = (uintptr_t)plane_stride | ((uintptr_t)d_h >> 1) | ((uintptr_t)d_v >> 1);
+    for (int r = 0; r < g.n_runs; ++r) align_or |= (uintptr_t)runs.p[r];
+    return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && (uint64_t)g.N * plane_stride + npix < 0xfffffff0ull &&
+           npix < 0x7fffffffull;
 }
-
-static bool pks_built(int N) { return N == 42 || N == 44 || N == 46; }
 
 // variant: 0 = library default; otherwise ABL*10000000 + NT*1000000 + ALG*100000 + PX*1000 + BLOCK, e.g. 104128 = packed-16 kernel,
 // 4 pixels per lane, 128-thread workgroups; ALG 0 = lane-mask (v_cmp) kernel, 1 = packed-16 kernel; NT = non-temporal loads.
@@ -883,14 +717,12 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
     const int abl = variant / 10000000;
     variant %= 10000000;
     const int nt = variant / 1000000, alg = (variant / 100000) % 10, px = (variant / 1000) % 100, block = variant % 1000;
-    if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 4 || nt > 1)
+    if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 1 || nt > 1)
         return slgc_fail(ctx, SLGC_EINVAL, "bad variant %d", variant);
     if (px > max_px) return slgc_fail(ctx, SLGC_EINVAL, "variant %d needs %d-byte alignment", variant, px);
     if (alg >= 1 && (!fits32 || px == 1)) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: band too large for 32-bit offsets or px=1", variant);
     const size_t main_pix = npix / px * px;
     int rc = SLGC_EINVAL;
-    if (alg >= 2 && (g.n_runs != 1 || !pks_built(g.N)))
-        return slgc_fail(ctx, SLGC_EINVAL, "variant %d: the frame-count-specialised kernel is built for single runs of 42/44/46 frames", variant);
     if (alg >= 1) {
         PkArgs b{};
         for (int r = 0; r < g.n_runs; ++r) b.run[r] = a.run[r];
@@ -898,19 +730,6 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
         b.npix = (uint32_t)main_pix;
         b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + main_pix);
         b.h = d_h; b.v = d_v; b.g = g; b.e = e;
-#define SLGC_PKS(NF, P, B, T) if (alg == 2 && g.N == NF && px == P && block == B && nt == T) rc = launch_pks_t<NF, P, B, T>(ctx, b);
-#define SLGC_PKS3(P, B, T) SLGC_PKS(42, P, B, T) SLGC_PKS(44, P, B, T) SLGC_PKS(46, P, B, T)
-        SLGC_PKS3(4, 128, 1) SLGC_PKS3(4, 256, 1) SLGC_PKS3(8, 128, 1) SLGC_PKS3(8, 256, 1) SLGC_PKS3(4, 256, 0) SLGC_PKS3(8, 256, 0)
-        SLGC_PKS3(4, 64, 1) SLGC_PKS3(8, 64, 1)
-#undef SLGC_PKS3
-#undef SLGC_PKS
-        // ALG 3 = register-resident column (default occupancy), ALG 4 = same with an 8 waves/SIMD register cap
-#define SLGC_PKR(NF, P, B, T) if (alg == 3 && g.N == NF && px == P && block == B && nt == T) rc = launch_pkr_t<NF, P, B, T, 1>(ctx, b); \
-                              if (alg == 4 && g.N == NF && px == P && block == B && nt == T) rc = launch_pkr_t<NF, P, B, T, 5>(ctx, b);
-#define SLGC_PKR3(P, B, T) SLGC_PKR(42, P, B, T) SLGC_PKR(44, P, B, T) SLGC_PKR(46, P, B, T)
-        SLGC_PKR3(4, 128, 1) SLGC_PKR3(4, 256, 1) SLGC_PKR3(4, 64, 1) SLGC_PKR3(8, 256, 1) SLGC_PKR3(8, 128, 1) SLGC_PKR3(4, 256, 0)
-#undef SLGC_PKR3
-#undef SLGC_PKR
 #define SLGC_PK(P, B, T) if (alg == 1 && px == P && block == B && nt == T) rc = launch_pk_t<P, B, T>(ctx, b, abl);
         SLGC_PK(4, 64, 0) SLGC_PK(4, 128, 0) SLGC_PK(4, 256, 0) SLGC_PK(8, 64, 0) SLGC_PK(8, 128, 0) SLGC_PK(8, 256, 0)
         SLGC_PK(16, 64, 0) SLGC_PK(16, 128, 0) SLGC_PK(16, 256, 0)

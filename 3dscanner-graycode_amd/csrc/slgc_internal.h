@@ -91,6 +91,11 @@ int launch_decode_generic(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &run
 int launch_codes_to_pixels(slgc_ctx *ctx, const int8_t *d_hc, const int8_t *d_vc, int n_runs, int L, size_t npix,
                            int64_t *d_h, int64_t *d_v);
 bool decode_fast_eligible(double eps, int *e_out);
+int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h);
+bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
+                         const float *d_xyz);
+int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
 int launch_widen_maps(slgc_ctx *ctx, const int16_t *d_h16, const int16_t *d_v16, size_t npix, int64_t *d_h, int64_t *d_v);
 // correspond.hip
 int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,

@@ -13,7 +13,10 @@
 //
 // Compiled with -ffp-contract=off; float32 divide/sqrt are correctly rounded (hipcc default), so the float32 steps
 // NumPy performs (:90 and the norm in :92) are reproduced bit for bit.
+#include <cstdlib>
+
 #include "slgc_internal.h"
+#include "tri_math.h"
 
 int launch_triangulate_maps_direct(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, size_t first, int W, int row0,
                                    int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
@@ -21,10 +24,6 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
                                         int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count);
 
 namespace {
-
-struct Ray2 {
-    float x, y;
-};
 
 // cv::undistortPoints(src, K, dist, R) for one point, default TermCriteria(MAX_ITER, 5, 0.01).
 __device__ __forceinline__ Ray2 undistort_point(float uf, float vf, const double (&kk)[4], const double (&k)[12], const double *R)
@@ -62,10 +61,6 @@ __device__ __forceinline__ Ray2 undistort_point(float uf, float vf, const double
     }
     return o;
 }
-
-struct Xyz {
-    double x, y, z;
-};
 
 // Valid-pixel counting: a single counter word serialises at the memory side (~11 ns per atomic, 48k waves = 0.5 ms),
 // so each workgroup adds once into one of kCountSlots words on separate 128-byte lines; k_count_finish folds them.
@@ -115,44 +110,6 @@ __device__ __forceinline__ Xyz law_of_sines(Ray2 cam, Ray2 prj, const double (&T
         len = t_len * sin_b / (sin_a * cos_b + cos_a * sin_b);
     }
     return Xyz{(double)rx * len, (double)ry * len, (double)rz * len};                                        // :95
-}
-
-// ~1e-16-accurate fp64 reciprocal / square root from the hardware seeds plus Newton steps (no IEEE divide expansion).
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-__device__ __forceinline__ double fast_sqrt(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    return x > 0.0 ? g : 0.0;
-}
-
-// Algebraic form of triangulate.py:86-95 with the normalisations cancelled (c = camera ray [cx, cy, 1], p = projector ray):
-//   A = -T.c, B = T.p, Sa = sqrt(|T|^2 |c|^2 - A^2) = |T||c| sin(alpha), Sb likewise for beta,
-//   sin(gamma) = sin(alpha + beta)   =>   Pts = c * |T|^2 * Sb / (Sa*B + A*Sb).
-// Two square roots and one reciprocal per point; agrees with the acos/sin form to ~1e-13 relative away from degenerate
-// geometry (rays parallel to the baseline), far inside the 1e-4 tolerance of the build's north star.
-__device__ __forceinline__ Xyz law_of_sines_fast(Ray2 cam, Ray2 prj, const double (&T)[3], double t_len)
-{
-    const double cx = cam.x, cy = cam.y, px = prj.x, py = prj.y;
-    const double tl2 = t_len * t_len;
-    const double A = -fma(T[0], cx, fma(T[1], cy, T[2]));
-    const double B = fma(T[0], px, fma(T[1], py, T[2]));
-    const double cn2 = fma(cx, cx, fma(cy, cy, 1.0)), pn2 = fma(px, px, fma(py, py, 1.0));
-    const double Sa = fast_sqrt(fma(tl2, cn2, -A * A)), Sb = fast_sqrt(fma(tl2, pn2, -B * B));
-    const double s = tl2 * Sb * fast_rcp(fma(Sa, B, A * Sb));
-    return Xyz{cx * s, cy * s, s};
 }
 
 template <int MODE>
@@ -219,13 +176,6 @@ __global__ void __launch_bounds__(256) k_build_cam_lut(const Calib c, float2 *__
     lut[p] = make_float2(a.x, a.y);
 }
 
-// The projector table is stored in 8x8-pixel tiles (512 B) so that a wave's gather stays within a few cache lines
-// whichever way the decoded projector coordinates drift along a camera row.
-__device__ __forceinline__ uint32_t proj_lut_index(int pu, int pv, int tiles_x)
-{
-    return (((uint32_t)(pv >> 3) * (uint32_t)tiles_x + (uint32_t)(pu >> 3)) << 6) | (uint32_t)((pv & 7) << 3) | (uint32_t)(pu & 7);
-}
-
 __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
                                                         size_t nslots)
 {
@@ -247,7 +197,8 @@ struct TriConst {
 };
 
 // Four pixels per lane (8-byte map loads, 32-byte ray loads, 48-byte XYZ stores).
-template <int MODE>
+// ABL (timing-only diagnostics, wrong results): 1 = no projector gather, 2 = wave-contiguous store layout, 3 = no fp64 math.
+template <int MODE, int ABL = 0>
 __global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc, const int16_t *__restrict__ h,
                                                               const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
@@ -269,19 +220,98 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc,
             float X = __builtin_nanf(""), Y = X, Z = X;
             if (ok) {
                 const int pu = min(proj_w - 1, hv), pv = min(proj_h - 1, vv);         // :60-61
-                const float2 pr = proj_lut[proj_lut_index(pu, pv, tiles_x)];
-                const Xyz r = MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len)
+                const float2 pr = ABL == 1 ? make_float2(cy[j] + (float)pu, cx[j] + (float)pv) : proj_lut[proj_lut_index(pu, pv, tiles_x)];
+                const Xyz r = ABL == 3 ? Xyz{(double)pr.x, (double)pr.y, (double)cx[j]} : MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len)
                                                      : law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
                 X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
                 ++nvalid;
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
-        float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * g;
-        dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-        dst[1] = make_float4(out[4], out[5], out[6], out[7]);
-        dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+        if constexpr (ABL == 2) {
+            float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * (g & ~(size_t)63) + (g & 63);
+            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+            dst[64] = make_float4(out[4], out[5], out[6], out[7]);
+            dst[128] = make_float4(out[8], out[9], out[10], out[11]);
+        } else {
+            float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * g;
+            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+        }
     }
+    if (count) block_count_add(count, nvalid);
+}
+
+// LDS-staged variant (shipped): the per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
+// each projector-table gather instruction touch ~50 cache lines and each XYZ store instruction a 48-byte-strided
+// scatter.  Here the workgroup (1024 pixels) exchanges through LDS instead:
+//   1. every lane turns its 4 decoded pixels into table indices            -> s_idx  (4 KB)
+//   2. gathers run pixel-per-lane (64 neighbouring pixels per instruction) -> s_ray  (8 KB)
+//   3. every lane triangulates its own 4 pixels                            -> s_xyz  (12 KB, aliases s_ray)
+//   4. the 12 KB of XYZ leave as wave-contiguous 1 KB stores.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc, const int16_t *__restrict__ h,
+                                                              const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
+                                                              const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
+                                                              int proj_h, int tiles_x, float *__restrict__ xyz,
+                                                              unsigned long long *__restrict__ count)
+{
+    __shared__ uint4 s_idx[256];
+    __shared__ float4 s_buf[768];
+    const int tid = threadIdx.x;
+    const size_t g = (size_t)blockIdx.x * 256 + tid;
+    const bool live = g < ngroups;
+    uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const uint2 hw = reinterpret_cast<const uint2 *>(h)[g], vw = reinterpret_cast<const uint2 *>(v)[g];
+        const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
+        cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+        const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hv = (int)(short)(hq[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vq[j >> 1] >> (16 * (j & 1)));
+            if (!(hv == -1 || vv == -1))                                                              // triangulate.py:56
+                idx[j] = proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x);          // :60-61
+        }
+    }
+    s_idx[tid] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+    __syncthreads();
+    float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
+    const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t i = s_idx1[it * 256 + tid];
+        s_ray[it * 256 + tid] = (i != 0xffffffffu) ? proj_lut[i] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
+    __syncthreads();
+    const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
+    float out[12];
+    unsigned nvalid = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float X = __builtin_nanf(""), Y = X, Z = X;
+        if (idx[j] != 0xffffffffu) {
+            const Xyz r = MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len)
+                                                 : law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
+            X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
+            ++nvalid;
+        }
+        out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
+    }
+    s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
+    s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
+    s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
+    __syncthreads();
+    const size_t first = (size_t)blockIdx.x * 256;
+    const size_t nvec = (ngroups - first < 256 ? ngroups - first : 256) * 3;      // float4s this workgroup owns
+    float4 *dst = reinterpret_cast<float4 *>(xyz) + first * 3;
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+        if ((size_t)(it * 256 + tid) < nvec) dst[it * 256 + tid] = s_buf[it * 256 + tid];
     if (count) block_count_add(count, nvalid);
 }
 
@@ -300,7 +330,7 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
 }
 
 // Build (or reuse) the ray tables for this calibration / geometry.
-static int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
+int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
 {
     const int tiles_x = (proj_w + 7) / 8, tiles_y = (proj_h + 7) / 8;
     const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * 64;
@@ -368,7 +398,21 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         tc.t_len = ctx->calib.t_len;
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
-        if (mode == SLGC_TRI_EXACT)
+        const char *abl_env = getenv("SLGC_TRI_ABL");
+        const int abl = abl_env ? atoi(abl_env) : 0;
+#define SLGC_TRI_ABL_LAUNCH(A) hipLaunchKernelGGL((k_triangulate_maps_lut<SLGC_TRI_ALGEBRAIC, A>), dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, \
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count)
+        if (abl == 0) {
+            if (mode == SLGC_TRI_EXACT)
+                hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+                                   (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
+            else
+                hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+                                   (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
+        } else if (abl == 1) SLGC_TRI_ABL_LAUNCH(1);
+        else if (abl == 2) SLGC_TRI_ABL_LAUNCH(2);
+        else if (abl == 3) SLGC_TRI_ABL_LAUNCH(3);
+        else if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
         else

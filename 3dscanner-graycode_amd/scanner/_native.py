@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SLGC_LIB", os.path.join(_PKG_ROOT, "lib", "libslgc.so
 
 U8, F64 = 0, 1
 ORDER_X, ORDER_ROW = 0, 1
-TRI_EXACT, TRI_ALGEBRAIC = 0, 1
+TRI_EXACT, TRI_ALGEBRAIC, TRI_DIRECT, TRI_SPLIT = 0, 1, 2, 4
 UNIQUE_ID_BYTES = 128
 
 

@@ -1,0 +1,134 @@
+"""Row-sharded scan across the GPUs of one node (BASELINE.json configs[3]).
+
+The reference is single-process; this module exists because the build shards ONE scan by image rows:
+rank r decodes + triangulates rows [row0, row0+rows) of every frame, compacts its band row-major
+(float32 XYZ + uint32 linear pixel key) and the ranks all-gatherv the records so every rank holds the
+reassembled cloud.  Band-major concatenation == row-major order of the full image; the reference's
+x-major order (triangulate.py:52-53) is recovered from the keys (:func:`x_major_permutation`).
+
+The exchange is behind a three-method protocol (``allgather_i64``, ``allgatherv``, ``barrier``):
+:class:`RcclExchange` is the product implementation (RCCL over xGMI through the C-ABI, device pointers);
+the CPU test-suite drives the same planning / layout / reassembly code over gloo with host arrays.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+POINT_BYTES = 12   # float32 x, y, z
+KEY_BYTES = 4      # uint32 linear pixel index  y * W + x
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Contiguous row bands: the first H % G ranks get one extra row."""
+    H: int
+    W: int
+    G: int
+
+    def band(self, rank: int):
+        if not 0 <= rank < self.G:
+            raise ValueError("rank out of range")
+        base, extra = divmod(self.H, self.G)
+        rows = base + (1 if rank < extra else 0)
+        row0 = rank * base + min(rank, extra)
+        return row0, rows
+
+    def bands(self):
+        return [self.band(r) for r in range(self.G)]
+
+    def band_offset_bytes(self, rank: int) -> int:
+        """Offset of the band inside one uint8 frame plane."""
+        return self.band(rank)[0] * self.W
+
+
+def gather_layout(counts, record_bytes: int):
+    """Per-rank byte counts and displacements of an all-gatherv of ``counts[r]`` records."""
+    c = [int(x) for x in counts]
+    if any(x < 0 for x in c):
+        raise ValueError("negative count")
+    byte_counts = [x * record_bytes for x in c]
+    displs, acc = [], 0
+    for b in byte_counts:
+        displs.append(acc)
+        acc += b
+    return byte_counts, displs, acc
+
+
+def x_major_permutation(keys: np.ndarray, W: int, H: int) -> np.ndarray:
+    """Permutation that sorts records from row-major (key order) into the reference's x-major order."""
+    k = np.asarray(keys, dtype=np.int64)
+    return np.argsort((k % W) * H + (k // W), kind="stable")
+
+
+def to_reference_lists(points: np.ndarray, keys: np.ndarray, W: int, H: int):
+    """Reassembled cloud -> (cam_pts float32 [M,2] x-major, Pts float64 (3,M)) as the reference returns them."""
+    perm = x_major_permutation(keys, W, H)
+    k = np.asarray(keys, dtype=np.int64)[perm]
+    cam = np.stack([k % W, k // W], axis=1).astype(np.float32)
+    return cam, np.ascontiguousarray(np.asarray(points, dtype=np.float64)[perm].T)
+
+
+def exchange_records(exchange, send_points, send_keys, count: int, recv_points, recv_keys):
+    """Counts all-gather, then two all-gathervs (points, keys).  Buffers are whatever the exchange understands
+    (device pointers for RCCL, NumPy arrays for the gloo test double).  Returns (counts, total)."""
+    counts = exchange.allgather_i64(int(count))
+    pc, pd, _ = gather_layout(counts, POINT_BYTES)
+    kc, kd, _ = gather_layout(counts, KEY_BYTES)
+    exchange.allgatherv(send_points, recv_points, pc, pd)
+    exchange.allgatherv(send_keys, recv_keys, kc, kd)
+    return counts, sum(counts)
+
+
+class RcclExchange:
+    """RCCL over xGMI through libslgc.so (one context = one rank = one GPU)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.rank, self.nranks = ctx.rank, ctx.nranks
+
+    def allgather_i64(self, value: int):
+        return self.ctx.comm_allgather_i64(value)
+
+    def allgatherv(self, d_send: int, d_recv: int, byte_counts, byte_displs):
+        self.ctx.comm_allgatherv(d_send, d_recv, byte_counts, byte_displs)
+
+    def barrier(self):
+        self.ctx.comm_barrier()
+
+
+class ShardedScanner:
+    """Device-resident sharded scan: owns the per-rank output buffers, runs one band per call."""
+
+    def __init__(self, ctx, exchange, plan: ShardPlan, proj_size, n_frames: int, mode: int = 1):
+        self.ctx, self.exchange, self.plan = ctx, exchange, plan
+        self.proj_size, self.N, self.mode = proj_size, n_frames, mode
+        self.rank = exchange.rank
+        self.row0, self.rows = plan.band(self.rank)
+        band_px, full_px = self.rows * plan.W, plan.H * plan.W
+        self.maps = ctx.alloc(max(16, band_px * 4))
+        self.xyz = ctx.alloc(max(16, band_px * 12))
+        self.count = ctx.alloc(8)
+        self.points = ctx.alloc(max(16, band_px * POINT_BYTES))
+        self.keys = ctx.alloc(max(16, band_px * KEY_BYTES))
+        self.all_points = ctx.alloc(max(16, full_px * POINT_BYTES))
+        self.all_keys = ctx.alloc(max(16, full_px * KEY_BYTES))
+        self.last_counts = None
+
+    def scan(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
+        """d_band_stack points at this rank's first row of frame 0.  Returns the total number of points (all ranks)."""
+        c, W = self.ctx, self.plan.W
+        band_px = self.rows * W
+        c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0,
+                   self.proj_size, self.xyz.ptr, None, self.maps.at(0), self.maps.at(band_px * 2), eps=eps, mode=self.mode)
+        c.compact_dev(self.xyz.ptr, self.rows, W, self.row0, self.points.ptr, self.keys.ptr, self.count.ptr)
+        m = int(self.count.download((1,), np.uint64)[0])          # the host needs M_r for the displacements
+        self.last_counts, total = exchange_records(self.exchange, self.points.ptr, self.keys.ptr, m,
+                                                   self.all_points.ptr, self.all_keys.ptr)
+        return total
+
+    def fetch(self, total: int):
+        """Reassembled cloud on the host: (points float32 [M,3], keys uint32 [M]) in row-major (key) order."""
+        self.ctx.synchronize()
+        return (self.all_points.download((total, 3), np.float32), self.all_keys.download((total,), np.uint32))

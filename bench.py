@@ -10,6 +10,10 @@ and leaves a dense float32 XYZ map + int16 projector maps in HBM.  No torch: HIP
       one rank per GPU: the same scan row-sharded across the N GPUs (configs[3]); each step ends with the RCCL
       all-gatherv that reassembles the compacted point cloud (float32 XYZ + uint32 pixel key) on every rank.
 
+The timed region runs the two-kernel pipeline (decode kernel, then triangulation kernel) so that the graded decode kernel is
+its own launch; at N=1 the single-kernel fused pipeline (decode with the triangulation tail, `--pipeline fused`) is timed right
+after over the same K steps and reported in the extra object "fused_pipeline".
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      decode kernel: algorithmic bytes (N+4 per pixel) / mean launch duration from HIP events recorded on the
                 launch stream inside the timed region, against the 8 TB/s HBM3E peak
@@ -108,9 +112,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_4096x3000x44", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="algebraic", choices=["algebraic", "exact"])
+    ap.add_argument("--pipeline", default="split", choices=["split", "fused"],
+                    help="split: decode kernel + triangulation kernel (default); fused: one kernel")
     ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input stacks rotated between steps")
     args = ap.parse_args()
 
@@ -130,11 +137,16 @@ def main():
     rows = cam_h // G
     row0 = rank * rows
     mode = (_native.TRI_ALGEBRAIC if args.mode == "algebraic" else _native.TRI_EXACT) | (2 if args.tri == "direct" else 0)
+    mode_split, mode_fused = mode | _native.TRI_SPLIT, mode & ~_native.TRI_SPLIT
+    mode = mode_split if args.pipeline == "split" else mode_fused
 
     ctx = _native.Context(local_rank)
     calib = calibration(cam_w, cam_h, proj_w, proj_h)
     ctx.set_calibration(*calib)
     uid_path = None
+    use_comm = G > 1 or args.force_sharded
+    if G == 1 and args.force_sharded:
+        ctx.comm_init(0, 1, _native.Context.comm_unique_id())
     if G > 1:
         uid, uid_path = rendezvous_uid(rank, G)
         ctx.comm_init(rank, G, uid)
@@ -155,48 +167,49 @@ def main():
     maps = ctx.alloc(band_px * 4)
     xyz = ctx.alloc(band_px * 12)
     count = ctx.alloc(8).zero()
-    pts = keys = recv_pts = recv_keys = None
-    if G > 1:
-        pts, keys = ctx.alloc(band_px * 12), ctx.alloc(band_px * 4)
-        recv_pts, recv_keys = ctx.alloc(cam_w * cam_h * 12), ctx.alloc(cam_w * cam_h * 4)
+    sharded_scanner = None
+    if use_comm:
+        from scanner import sharded
+        sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(cam_h, cam_w, G),
+                                                 (proj_w, proj_h), N, mode=mode)
     ctx.synchronize()
 
-    def step(i, counted=False):
+    def step(i, counted=False, mode=mode):
         s = stacks[i % len(stacks)]
+        if use_comm:
+            return sharded_scanner.scan(s.ptr, plane)        # band scan + compaction + counts + RCCL all-gatherv
         ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
                      maps.at(0), maps.at(band_px * 2), mode=mode)
-        if G > 1:
-            ctx.compact_dev(xyz.ptr, rows, cam_w, row0, pts.ptr, keys.ptr, count.ptr)
-            m = int(count.download((1,), np.uint64)[0])                 # host needs M_r for the displacements
-            allm = ctx.comm_allgather_i64(m)
-            displ = np.concatenate([[0], np.cumsum(allm)[:-1]])
-            ctx.comm_allgatherv(pts.ptr, recv_pts.ptr, [12 * x for x in allm], [12 * int(d) for d in displ])
-            ctx.comm_allgatherv(keys.ptr, recv_keys.ptr, [4 * x for x in allm], [4 * int(d) for d in displ])
-            return sum(allm)
         return None
 
-    for i in range(args.warmup):
-        step(i)
-    ctx.synchronize()
-    if G > 1:
-        ctx.comm_barrier()
-    count.zero()
-    ctx.synchronize()
-    ctx.prof_begin(args.steps + 8)
-    t0 = time.perf_counter()
-    total_pts = None
-    for i in range(args.steps):
-        total_pts = step(i)
-    ctx.synchronize()
-    if G > 1:
-        ctx.comm_barrier()
-    elapsed = time.perf_counter() - t0
-    dec_ms, dec_n = ctx.prof_end()
-    if G > 1:
-        elapsed = ctx.comm_allreduce_max(elapsed)
-        dec_ms = ctx.comm_allreduce_max(dec_ms)
+    def timed(K, W_, **kw):
+        for i in range(W_):
+            step(i, **kw)
+        ctx.synchronize()
+        if G > 1:
+            ctx.comm_barrier()
+        ctx.prof_begin(K + 8)
+        t0 = time.perf_counter()
+        tot = None
+        for i in range(K):
+            tot = step(i, **kw)
+        ctx.synchronize()
+        if G > 1:
+            ctx.comm_barrier()
+        el = time.perf_counter() - t0
+        kms, kn = ctx.prof_end()
+        if G > 1:
+            el = ctx.comm_allreduce_max(el)
+            kms = ctx.comm_allreduce_max(kms)
+        return el, kms, kn, tot
 
-    if G == 1:
+    elapsed, dec_ms, dec_n, total_pts = timed(args.steps, args.warmup)
+    other = None
+    if G == 1 and not use_comm and args.mode == "algebraic" and args.tri == "lut":
+        om = mode_fused if args.pipeline == "split" else mode_split
+        other = timed(args.steps, max(2, args.warmup // 2), mode=om)
+
+    if not use_comm:
         count.zero()
         step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
         ctx.synchronize()
@@ -207,34 +220,46 @@ def main():
         mpix_per_step = cam_w * cam_h / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         value = mpix_per_step * args.steps / elapsed
-        dec_avg_ms = dec_ms / max(1, dec_n)
-        algo_bytes = (N + 4) * band_px                      # N bytes in + 2x int16 out per pixel
-        achieved = algo_bytes / (dec_avg_ms * 1e-3) / 1e9
+        def kernel_roofline(pipeline, kms, kn):
+            """decode kernel: N bytes in + 2x int16 out per pixel; fused kernel: + 12 B float32 XYZ out."""
+            per_px = (N + 4) if pipeline == "split" else (N + 4 + 12)
+            avg_ms = kms / max(1, kn)
+            ach = per_px * band_px / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "kernel": "k_decode_pk<4,128,nt>" + ("" if pipeline == "split" else " + triangulation tail (fused)"),
+                    "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, "algorithmic_bytes_per_px": per_px,
+                    "algorithmic_bytes_per_launch": per_px * band_px}
+
         out = {
             "metric": "Mpixels/s decode+triangulate", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": G,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
-                                   + ("" if G == 1 else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
+                                   + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
+                       "pipeline": args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)"),
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks),
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
-                                  + ("" if G == 1 else "; compacted XYZ+key all-gathered to every rank")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_decode_fast", "avg_launch_ms": round(dec_avg_ms, 5), "launches_timed": dec_n,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                                  + ("" if not use_comm else "; compacted XYZ+key all-gathered to every rank")},
+            "roofline": kernel_roofline(args.pipeline, dec_ms, dec_n),
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
         }
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                t = json.load(open(tpath)).get(f"{args.workload}/g{G}")
+                t = json.load(open(tpath)).get(f"{args.workload}/g{G}/{args.pipeline}")
                 if t:
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = t.get("source")
             except Exception:
                 pass
+        if other is not None:
+            o_el, o_kms, o_kn, _ = other
+            o_name = "fused" if args.pipeline == "split" else "split"
+            out[o_name + "_pipeline"] = {"value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
+                                         "ms_per_step": round(o_el / args.steps * 1e3, 4), "steps": args.steps,
+                                         "roofline": kernel_roofline(o_name, o_kms, o_kn),
+                                         "note": "same scan, same run, timed right after the main region"}
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, 1536, 768, calib, (proj_w, proj_h))
         print(json.dumps(out), flush=True)

@@ -46,7 +46,8 @@ enum { SLGC_ORDER_X = 0 /* reference scan order, triangulate.py:52-53 */, SLGC_O
 enum {
     SLGC_TRI_EXACT = 0,     /* acos/sin as triangulate.py:91-94 */
     SLGC_TRI_ALGEBRAIC = 1, /* algebraically identical sqrt form */
-    SLGC_TRI_DIRECT = 2     /* flag for the dense (_dev) path: evaluate undistortPoints per pixel instead of the ray tables */
+    SLGC_TRI_DIRECT = 2,    /* flag for the dense (_dev) path: evaluate undistortPoints per pixel instead of the ray tables */
+    SLGC_TRI_SPLIT = 4      /* flag for slgc_scan_dev: always run decode and triangulation as two kernels (no fusion) */
 };
 
 typedef struct slgc_ctx slgc_ctx;
@@ -120,9 +121,10 @@ int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t bytes);
 int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
                     int rows, int W, double eps, double m, int16_t *d_h, int16_t *d_v, int variant);
 
-/* Fused decode -> clamp -> triangulate on a row band: dense float32 XYZ [rows][W][3] (NaN where undecodable),
+/* Decode -> clamp -> triangulate on a row band: dense float32 XYZ [rows][W][3] (NaN where undecodable),
  * optional int16 maps (may be NULL), and *d_count += number of valid pixels.  row0 = first row of the band in the
- * full image (camera y of local row 0). */
+ * full image (camera y of local row 0).  With mode = SLGC_TRI_ALGEBRAIC, no count requested and 4-byte aligned buffers
+ * this is ONE kernel (decode with the triangulation tail); otherwise (or with SLGC_TRI_SPLIT) two kernels. */
 int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
                   int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
                   int16_t *d_v, float *d_xyz, unsigned long long *d_count);

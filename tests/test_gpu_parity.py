@@ -172,23 +172,6 @@ def test_decode_dev_variants(ctx, variant):
     assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
 
 
-@pytest.mark.parametrize("N", [42, 44, 46])
-@pytest.mark.parametrize("variant", [1204064, 1204128, 1204256, 1208064, 1208128, 1208256, 204256, 208256])
-def test_decode_dev_frame_count_specialised(ctx, N, variant):
-    """K1a-pks: one HBM read per byte, frame count fixed at compile time (single run)."""
-    rng = np.random.default_rng(N)
-    for st in (rng.integers(0, 256, (1, N, 72, 200), dtype=np.uint8), onp.synth_scene(N, 72, 200, seed=5)[None]):
-        st[0, :, :5, :11] = 0
-        ref = oc.decode(st)
-        h, v = dev_decode(ctx, st, variant)
-        assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1])
-        rb = oc.decode(st[:, :, 16:56])
-        h, v = dev_decode(ctx, st, variant, band=(16, 56))
-        assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
-    with pytest.raises(ValueError):
-        dev_decode(ctx, np.zeros((2, N, 8, 64), np.uint8), variant)          # multi-run goes to the generic packed kernel
-
-
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
@@ -346,6 +329,26 @@ def test_scan_dev_vs_oracle(ctx, calib):
         assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, H * W * 2), vp)
         assert np.isnan(got[~ok]).all() and np.isfinite(got[ok]).all()
         np.testing.assert_allclose(got[ok], np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+    # fused single-kernel path (no count requested, algebraic): same maps, same cloud
+    maps.zero()
+    ctx.scan_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, 0, psize, xyz.ptr, None, maps.at(0), maps.at(H * W * 2), mode=1)
+    ctx.synchronize()
+    got = xyz.download((H, W, 3), np.float32)
+    assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, H * W * 2), vp)
+    assert np.isnan(got[~ok]).all() and np.isfinite(got[ok]).all()
+    np.testing.assert_allclose(got[ok], np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+    # fused, two runs, band rows 16..80 without caller-provided maps
+    st2 = np.stack([st, onp.synth_scene_int(N, H, W, seed=9, noise=6)[0]])
+    hp2, vp2, ref2 = oc.scan_dense(st2[:, :, 16:80], psize, np.array([[K[0, 0], 0, K[0, 2]], [0, K[1, 1], K[1, 2] - 16], [0, 0, 1]]),
+                                   calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    stack2 = ctx.alloc(st2.nbytes).upload(st2)
+    ctx.scan_dev(stack2.at(16 * W), 2, st.nbytes, H * W, N, 64, W, 16, psize, xyz.ptr, None, mode=1)
+    ctx.synchronize()
+    got2 = xyz.download((64, W, 3), np.float32)
+    ok2 = (hp2 != -1) & (vp2 != -1)
+    assert np.array_equal(np.isfinite(got2[..., 0]), ok2)
+    np.testing.assert_allclose(got2[ok2], np.moveaxis(ref2, 0, -1)[ok2], rtol=XYZ_RTOL, atol=0)
+    stack2.free()
     # band with row0 (multi-GPU shard): rows 32..64
     cnt.zero()
     ctx.scan_dev(stack.at(32 * W), 1, st.nbytes, H * W, N, 32, W, 32, psize, xyz.ptr, cnt.ptr, mode=0)
@@ -382,5 +385,34 @@ def test_rccl_single_rank(ctx):
         ctx.comm_allgatherv(src.ptr, dst.ptr, [1000], [0])
         ctx.synchronize()
         assert np.array_equal(dst.download((1000,), np.uint8), np.arange(1000, dtype=np.uint8))
+    finally:
+        ctx.comm_destroy()
+
+
+def test_sharded_scanner_single_rank_rccl(ctx, calib):
+    """ShardedScanner + RcclExchange end to end on one GPU (nranks = 1): band scan, compaction, counts all-gather and
+    the all-gatherv must reproduce the oracle's cloud, and the keys must give back the reference's x-major lists."""
+    from scanner import _native, sharded
+    N, H, W = 26, 40, 128
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=6)
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 250.0, 250.0
+    psize = (160, 120)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    hp, vp, ref = oc.scan_dense(st, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    ctx.comm_init(0, 1, _native.Context.comm_unique_id())
+    try:
+        sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT)
+        stack = ctx.alloc(st.nbytes).upload(st)
+        total = sc.scan(stack.ptr, H * W)
+        pts, keys = sc.fetch(total)
+        ok = (hp != -1) & (vp != -1)
+        assert total == ok.sum() and np.array_equal(keys, np.nonzero(ok.ravel())[0])
+        np.testing.assert_allclose(pts, np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+        cam, P = sharded.to_reference_lists(pts, keys, W, H)
+        rcam, _, _ = oc.cam_proj_pts(hp, vp, (W, H), psize, None, order="x")
+        assert np.array_equal(cam, rcam) and P.shape == (3, total)
     finally:
         ctx.comm_destroy()

@@ -1,0 +1,137 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo run of the row-sharding plan, the counts + all-gatherv exchange protocol
+and the reassembly / x-major reordering code of scanner/sharded.py.  The per-band compute is done by the oracle here
+(this is a CPU test of the host logic); on the GPU box the same functions drive RcclExchange with device pointers."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class GlooExchange:
+    """Test double with the RcclExchange protocol, over torch.distributed(gloo) and NumPy buffers."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    def allgather_i64(self, value):
+        t = self.torch.tensor([value], dtype=self.torch.int64)
+        out = [self.torch.zeros(1, dtype=self.torch.int64) for _ in range(self.nranks)]
+        self.dist.all_gather(out, t)
+        return [int(x[0]) for x in out]
+
+    def allgatherv(self, send, recv, byte_counts, byte_displs):
+        """Same contract as slgc_comm_allgatherv: one broadcast per contributing rank into recv[displ : displ+count]."""
+        rb = recv.view(np.uint8).reshape(-1)
+        sb = send.view(np.uint8).reshape(-1)
+        for r in range(self.nranks):
+            n = byte_counts[r]
+            if n == 0:
+                continue
+            if r == self.rank:
+                rb[byte_displs[r]:byte_displs[r] + n] = sb[:n]
+            t = self.torch.from_numpy(rb[byte_displs[r]:byte_displs[r] + n])
+            self.dist.broadcast(t, src=r)
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def _worker(rank, world, port, H, W, N, q):
+    try:
+        for p in (PKG, os.path.join(ROOT, "oracle")):
+            sys.path.insert(0, p)
+        import torch
+        import torch.distributed as dist
+        import oracle_c as oc
+        import oracle_np as onp
+        from scanner import reference_calibration as rc
+        from scanner import sharded
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ex = GlooExchange(dist, torch)
+        plan = sharded.ShardPlan(H, W, world)
+        row0, rows = plan.band(rank)
+        st, _, _ = onp.synth_scene_int(N, H, W, seed=4)
+        K = rc.CAM_MTX.copy()
+        K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 200.0, 200.0
+        psize = (200, 150)
+        pk = onp.scale_proj_mtx(rc.PROJ_MTX, psize, (1920, 1080))
+        th = np.deg2rad(-20.0)
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        T = np.array([[0.25], [0.02], [0.04]])
+        # ---- per-band compute (oracle stands in for scan_dev + compact_dev): band of the stack only
+        band = np.ascontiguousarray(st[:, row0:row0 + rows])
+        Kb = K.copy()
+        Kb[1, 2] -= row0                                     # camera y of local row 0 is row0
+        hp, vp, xyz = oc.scan_dense(band, psize, Kb, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T) if rows else (None, None, np.zeros((3, 0, W)))
+        dense = np.moveaxis(xyz, 0, -1).astype(np.float32).reshape(-1, 3)
+        ok = np.isfinite(dense[:, 0])
+        pts = np.ascontiguousarray(dense[ok])
+        keys = (np.nonzero(ok)[0] + row0 * W).astype(np.uint32)
+        # ---- the code under test: layout + exchange + reassembly
+        all_pts = np.zeros((H * W, 3), np.float32)
+        all_keys = np.zeros(H * W, np.uint32)
+        counts, total = sharded.exchange_records(ex, pts, keys, len(pts), all_pts, all_keys)
+        ex.barrier()
+        # ---- reference: the whole image in one go
+        fh, fv, fxyz = oc.scan_dense(st, psize, K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
+        fdense = np.moveaxis(fxyz, 0, -1).astype(np.float32).reshape(-1, 3)
+        fok = np.isfinite(fdense[:, 0])
+        assert total == int(fok.sum()) and sum(counts) == total and len(counts) == world
+        assert np.array_equal(all_keys[:total], np.nonzero(fok)[0].astype(np.uint32))       # band-major == row-major
+        np.testing.assert_allclose(all_pts[:total], fdense[fok], rtol=1e-6)
+        cam, P = sharded.to_reference_lists(all_pts[:total], all_keys[:total], W, H)
+        rcam, _, _ = oc.cam_proj_pts(fh, fv, (W, H), psize, None, order="x")
+        assert np.array_equal(cam, rcam) and P.shape == (3, total) and P.dtype == np.float64
+        dist.destroy_process_group()
+        q.put((rank, "ok", counts))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world,H", [(2, 48), (3, 50)])
+def test_sharded_exchange_gloo(world, H):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, 64, 26, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in results:
+        assert status == "ok", f"rank {rank}: {info}"
+    assert len({tuple(info) for _, _, info in results}) == 1          # every rank saw the same counts
+
+
+def test_shard_plan_and_layout():
+    from scanner import sharded
+    for H, G in ((3000, 8), (3000, 7), (5, 8), (1080, 4)):
+        plan = sharded.ShardPlan(H, 64, G)
+        bands = plan.bands()
+        assert bands[0][0] == 0 and sum(r for _, r in bands) == H
+        for (a0, ar), (b0, _) in zip(bands, bands[1:]):
+            assert a0 + ar == b0
+        assert max(r for _, r in bands) - min(r for _, r in bands) <= 1
+    bc, bd, tot = sharded.gather_layout([3, 0, 5], 12)
+    assert bc == [36, 0, 60] and bd == [0, 36, 36] and tot == 96
+    with pytest.raises(ValueError):
+        sharded.gather_layout([1, -1], 4)
+    keys = np.array([0 * 4 + 1, 0 * 4 + 3, 1 * 4 + 0, 2 * 4 + 1], dtype=np.uint32)      # W=4: (x,y) = (1,0),(3,0),(0,1),(1,2)
+    perm = sharded.x_major_permutation(keys, 4, 3)
+    assert list(perm) == [2, 0, 3, 1]                                                     # x=0 | x=1 (y=0,2) | x=3
