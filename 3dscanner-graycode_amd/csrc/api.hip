@@ -654,6 +654,15 @@ extern "C" int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int
     return launch_compact_dense(ctx, d_xyz, rows, W, row0, d_points, d_keys, d_count);
 }
 
+extern "C" int slgc_compact_records_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, void *d_records,
+                                        unsigned long long *d_count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_xyz || !d_records || !d_count || ((uintptr_t)d_records & 15)) return slgc_fail(ctx, SLGC_EINVAL, "null / misaligned pointer");
+    return launch_compact_records(ctx, d_xyz, rows, W, row0, d_records, d_count);
+}
+
 extern "C" int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                                     uint32_t seed, int noise, int shadow)
 {

@@ -249,6 +249,16 @@ struct EmitPoints {
     }
 };
 
+struct EmitRecords {   // 16-byte exchange records: float32 x, y, z + uint32 linear pixel key (one all-gatherv instead of two)
+    const float *xyz;
+    uint32_t key0;
+    float4 *rec;
+    __device__ void operator()(size_t i, unsigned long long o) const
+    {
+        rec[o] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(key0 + (uint32_t)i));
+    }
+};
+
 template <class Pred, class Emit>
 int compact(slgc_ctx *ctx, Pred pred, Emit emit, size_t n, unsigned long long *d_total)
 {
@@ -323,5 +333,12 @@ int launch_compact_dense(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int
 {
     PredFinite pred{d_xyz};
     EmitPoints emit{d_xyz, (uint32_t)((size_t)row0 * W), d_points, d_keys};
+    return compact(ctx, pred, emit, (size_t)rows * W, d_count);
+}
+
+int launch_compact_records(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, void *d_records, unsigned long long *d_count)
+{
+    PredFinite pred{d_xyz};
+    EmitRecords emit{d_xyz, (uint32_t)((size_t)row0 * W), (float4 *)d_records};
     return compact(ctx, pred, emit, (size_t)rows * W, d_count);
 }

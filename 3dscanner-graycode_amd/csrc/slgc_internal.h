@@ -105,6 +105,7 @@ int launch_filter(slgc_ctx *ctx, const double *d_xyz, const double *d_colors, in
                   double *d_colors_out, unsigned long long *d_total, int pass);
 int launch_compact_dense(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
                          unsigned long long *d_count);
+int launch_compact_records(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, void *d_records, unsigned long long *d_count);
 // triangulate.hip
 int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz);
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,

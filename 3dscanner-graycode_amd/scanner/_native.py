@@ -57,6 +57,7 @@ SIGNATURES = {
     "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
@@ -335,6 +336,9 @@ class Context:
 
     def compact_dev(self, d_xyz: int, rows, W, row0, d_points: int, d_keys, d_count: int):
         self._ck(lib().slgc_compact_dev(self._h, d_xyz, rows, W, row0, d_points, d_keys, d_count))
+
+    def compact_records_dev(self, d_xyz: int, rows, W, row0, d_records: int, d_count: int):
+        self._ck(lib().slgc_compact_records_dev(self._h, d_xyz, rows, W, row0, d_records, d_count))
 
     def synth_scene_dev(self, d_stack: int, plane_stride, N, H, W, row0=0, rows=None, seed=1, noise=3, shadow=True):
         rows = H if rows is None else rows

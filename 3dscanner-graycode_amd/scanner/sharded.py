@@ -2,7 +2,7 @@
 
 The reference is single-process; this module exists because the build shards ONE scan by image rows:
 rank r decodes + triangulates rows [row0, row0+rows) of every frame, compacts its band row-major
-(float32 XYZ + uint32 linear pixel key) and the ranks all-gatherv the records so every rank holds the
+(16-byte records: float32 XYZ + uint32 linear pixel key) and the ranks all-gatherv the records so every rank holds the
 reassembled cloud.  Band-major concatenation == row-major order of the full image; the reference's
 x-major order (triangulate.py:52-53) is recovered from the keys (:func:`x_major_permutation`).
 
@@ -16,8 +16,8 @@ from dataclasses import dataclass
 
 import numpy as np
 
-POINT_BYTES = 12   # float32 x, y, z
-KEY_BYTES = 4      # uint32 linear pixel index  y * W + x
+RECORD_BYTES = 16  # float32 x, y, z + uint32 linear pixel index (y * W + x)
+RECORD_DTYPE = np.dtype([("xyz", np.float32, 3), ("key", np.uint32)])
 
 
 @dataclass(frozen=True)
@@ -62,22 +62,20 @@ def x_major_permutation(keys: np.ndarray, W: int, H: int) -> np.ndarray:
     return np.argsort((k % W) * H + (k // W), kind="stable")
 
 
-def to_reference_lists(points: np.ndarray, keys: np.ndarray, W: int, H: int):
-    """Reassembled cloud -> (cam_pts float32 [M,2] x-major, Pts float64 (3,M)) as the reference returns them."""
-    perm = x_major_permutation(keys, W, H)
-    k = np.asarray(keys, dtype=np.int64)[perm]
+def to_reference_lists(records: np.ndarray, W: int, H: int):
+    """Reassembled cloud (RECORD_DTYPE array) -> (cam_pts float32 [M,2] x-major, Pts float64 (3,M)) as the reference returns them."""
+    perm = x_major_permutation(records["key"], W, H)
+    k = records["key"].astype(np.int64)[perm]
     cam = np.stack([k % W, k // W], axis=1).astype(np.float32)
-    return cam, np.ascontiguousarray(np.asarray(points, dtype=np.float64)[perm].T)
+    return cam, np.ascontiguousarray(records["xyz"].astype(np.float64)[perm].T)
 
 
-def exchange_records(exchange, send_points, send_keys, count: int, recv_points, recv_keys):
-    """Counts all-gather, then two all-gathervs (points, keys).  Buffers are whatever the exchange understands
+def exchange_records(exchange, send_records, count: int, recv_records):
+    """Counts all-gather, then ONE all-gatherv of the 16-byte records.  Buffers are whatever the exchange understands
     (device pointers for RCCL, NumPy arrays for the gloo test double).  Returns (counts, total)."""
     counts = exchange.allgather_i64(int(count))
-    pc, pd, _ = gather_layout(counts, POINT_BYTES)
-    kc, kd, _ = gather_layout(counts, KEY_BYTES)
-    exchange.allgatherv(send_points, recv_points, pc, pd)
-    exchange.allgatherv(send_keys, recv_keys, kc, kd)
+    bc, bd, _ = gather_layout(counts, RECORD_BYTES)
+    exchange.allgatherv(send_records, recv_records, bc, bd)
     return counts, sum(counts)
 
 
@@ -110,10 +108,8 @@ class ShardedScanner:
         self.maps = ctx.alloc(max(16, band_px * 4))
         self.xyz = ctx.alloc(max(16, band_px * 12))
         self.count = ctx.alloc(8)
-        self.points = ctx.alloc(max(16, band_px * POINT_BYTES))
-        self.keys = ctx.alloc(max(16, band_px * KEY_BYTES))
-        self.all_points = ctx.alloc(max(16, full_px * POINT_BYTES))
-        self.all_keys = ctx.alloc(max(16, full_px * KEY_BYTES))
+        self.records = ctx.alloc(max(16, band_px * RECORD_BYTES))
+        self.all_records = ctx.alloc(max(16, full_px * RECORD_BYTES))
         self.last_counts = None
 
     def scan(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
@@ -122,13 +118,12 @@ class ShardedScanner:
         band_px = self.rows * W
         c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0,
                    self.proj_size, self.xyz.ptr, None, self.maps.at(0), self.maps.at(band_px * 2), eps=eps, mode=self.mode)
-        c.compact_dev(self.xyz.ptr, self.rows, W, self.row0, self.points.ptr, self.keys.ptr, self.count.ptr)
+        c.compact_records_dev(self.xyz.ptr, self.rows, W, self.row0, self.records.ptr, self.count.ptr)
         m = int(self.count.download((1,), np.uint64)[0])          # the host needs M_r for the displacements
-        self.last_counts, total = exchange_records(self.exchange, self.points.ptr, self.keys.ptr, m,
-                                                   self.all_points.ptr, self.all_keys.ptr)
+        self.last_counts, total = exchange_records(self.exchange, self.records.ptr, m, self.all_records.ptr)
         return total
 
     def fetch(self, total: int):
-        """Reassembled cloud on the host: (points float32 [M,3], keys uint32 [M]) in row-major (key) order."""
+        """Reassembled cloud on the host: RECORD_DTYPE array [M] in row-major (key) order."""
         self.ctx.synchronize()
-        return (self.all_points.download((total, 3), np.float32), self.all_keys.download((total,), np.uint32))
+        return self.all_records.download((total,), RECORD_DTYPE)

@@ -10,9 +10,10 @@ and leaves a dense float32 XYZ map + int16 projector maps in HBM.  No torch: HIP
       one rank per GPU: the same scan row-sharded across the N GPUs (configs[3]); each step ends with the RCCL
       all-gatherv that reassembles the compacted point cloud (float32 XYZ + uint32 pixel key) on every rank.
 
-The timed region runs the two-kernel pipeline (decode kernel, then triangulation kernel) so that the graded decode kernel is
-its own launch; at N=1 the single-kernel fused pipeline (decode with the triangulation tail, `--pipeline fused`) is timed right
-after over the same K steps and reported in the extra object "fused_pipeline".
+The timed region runs the library's default pipeline: ONE kernel per scan (the decode kernel with the triangulation tail,
+`--pipeline fused`).  At N=1 the two-kernel pipeline (`--pipeline split`: the decode kernel as its own launch, then the dense
+triangulation kernel) is timed right after over the same K steps and reported in the extra object "split_pipeline", so the
+decode kernel's own roofline fraction (the north star's 60 % target) is measured in the same run.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      decode kernel: algorithmic bytes (N+4 per pixel) / mean launch duration from HIP events recorded on the
@@ -105,6 +106,44 @@ def cpu_baseline(N, crop_w, crop_h, calib, proj_size):
             "c_oracle_value": round(mpix / dt_c, 3), "c_oracle_note": "plain-C scalar oracle, 1 thread, same crop"}
 
 
+def throughput_mode(ctx, _native, G, steps, mode):
+    """BASELINE.json configs[4]: 16 independent 1920x1080x44 scans per step, spread over the G GPUs, no collective
+    (replicas only -- SURVEY.md 8(e)).  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
+    cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
+    per_rank = max(1, 16 // G)
+    ctx.set_calibration(*calibration(cw, ch, pw, ph))
+    px = cw * ch
+    stacks = []
+    for b in range(max(per_rank, 4)):                       # >= 4 distinct stacks (364 MB) so the Infinity Cache cannot serve repeats
+        s = ctx.alloc(n * px)
+        ctx.synth_scene_dev(s.ptr, px, n, ch, cw, seed=11 + b)
+        stacks.append(s)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+
+    def one_step(i):
+        for j in range(per_rank):
+            s = stacks[(i * per_rank + j) % len(stacks)]
+            ctx.scan_dev(s.ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+
+    for i in range(3):
+        one_step(i)
+    ctx.synchronize()
+    if G > 1:
+        ctx.comm_barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(i)
+    ctx.synchronize()
+    if G > 1:
+        ctx.comm_barrier()
+    el = time.perf_counter() - t0
+    if G > 1:
+        el = ctx.comm_allreduce_max(el)
+    for b in stacks + [maps, xyz]:
+        b.free()
+    return el, per_rank * G, px / 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,11 +151,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_4096x3000x44", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="algebraic", choices=["algebraic", "exact"])
-    ap.add_argument("--pipeline", default="split", choices=["split", "fused"],
-                    help="split: decode kernel + triangulation kernel (default); fused: one kernel")
+    ap.add_argument("--pipeline", default="fused", choices=["split", "fused"],
+                    help="fused: decode kernel with the triangulation tail, one launch per scan (default, the library's own choice); "
+                         "split: decode kernel + triangulation kernel")
     ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input stacks rotated between steps")
     args = ap.parse_args()
@@ -209,6 +250,10 @@ def main():
         om = mode_fused if args.pipeline == "split" else mode_split
         other = timed(args.steps, max(2, args.warmup // 2), mode=om)
 
+    thr = None
+    if not args.no_throughput_mode and args.mode == "algebraic" and args.tri == "lut":
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused)
+        ctx.set_calibration(*calib)
     if not use_comm:
         count.zero()
         step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
@@ -244,15 +289,18 @@ def main():
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
         }
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        def add_traffic(roof, pipeline):
+            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), same workload only."""
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
             try:
-                t = json.load(open(tpath)).get(f"{args.workload}/g{G}/{args.pipeline}")
+                t = json.load(open(tpath)).get(f"{args.workload}/g{G}/{pipeline}")
                 if t:
-                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = t.get("source")
+                    roof["traffic"] = t["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = t.get("source")
             except Exception:
                 pass
+
+        add_traffic(out["roofline"], args.pipeline)
         if other is not None:
             o_el, o_kms, o_kn, _ = other
             o_name = "fused" if args.pipeline == "split" else "split"
@@ -260,8 +308,16 @@ def main():
                                          "ms_per_step": round(o_el / args.steps * 1e3, 4), "steps": args.steps,
                                          "roofline": kernel_roofline(o_name, o_kms, o_kn),
                                          "note": "same scan, same run, timed right after the main region"}
+            add_traffic(out[o_name + "_pipeline"]["roofline"], o_name)
+        if thr is not None:
+            t_el, t_scans, t_mpix = thr
+            t_steps = max(5, args.steps // 4)
+            out["throughput_mode"] = {"value": round(t_scans * t_mpix * t_steps / t_el, 1), "unit": "Mpixels/s",
+                                      "config": f"{t_scans} independent 1920x1080x44 scans per step ({t_scans // G} per GPU), no collective "
+                                                "(BASELINE.json configs[4], replicas only)",
+                                      "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "scaling": "weak"}
         if G == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, 1536, 768, calib, (proj_w, proj_h))
+            out["cpu_baseline"] = cpu_baseline(N, 2048, 1024, calib, (proj_w, proj_h))
         print(json.dumps(out), flush=True)
     if G > 1:
         ctx.comm_barrier()

@@ -138,6 +138,10 @@ int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *
 int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
                      unsigned long long *d_count);
 
+/* Same compaction into 16-byte exchange records {float32 x, y, z, uint32 key} (d_records 16-byte aligned). */
+int slgc_compact_records_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, void *d_records,
+                             unsigned long long *d_count);
+
 /* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
 int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                          uint32_t seed, int noise, int shadow);

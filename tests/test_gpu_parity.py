@@ -407,11 +407,11 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
         sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT)
         stack = ctx.alloc(st.nbytes).upload(st)
         total = sc.scan(stack.ptr, H * W)
-        pts, keys = sc.fetch(total)
+        rec = sc.fetch(total)
         ok = (hp != -1) & (vp != -1)
-        assert total == ok.sum() and np.array_equal(keys, np.nonzero(ok.ravel())[0])
-        np.testing.assert_allclose(pts, np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
-        cam, P = sharded.to_reference_lists(pts, keys, W, H)
+        assert total == ok.sum() and np.array_equal(rec["key"], np.nonzero(ok.ravel())[0])
+        np.testing.assert_allclose(rec["xyz"], np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+        cam, P = sharded.to_reference_lists(rec, W, H)
         rcam, _, _ = oc.cam_proj_pts(hp, vp, (W, H), psize, None, order="x")
         assert np.array_equal(cam, rcam) and P.shape == (3, total)
     finally:

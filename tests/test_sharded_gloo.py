@@ -78,12 +78,13 @@ def _worker(rank, world, port, H, W, N, q):
         hp, vp, xyz = oc.scan_dense(band, psize, Kb, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T) if rows else (None, None, np.zeros((3, 0, W)))
         dense = np.moveaxis(xyz, 0, -1).astype(np.float32).reshape(-1, 3)
         ok = np.isfinite(dense[:, 0])
-        pts = np.ascontiguousarray(dense[ok])
-        keys = (np.nonzero(ok)[0] + row0 * W).astype(np.uint32)
+        rec = np.zeros(int(ok.sum()), sharded.RECORD_DTYPE)
+        rec["xyz"] = dense[ok]
+        rec["key"] = (np.nonzero(ok)[0] + row0 * W).astype(np.uint32)
         # ---- the code under test: layout + exchange + reassembly
-        all_pts = np.zeros((H * W, 3), np.float32)
-        all_keys = np.zeros(H * W, np.uint32)
-        counts, total = sharded.exchange_records(ex, pts, keys, len(pts), all_pts, all_keys)
+        all_rec = np.zeros(H * W, sharded.RECORD_DTYPE)
+        counts, total = sharded.exchange_records(ex, rec, len(rec), all_rec)
+        all_pts, all_keys = all_rec["xyz"], all_rec["key"]
         ex.barrier()
         # ---- reference: the whole image in one go
         fh, fv, fxyz = oc.scan_dense(st, psize, K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
@@ -92,7 +93,7 @@ def _worker(rank, world, port, H, W, N, q):
         assert total == int(fok.sum()) and sum(counts) == total and len(counts) == world
         assert np.array_equal(all_keys[:total], np.nonzero(fok)[0].astype(np.uint32))       # band-major == row-major
         np.testing.assert_allclose(all_pts[:total], fdense[fok], rtol=1e-6)
-        cam, P = sharded.to_reference_lists(all_pts[:total], all_keys[:total], W, H)
+        cam, P = sharded.to_reference_lists(all_rec[:total], W, H)
         rcam, _, _ = oc.cam_proj_pts(fh, fv, (W, H), psize, None, order="x")
         assert np.array_equal(cam, rcam) and P.shape == (3, total) and P.dtype == np.float64
         dist.destroy_process_group()
@@ -128,8 +129,8 @@ def test_shard_plan_and_layout():
         for (a0, ar), (b0, _) in zip(bands, bands[1:]):
             assert a0 + ar == b0
         assert max(r for _, r in bands) - min(r for _, r in bands) <= 1
-    bc, bd, tot = sharded.gather_layout([3, 0, 5], 12)
-    assert bc == [36, 0, 60] and bd == [0, 36, 36] and tot == 96
+    bc, bd, tot = sharded.gather_layout([3, 0, 5], sharded.RECORD_BYTES)
+    assert bc == [48, 0, 80] and bd == [0, 48, 48] and tot == 128 and sharded.RECORD_DTYPE.itemsize == sharded.RECORD_BYTES
     with pytest.raises(ValueError):
         sharded.gather_layout([1, -1], 4)
     keys = np.array([0 * 4 + 1, 0 * 4 + 3, 1 * 4 + 0, 2 * 4 + 1], dtype=np.uint32)      # W=4: (x,y) = (1,0),(3,0),(0,1),(1,2)
