@@ -470,8 +470,8 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         for (int j = 0; j < 4; ++j) {
             float X = __builtin_nanf(""), Y = X, Z = X;
             if (idx[j] != 0xffffffffu) {
-                const Xyz r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, a.f.T, a.f.t_len);
-                X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
+                const Xyzf r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, a.f.T, a.f.t_len);
+                X = r.x; Y = r.y; Z = r.z;
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }

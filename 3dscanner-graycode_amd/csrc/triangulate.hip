@@ -196,54 +196,7 @@ struct TriConst {
     double t_len;
 };
 
-// Four pixels per lane (8-byte map loads, 32-byte ray loads, 48-byte XYZ stores).
-// ABL (timing-only diagnostics, wrong results): 1 = no projector gather, 2 = wave-contiguous store layout, 3 = no fp64 math.
-template <int MODE, int ABL = 0>
-__global__ void __launch_bounds__(256) k_triangulate_maps_lut(const TriConst tc, const int16_t *__restrict__ h,
-                                                              const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
-                                                              const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
-                                                              int proj_h, int tiles_x, float *__restrict__ xyz,
-                                                              unsigned long long *__restrict__ count)
-{
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned nvalid = 0;
-    if (g < ngroups) {
-        const uint2 hw = reinterpret_cast<const uint2 *>(h)[g], vw = reinterpret_cast<const uint2 *>(v)[g];
-        const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
-        const float cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
-        const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
-        float out[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int hv = (int)(short)(hq[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vq[j >> 1] >> (16 * (j & 1)));
-            const bool ok = !(hv == -1 || vv == -1);                                  // triangulate.py:56
-            float X = __builtin_nanf(""), Y = X, Z = X;
-            if (ok) {
-                const int pu = min(proj_w - 1, hv), pv = min(proj_h - 1, vv);         // :60-61
-                const float2 pr = ABL == 1 ? make_float2(cy[j] + (float)pu, cx[j] + (float)pv) : proj_lut[proj_lut_index(pu, pv, tiles_x)];
-                const Xyz r = ABL == 3 ? Xyz{(double)pr.x, (double)pr.y, (double)cx[j]} : MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len)
-                                                     : law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
-                X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
-                ++nvalid;
-            }
-            out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
-        }
-        if constexpr (ABL == 2) {
-            float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * (g & ~(size_t)63) + (g & 63);
-            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-            dst[64] = make_float4(out[4], out[5], out[6], out[7]);
-            dst[128] = make_float4(out[8], out[9], out[10], out[11]);
-        } else {
-            float4 *dst = reinterpret_cast<float4 *>(xyz) + 3 * g;
-            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
-            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
-        }
-    }
-    if (count) block_count_add(count, nvalid);
-}
-
-// LDS-staged variant (shipped): the per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
+// Dense kernel.  Four pixels per lane (8-byte map loads, 32-byte ray loads).  The per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
 // each projector-table gather instruction touch ~50 cache lines and each XYZ store instruction a 48-byte-strided
 // scatter.  Here the workgroup (1024 pixels) exchanges through LDS instead:
 //   1. every lane turns its 4 decoded pixels into table indices            -> s_idx  (4 KB)
@@ -295,9 +248,13 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     for (int j = 0; j < 4; ++j) {
         float X = __builtin_nanf(""), Y = X, Z = X;
         if (idx[j] != 0xffffffffu) {
-            const Xyz r = MODE == SLGC_TRI_EXACT ? law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len)
-                                                 : law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
-            X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
+            if constexpr (MODE == SLGC_TRI_EXACT) {
+                const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
+                X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
+            } else {
+                const Xyzf r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
+                X = r.x; Y = r.y; Z = r.z;
+            }
             ++nvalid;
         }
         out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
@@ -398,25 +355,11 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         tc.t_len = ctx->calib.t_len;
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
-        const char *abl_env = getenv("SLGC_TRI_ABL");
-        const int abl = abl_env ? atoi(abl_env) : 0;
-#define SLGC_TRI_ABL_LAUNCH(A) hipLaunchKernelGGL((k_triangulate_maps_lut<SLGC_TRI_ALGEBRAIC, A>), dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, \
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count)
-        if (abl == 0) {
-            if (mode == SLGC_TRI_EXACT)
-                hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                                   (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
-            else
-                hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                                   (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
-        } else if (abl == 1) SLGC_TRI_ABL_LAUNCH(1);
-        else if (abl == 2) SLGC_TRI_ABL_LAUNCH(2);
-        else if (abl == 3) SLGC_TRI_ABL_LAUNCH(3);
-        else if (mode == SLGC_TRI_EXACT)
-            hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+        if (mode == SLGC_TRI_EXACT)
+            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
         else
-            hipLaunchKernelGGL(k_triangulate_maps_lut<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
