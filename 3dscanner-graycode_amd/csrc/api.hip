@@ -146,7 +146,7 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     slgc_comm_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < SLGC_WS_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
@@ -468,6 +468,127 @@ extern "C" int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_
         if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, d_xo, K * 24, hipMemcpyDeviceToHost, ctx->stream));
         if (colors_out && ctx->filt_colors) HIP_TRY(ctx, hipMemcpyAsync(colors_out, d_co, K * 24, hipMemcpyDeviceToHost, ctx->stream));
     }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ whole pipeline, one upload
+// Driver glue of the reference in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, merge,
+// gray_to_decimal) followed by src/4-triangulate.py:50-71 (get_cam_proj_pts, triangulate, filter_3d_pts).
+extern "C" int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, int H, int W, double eps,
+                                   double m, int proj_w, int proj_h, const uint8_t *white_rgb, int order, int mode, double threshold,
+                                   int64_t *M)
+{
+    (void)m;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->pipe_M = -1;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if ((rc = check_dims(ctx, dtype, N, H, W))) return rc;
+    if (!stacks || !M) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (std::isnan(eps)) return slgc_fail(ctx, SLGC_EINVAL, "eps is NaN");
+    if (order != SLGC_ORDER_X && order != SLGC_ORDER_ROW) return slgc_fail(ctx, SLGC_EINVAL, "bad order");
+    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    DecodeGeom g;
+    if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d (max %d)", N, n_runs, SLGC_MAX_RUNS);
+    const size_t npix = (size_t)H * W;
+    RunPtrs runs{};
+    if ((rc = upload_runs(ctx, stacks, dtype, n_runs, N, npix, &runs))) return rc;
+    // 1. decode -> int64 maps (slot 3)
+    void *d_maps;
+    if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
+    int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
+    int e;
+    if (dtype == SLGC_U8 && decode_fast_eligible(eps, &e)) {
+        void *d16;
+        if ((rc = slgc_ws(ctx, 2, npix * 4 + 128, &d16))) return rc;
+        int16_t *d_h16 = (int16_t *)d16, *d_v16 = d_h16 + ((npix + 31) & ~(size_t)31);
+        rc = launch_decode_fast(ctx, g, runs, npix, H, W, e, d_h16, d_v16, 0);
+        if (!rc) rc = launch_widen_maps(ctx, d_h16, d_v16, npix, d_h, d_v);
+    } else {
+        rc = launch_decode_generic(ctx, g, runs, dtype, npix, npix, eps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, d_h, d_v);
+    }
+    if (rc) return rc;
+    // 2. correspondences (slot 8: colours | cam | proj), colour source in slot 1
+    void *d_white = nullptr, *d_corr, *d_total;
+    if ((rc = slgc_ws(ctx, 8, npix * (8 + 8 + (white_rgb ? 24 : 0)) + 64, &d_corr))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_total))) return rc;
+    if (white_rgb) {
+        if ((rc = slgc_ws(ctx, 1, npix * 3, &d_white))) return rc;
+        if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_white, white_rgb, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double *d_colors = (double *)d_corr;
+    float *d_cam = (float *)((char *)d_corr + (white_rgb ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
+    if ((rc = launch_correspond(ctx, d_h, d_v, W, H, proj_w, proj_h, (const uint8_t *)d_white, order, d_cam, d_proj, d_colors,
+                                (unsigned long long *)d_total)))
+        return rc;
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // 3. triangulate (slot 9: xyz (3,M) float64)
+    void *d_xyz;
+    if ((rc = slgc_ws(ctx, 9, (size_t)total * 24, &d_xyz))) return rc;
+    if ((rc = launch_triangulate_list(ctx, d_cam, d_proj, (int64_t)total, mode, (double *)d_xyz))) return rc;
+    ctx->pipe_M_raw = (int64_t)total;
+    ctx->pipe_npix = npix;
+    ctx->pipe_colors = white_rgb != nullptr;
+    ctx->pipe_filtered = false;
+    ctx->pipe_M = (int64_t)total;
+    // 4. optional box filter (slot 10: xyz' | colours')
+    if (!std::isnan(threshold)) {
+        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, nullptr, nullptr,
+                                (unsigned long long *)d_total, 0)))
+            return rc;
+        unsigned long long kept = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        void *d_f;
+        if ((rc = slgc_ws(ctx, 10, (size_t)kept * (24 + (white_rgb ? 24 : 0)), &d_f))) return rc;
+        double *d_fx = (double *)d_f, *d_fc = white_rgb ? d_fx + 3 * (size_t)kept : nullptr;
+        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, d_fx, d_fc,
+                                (unsigned long long *)d_total, 1)))
+            return rc;
+        ctx->pipe_filtered = true;
+        ctx->pipe_M = (int64_t)kept;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pend_M = -1;
+    ctx->filt_M = -1;
+    *M = ctx->pipe_M;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_pixels, double *xyz, double *colors, int64_t *M_unfiltered,
+                                   float *cam_pts, float *proj_pts)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->pipe_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending pipeline result (call slgc_pipeline_count first)");
+    const size_t npix = ctx->pipe_npix, M = (size_t)ctx->pipe_M, Mr = (size_t)ctx->pipe_M_raw;
+    const int64_t *d_h = (const int64_t *)ctx->ws[3];
+    if (npix) {
+        if (h_pixels) HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (v_pixels) HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_h + npix, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    const char *d_corr = (const char *)ctx->ws[8];
+    const double *d_colors = (const double *)d_corr;
+    const float *d_cam = (const float *)(d_corr + (ctx->pipe_colors ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
+    if (Mr) {
+        if (cam_pts) HIP_TRY(ctx, hipMemcpyAsync(cam_pts, d_cam, Mr * 8, hipMemcpyDeviceToHost, ctx->stream));      // unfiltered lists
+        if (proj_pts) HIP_TRY(ctx, hipMemcpyAsync(proj_pts, d_proj, Mr * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (M) {
+        if (ctx->pipe_filtered) {
+            const double *d_fx = (const double *)ctx->ws[10];
+            if (xyz) HIP_TRY(ctx, hipMemcpyAsync(xyz, d_fx, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+            if (colors && ctx->pipe_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_fx + 3 * M, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            if (xyz) HIP_TRY(ctx, hipMemcpyAsync(xyz, ctx->ws[9], M * 24, hipMemcpyDeviceToHost, ctx->stream));
+            if (colors && ctx->pipe_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_colors, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    if (M_unfiltered) *M_unfiltered = ctx->pipe_M_raw;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }

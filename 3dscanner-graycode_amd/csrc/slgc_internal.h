@@ -11,6 +11,7 @@
 
 #define SLGC_MAX_RUNS 8
 #define SLGC_MAX_EVENTS 16
+#define SLGC_WS_SLOTS 12
 
 // Frame bookkeeping of one decode call; the index arithmetic follows the reference exactly
 // (decode_codes.py:109-111 float pattern_len + uint8 truncation; :149 int pattern_len).
@@ -43,8 +44,8 @@ struct slgc_ctx {
     hipEvent_t events[SLGC_MAX_EVENTS];
     char err[512];
     // workspace (grown on demand, reused across calls)
-    void *ws[8];
-    size_t ws_bytes[8];
+    void *ws[SLGC_WS_SLOTS];
+    size_t ws_bytes[SLGC_WS_SLOTS];
     // calibration
     bool have_calib;
     Calib calib;
@@ -60,6 +61,10 @@ struct slgc_ctx {
     bool pend_colors;
     int64_t filt_M;
     bool filt_colors;
+    // slgc_pipeline_* results kept on the device between _count and _fetch
+    int64_t pipe_M, pipe_M_raw;
+    size_t pipe_npix;
+    bool pipe_colors, pipe_filtered;
     // per-launch HIP-event timing of the decode kernel (slgc_prof_*), recorded on the launch stream
     bool prof_on;
     hipEvent_t *prof_ev;   // pairs: [2i] before, [2i+1] after the decode launch

@@ -7,3 +7,4 @@ calibration and visualisation are out of scope and stay wi
 """
 from . import _native  # noqa: F401
 from ._native import Context, SlgcError, default_context  # noqa: F401
+from .pipeline import scan_to_cloud  # noqa: F401,E402

@@ -48,6 +48,8 @@ SIGNATURES = {
     "slgc_triangulate": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "slgc_filter_count": (_i, [_vp, _vp, _vp, _i64, _d, C.POINTER(_i64)]),
     "slgc_filter_fetch": (_i, [_vp, _vp, _vp]),
+    "slgc_pipeline_count": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64)]),
+    "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "slgc_dev_free": (_i, [_vp, _vp]),
     "slgc_h2d": (_i, [_vp, _vp, _vp, _sz]),
@@ -319,6 +321,41 @@ class Context:
         co = None if c is None else np.empty((kept.value, 3), np.float64)
         self._ck(lib().slgc_filter_fetch(self._h, _ptr(xo), _ptr(co)))
         return xo, co
+
+    def pipeline(self, runs, proj_size, img_white=None, threshold=None, eps=1, m=10, order=ORDER_X, mode=TRI_EXACT,
+                 want_maps=True, want_lists=False):
+        """Whole reference pipeline with one upload (set_calibration first).  Returns a dict: pts (3,M) float64, colors
+        [M,3] or None, h_pixels / v_pixels int64 (if want_maps), cam_pts / proj_pts (unfiltered lists, if want_lists)."""
+        arr = runs if isinstance(runs, np.ndarray) else None
+        stacks = [arr] if (arr is not None and arr.ndim == 3) else list(runs)
+        prepared = [self._stack(s) for s in stacks]
+        if len({dt for _, dt in prepared}) != 1 or len({s.shape for s, _ in prepared}) != 1:
+            raise ValueError("all runs must share dtype and shape")
+        dt = prepared[0][1]
+        N, H, W = prepared[0][0].shape
+        wh = None
+        if img_white is not None:
+            wh = np.ascontiguousarray(np.asarray(img_white)[:H, :W, :3], dtype=np.uint8)
+            if wh.shape != (H, W, 3):
+                raise ValueError("img_white must be [H,W,3]")
+        ptrs = (C.c_void_p * len(prepared))(*[s.ctypes.data for s, _ in prepared])
+        M = C.c_int64()
+        thr = float("nan") if threshold is None else float(threshold)
+        self._ck(lib().slgc_pipeline_count(self._h, ptrs, dt, len(prepared), N, H, W, float(eps), float(m), int(proj_size[0]),
+                                           int(proj_size[1]), _ptr(wh), int(order), int(mode), thr, C.byref(M)))
+        n = M.value
+        out = {"pts": np.empty((3, n), np.float64), "colors": np.empty((n, 3), np.float64) if wh is not None else None}
+        hp = vp = cam = proj = None
+        if want_maps:
+            hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+        raw = C.c_int64()
+        # first fetch learns the unfiltered length when the lists are wanted
+        self._ck(lib().slgc_pipeline_fetch(self._h, _ptr(hp), _ptr(vp), _ptr(out["pts"]), _ptr(out["colors"]), C.byref(raw), None, None))
+        if want_lists:
+            cam, proj = np.empty((raw.value, 2), np.float32), np.empty((raw.value, 2), np.float32)
+            self._ck(lib().slgc_pipeline_fetch(self._h, None, None, None, None, None, _ptr(cam), _ptr(proj)))
+        out.update(h_pixels=hp, v_pixels=vp, cam_pts=cam, proj_pts=proj, n_unfiltered=int(raw.value))
+        return out
 
     # ---- device-resident entry points (enqueue only)
     def decode_dev(self, d_stack: int, n_runs, run_stride, plane_stride, N, rows, W, d_h: int, d_v: int, eps=1, m=10, variant=0):

@@ -108,6 +108,17 @@ int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float *proj_pts,
 int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept);
 int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_out);
 
+/* ------------------------------------------------------------------ whole pipeline, one upload */
+
+/* The reference's driver glue in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, max-merge,
+ * gray_to_decimal) then src/4-triangulate.py:50-71 (get_cam_proj_pts, triangulate, filter_3d_pts when threshold is not NaN).
+ * _count runs it and returns the number of points (after the filter); _fetch copies out whatever pointers are non-NULL:
+ * maps int64 [H][W]; xyz float64 (3,M); colors float64 [M][3]; cam/proj float32 [M_unfiltered][2] (the lists before the filter). */
+int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, int H, int W, double eps, double m,
+                        int proj_w, int proj_h, const uint8_t *white_rgb, int order, int mode, double threshold, int64_t *M);
+int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_pixels, double *xyz, double *colors, int64_t *M_unfiltered,
+                        float *cam_pts, float *proj_pts);
+
 /* ------------------------------------------------------------------ device-resident path (what bench.py times) */
 int slgc_dev_alloc(slgc_ctx *ctx, size_t bytes, void **dptr);
 int slgc_dev_free(slgc_ctx *ctx, void *dptr);

@@ -416,3 +416,134 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
         assert np.array_equal(cam, rcam) and P.shape == (3, total)
     finally:
         ctx.comm_destroy()
+
+
+# ----------------------------------------------------------------------------------------- robustness
+def test_call_order_and_error_paths(calib):
+    from scanner import _native
+    c = _native.Context(0)
+    try:
+        with pytest.raises(_native.SlgcError, match="set_calibration"):
+            c.triangulate(np.zeros((4, 2), np.float32), np.zeros((4, 2), np.float32))
+        buf = c.alloc(64)
+        with pytest.raises(_native.SlgcError, match="set_calibration"):
+            c.scan_dev(buf.ptr, 1, 64, 4, 14, 1, 4, 0, (4, 4), buf.ptr)
+        with pytest.raises(ValueError):
+            c.decode_dev(buf.ptr, 1, 64, 4, 14, 1, 4, buf.ptr, buf.ptr, eps=0.5)      # device path needs an integer eps
+        with pytest.raises(ValueError):
+            c.decode_dev(buf.ptr, 1, 64, 2, 14, 1, 4, buf.ptr, buf.ptr)               # plane_stride smaller than the band
+        with pytest.raises(ValueError):
+            c.set_calibration(np.eye(3), np.zeros(15), np.eye(3), None, np.eye(3), np.zeros(3))
+        with pytest.raises(ValueError):
+            c.set_calibration(np.eye(3), [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.1, 0], np.eye(3), None, np.eye(3), np.zeros(3))   # tilt
+        with pytest.raises(_native.SlgcError):
+            c.comm_barrier()                                                           # no communicator
+        with pytest.raises(ValueError):
+            c.decode([np.zeros((14, 4, 4), np.uint8)] * 9)                              # more runs than SLGC_MAX_RUNS
+        with pytest.raises(ValueError):
+            c.decode([np.zeros((14, 4, 4), np.uint8), np.zeros((14, 4, 5), np.uint8)])
+    finally:
+        c.close()
+
+
+def test_two_contexts_in_two_threads(decode_cases):
+    """Contexts are independent (own stream + workspace); ctypes releases the GIL, so two Python threads overlap."""
+    import threading
+    from scanner import _native
+    rng = np.random.default_rng(21)
+    stacks = [rng.integers(0, 256, (44, 200, 320), dtype=np.uint8) for _ in range(2)]
+    refs = [oc.decode(s) for s in stacks]
+    errs = []
+
+    def worker(i):
+        try:
+            c = _native.Context(0)
+            for _ in range(5):
+                hp, vp = c.decode(stacks[i])
+                assert np.array_equal(hp, refs[i][0]) and np.array_equal(vp, refs[i][1])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("N,eps", [(65, 1), (14, 0), (30, 3), (58, 255)])
+def test_decode_extreme_frame_counts_and_eps(ctx, N, eps):
+    rng = np.random.default_rng(N + eps)
+    st = rng.integers(0, 256, (2, N, 41, 52), dtype=np.uint8)
+    st[1, :, 10:30] = np.clip(st[0, :, 10:30].astype(int) + rng.integers(-2, 3, st[0, :, 10:30].shape), 0, 255)
+    ref = oc.decode(st, eps=eps)
+    hp, vp = ctx.decode(list(st), eps=eps)
+    assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1])
+    h, v = dev_decode(ctx, st, 0, eps=eps)
+    assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1])
+    assert hp.max() <= (1 << int((N - 2) / 4)) - 1
+
+
+def test_scan_dev_ragged_sizes(ctx, calib):
+    """Bands whose pixel count is not a multiple of 4 (or whose width is odd) take the two-kernel path with byte-wide tails."""
+    N = 26
+    K = calib["cam_mtx"].copy()
+    psize = (200, 150)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    for (H, W) in ((7, 33), (5, 64), (9, 130)):
+        st, _, _ = onp.synth_scene_int(N, H, W, seed=H)
+        K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 150.0, 150.0
+        ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+        hp, vp, ref = oc.scan_dense(st, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+        stack = ctx.alloc(st.nbytes + 64).upload(st)
+        xyz = ctx.alloc(H * W * 12 + 64)
+        ctx.scan_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, 0, psize, xyz.ptr, None, mode=1)
+        ctx.synchronize()
+        got = xyz.download((H, W, 3), np.float32)
+        ok = (hp != -1) & (vp != -1)
+        assert np.array_equal(np.isfinite(got[..., 0]), ok)
+        np.testing.assert_allclose(got[ok], np.moveaxis(ref, 0, -1)[ok], rtol=XYZ_RTOL, atol=0)
+        stack.free()
+        xyz.free()
+
+
+def test_scan_to_cloud_matches_reference_pipeline(calib):
+    """One-upload pipeline == the reference's script 3 tail + script 4 (restated by the oracle) on the same captures."""
+    from scanner import scan_to_cloud
+    N, H, W = 42, 72, 160
+    rng = np.random.default_rng(31)
+    run0, _, _ = onp.synth_scene_int(N, H, W, seed=3, noise=4)
+    run1, _, _ = onp.synth_scene_int(N, H, W, seed=4, noise=9)
+    white = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 220.0, 220.0
+    psize, pcal = (200, 150), (1920, 1080)
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    pm = calib["proj_mtx"].copy()
+    pk = onp.scale_proj_mtx(pm, psize, pcal)
+    for runs in ([run0], [run0, run1], [run0.astype(np.float64), run1.astype(np.float64)]):
+        rh, rv = oc.decode(np.stack(runs))
+        rcam, rproj, rcol = oc.cam_proj_pts(rh, rv, (W, H), psize, white, order="x")
+        rpts = oc.triangulate(rcam, rproj, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+        for thr in (None, 0.5):
+            out = scan_to_cloud(runs if len(runs) > 1 else runs[0], K, calib["cam_dist"], psize, pcal, pm, calib["proj_dist"], R, T,
+                                img_white=white, threshold=thr, return_lists=True)
+            assert np.array_equal(pm, calib["proj_mtx"])                                   # not mutated
+            assert np.array_equal(out["h_pixels"], rh) and np.array_equal(out["v_pixels"], rv)
+            assert np.array_equal(out["cam_pts"], rcam) and np.array_equal(out["proj_pts"], rproj)
+            if thr is None:
+                epts, ecol = rpts, rcol
+            else:
+                epts, ecol = oc.filter_3d_pts(rpts, rcol, thr)
+                # the box filter is a strict compare on fp64 values that may differ in the last bits: compare on the oracle's mask
+                keep = (np.abs(rpts) < thr).all(axis=0)
+                borderline = np.abs(np.abs(rpts) - thr).min(axis=0) < 1e-9
+                assert not borderline[keep].any()
+            assert out["pts"].shape == epts.shape and out["pts"].dtype == np.float64
+            np.testing.assert_allclose(out["pts"], epts, rtol=1e-9, atol=1e-12)
+            assert np.array_equal(out["colors"], ecol)
+    out = scan_to_cloud(run0, K, calib["cam_dist"], psize, pcal, pm, calib["proj_dist"], R, T)      # no colours, no filter
+    assert out["colors"] is None and out["pts"].shape[1] == out["n_unfiltered"] > 100
