@@ -472,6 +472,52 @@ extern "C" int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_
     return SLGC_OK;
 }
 
+// ------------------------------------------------------------------------------------------ ingest ("next" rows)
+extern "C" int slgc_to_gray(slgc_ctx *ctx, const uint8_t *bgr, int n_frames, int H, int W, int coeff_bits, uint8_t *gray)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!bgr || !gray || n_frames < 0 || H < 0 || W < 0) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative size");
+    if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
+    const size_t npix = (size_t)n_frames * H * W;
+    void *d_in, *d_out;
+    if ((rc = slgc_ws(ctx, 0, npix * 3, &d_in))) return rc;
+    if ((rc = slgc_ws(ctx, 2, npix, &d_out))) return rc;
+    if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_in, bgr, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)d_in, (uint8_t *)d_out, npix, coeff_bits))) return rc;
+    if (npix) HIP_TRY(ctx, hipMemcpyAsync(gray, d_out, npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_to_gray_dev(slgc_ctx *ctx, const uint8_t *d_bgr, size_t npix, int coeff_bits, uint8_t *d_gray)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_bgr || !d_gray) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
+    return launch_bgr_to_gray(ctx, d_bgr, d_gray, npix, coeff_bits);
+}
+
+extern "C" int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
+                                      int64_t *counts)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (dtype != SLGC_U8 && dtype != SLGC_F64) return slgc_fail(ctx, SLGC_EINVAL, "dtype must be SLGC_U8 or SLGC_F64");
+    if (n_frames < 0 || (n_frames > 1 && (!frames || !counts))) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative size");
+    if (n_frames < 2) return SLGC_OK;
+    const size_t bytes = (size_t)n_frames * elems_per_frame * esize(dtype);
+    void *d_in, *d_cnt;
+    if ((rc = slgc_ws(ctx, 0, bytes, &d_in))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 8 * (size_t)n_frames + 64, &d_cnt))) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(d_in, frames, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_frame_diff_counts(ctx, d_in, dtype, n_frames, elems_per_frame, thresh, (unsigned long long *)d_cnt))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(counts, d_cnt, 8 * (size_t)(n_frames - 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
 // ------------------------------------------------------------------------------------------ whole pipeline, one upload
 // Driver glue of the reference in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, merge,
 // gray_to_decimal) followed by src/4-triangulate.py:50-71 (get_cam_proj_pts, triangulate, filter_3d_pts).

@@ -118,3 +118,7 @@ int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_
 // synth.hip
 int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
                  int noise, int shadow);
+// ingest.hip
+int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
+int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
+                             unsigned long long *d_counts);

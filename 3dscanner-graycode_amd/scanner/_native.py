@@ -48,6 +48,9 @@ SIGNATURES = {
     "slgc_triangulate": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "slgc_filter_count": (_i, [_vp, _vp, _vp, _i64, _d, C.POINTER(_i64)]),
     "slgc_filter_fetch": (_i, [_vp, _vp, _vp]),
+    "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "slgc_to_gray_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "slgc_frame_diff_counts": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
     "slgc_pipeline_count": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64)]),
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -321,6 +324,24 @@ class Context:
         co = None if c is None else np.empty((kept.value, 3), np.float64)
         self._ck(lib().slgc_filter_fetch(self._h, _ptr(xo), _ptr(co)))
         return xo, co
+
+    def to_gray(self, images, coeff_bits=15):
+        im = np.ascontiguousarray(np.asarray(images).astype(np.uint8, copy=False))
+        if im.ndim != 4 or im.shape[3] != 3:
+            raise ValueError("images must be [n,H,W,3]")
+        n, H, W, _ = im.shape
+        out = np.empty((n, H, W), np.uint8)
+        self._ck(lib().slgc_to_gray(self._h, _ptr(im), n, H, W, int(coeff_bits), _ptr(out)))
+        return out
+
+    def frame_diff_counts(self, frames, thresh):
+        fr = np.asarray(frames)
+        fr = np.ascontiguousarray(fr) if fr.dtype == np.uint8 else np.ascontiguousarray(fr, dtype=np.float64)
+        n = fr.shape[0]
+        elems = int(np.prod(fr.shape[1:])) if n else 0
+        out = np.zeros(max(n - 1, 0), np.int64)
+        self._ck(lib().slgc_frame_diff_counts(self._h, _ptr(fr), U8 if fr.dtype == np.uint8 else F64, n, elems, float(thresh), _ptr(out)))
+        return out
 
     def pipeline(self, runs, proj_size, img_white=None, threshold=None, eps=1, m=10, order=ORDER_X, mode=TRI_EXACT,
                  want_maps=True, want_lists=False):

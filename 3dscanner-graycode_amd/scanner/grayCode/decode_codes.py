@@ -11,10 +11,53 @@ get_codes -> run merge -> gray_to_decimal (src/3-capture_decode.py:75-100) into 
 """
 from __future__ import annotations
 
+import numpy as np
+
 from .._native import default_context
 
-__all__ = ["get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
+__all__ = ["read_images_order", "remove_bad_images", "to_gray", "get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
            "codes_to_pixels", "decode"]
+
+
+def read_images_order(file_names):
+    """File order of the reference's read_images (decode_codes.py:22): ``sorted(os.listdir(folder), key=len)`` -- a stable
+    sort by NAME LENGTH only, so frame_2.jpg sorts before frame_10.jpg but equal-length names keep listdir order.  The image
+    decoding itself (cv2.imread) stays with the caller: JPEG decoding is outside this build's scope."""
+    return sorted(file_names, key=len)
+
+
+def remove_bad_images(images, ctx=None):
+    """Indexes of the frames to keep (transition frames dropped), reference decode_codes.py:34-68.
+
+    The per-pair ``len(np.argwhere(cv2.absdiff(a, b) > 50))`` counts are one GPU reduction over all consecutive pairs
+    (csrc/ingest.hip); the keep/drop state machine of :56-66 is restated here unchanged in meaning.  ``images`` is the
+    reference's ``[n,H,W,3]`` (or ``[n,H,W]``) array, float64 or uint8."""
+    diff_thresh = 50
+    n = len(images)
+    d = [int(x) for x in (ctx or default_context()).frame_diff_counts(images, diff_thresh)]     # d[j] = count(|im[j+1]-im[j]| > 50)
+    diff1, diff2 = d[0], d[1]
+    kept = []
+    for i in range(n - 3):                                     # the reference iterates images[2:-1]
+        diff3 = d[i + 2]                                       # absdiff(images[i+3], images[i+2])
+        if diff1 < diff2 and diff1 < diff3 and diff2 < diff3 and i + 1 not in kept:
+            if len(kept) == 0 or (kept[-1] != i and kept[-1] != i + 2):
+                kept.append(i + 1)
+        elif diff2 <= diff1 and diff2 <= diff3 and i + 2 not in kept:
+            if len(kept) == 0 or (kept[-1] != i + 1 and kept[-1] != i + 3):
+                kept.append(i + 2)
+                diff3 = -1
+                diff2 = -1
+        diff1 = diff2
+        diff2 = diff3
+    return kept
+
+
+def to_gray(images, ctx=None, coeff_bits=15):
+    """Reference decode_codes.py:70-87: BGR -> grey per frame, returned as the float64 ``[n,H,W]`` array the reference
+    returns.  The arithmetic is OpenCV's 8-bit fixed-point luma (see csrc/ingest.hip); OpenCV 4.8.0.76 is not available
+    in the build container, so this function's parity with cv2.cvtColor is UNPINNED.  For the decode path prefer
+    ``Context.to_gray`` which keeps the uint8 stack."""
+    return (ctx or default_context()).to_gray(images, coeff_bits).astype(np.float64)
 
 
 def get_direct_indirect(images, ctx=None):

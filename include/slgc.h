@@ -108,6 +108,19 @@ int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float *proj_pts,
 int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept);
 int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_out);
 
+/* ------------------------------------------------------------------ ingest (the frames either side of the path) */
+
+/* to_gray(images) -- decode_codes.py:70-87 / src/3-capture_decode.py:66: cv2.cvtColor(BGR2GRAY) of n 8-bit BGR frames
+ * [n][H][W][3] into the uint8 stack [n][H][W].  coeff_bits 15 = OpenCV 4.x fixed-point luma (9798, 19235, 3735), 14 = the
+ * older (4899, 9617, 1868) set.  OpenCV is third-party and not installed in the build container: PARITY UNPINNED. */
+int slgc_to_gray(slgc_ctx *ctx, const uint8_t *bgr, int n_frames, int H, int W, int coeff_bits, uint8_t *gray);
+int slgc_to_gray_dev(slgc_ctx *ctx, const uint8_t *d_bgr, size_t npix, int coeff_bits, uint8_t *d_gray);
+
+/* The arithmetic of remove_bad_images (decode_codes.py:34-68): counts[j] = number of elements with
+ * |frames[j+1] - frames[j]| > thresh, j = 0 .. n_frames-2 (cv2.absdiff + np.argwhere + len).  frames: [n][elems]. */
+int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
+                           int64_t *counts);
+
 /* ------------------------------------------------------------------ whole pipeline, one upload */
 
 /* The reference's driver glue in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, max-merge,

@@ -406,3 +406,40 @@ def synth_scene_int(n_frames: int, H: int, W: int, seed: int = 1, noise: int = 3
             x ^= x >> np.uint32(16)
         img += (x % np.uint32(2 * noise + 1)).astype(np.int64) - noise
     return np.clip(img, 0, 255).astype(np.uint8), xs, ys
+
+
+# ----------------------------------------------------------------------------- "next" rows
+
+
+def frame_diff_counts(images, thresh=50):
+    """counts[j] = len(np.argwhere(cv2.absdiff(images[j+1], images[j]) > thresh)) -- decode_codes.py:49-53."""
+    im = np.asarray(images, dtype=np.float64)
+    return np.array([int((np.abs(im[j + 1] - im[j]) > thresh).sum()) for j in range(len(im) - 1)], dtype=np.int64)
+
+
+def remove_bad_images(images):
+    """decode_codes.py:34-68 (transition-frame filter); cv2.absdiff restated as |a - b| (OpenCV absent: that one call is
+    unpinned, the state machine is pinned by tests/golden/ingest.npz)."""
+    d = frame_diff_counts(images, 50)
+    diff1, diff2 = int(d[0]), int(d[1])
+    kept = []
+    for i in range(len(images) - 3):
+        diff3 = int(d[i + 2])
+        if diff1 < diff2 and diff1 < diff3 and diff2 < diff3 and i + 1 not in kept:
+            if len(kept) == 0 or (kept[-1] != i and kept[-1] != i + 2):
+                kept.append(i + 1)
+        elif diff2 <= diff1 and diff2 <= diff3 and i + 2 not in kept:
+            if len(kept) == 0 or (kept[-1] != i + 1 and kept[-1] != i + 3):
+                kept.append(i + 2)
+                diff3 = -1
+                diff2 = -1
+        diff1, diff2 = diff2, diff3
+    return kept
+
+
+def bgr_to_gray(images, coeff_bits=15):
+    """OpenCV 8-bit BGR2GRAY fixed-point luma (PARITY UNPINNED: cv2 not installed): 4.x uses 15-bit coefficients
+    (R 9798, G 19235, B 3735), older releases 14-bit (4899, 9617, 1868); rounding = + half, then shift."""
+    im = np.asarray(images).astype(np.int64)
+    ry, gy, by = (9798, 19235, 3735) if coeff_bits == 15 else (4899, 9617, 1868)
+    return ((im[..., 0] * by + im[..., 1] * gy + im[..., 2] * ry + (1 << (coeff_bits - 1))) >> coeff_bits).astype(np.uint8)

@@ -30,6 +30,7 @@ import oracle_np as onp  # noqa: E402  (only for the cv2 stand-ins and synthetic
 cv2_stub = types.ModuleType("cv2")
 cv2_stub.undistortPoints = lambda src, K, dist, R=None: onp.undistort_points(src, K, dist, R=R)
 cv2_stub.convertPointsToHomogeneous = lambda src: onp.to_homogeneous(src)
+cv2_stub.absdiff = lambda a, b: np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))   # float64 frames: exact |a-b|
 sys.modules["cv2"] = cv2_stub
 sys.path.insert(0, "/root/reference")
 from scanner.grayCode import decode_codes as ref_dc  # noqa: E402
@@ -193,6 +194,24 @@ def main():
         print("triangulate", name, "M =", cam_pts.shape[0], "kept", fp.shape[1],
               "nan:", int(np.isnan(pts).any(axis=0).sum()))
     np.savez_compressed(os.path.join(HERE, "triangulate.npz"), **tri)
+    # ------------------------------------------------------------------ remove_bad_images (decode_codes.py:34-68)
+    ing = {}
+    rng = np.random.default_rng(17)
+    for name, n in (("a", 24), ("b", 31), ("c", 9)):
+        # a capture: each projected pattern held for 2-3 frames with 0-1 blended transition frames in between
+        pats = rng.integers(0, 256, (n, 6, 8, 3)).astype(np.float64)
+        frames = []
+        for k in range(n):
+            if k and rng.random() < 0.6:
+                a = rng.uniform(0.2, 0.8)
+                frames.append(np.floor(a * pats[k - 1] + (1 - a) * pats[k]))
+            frames.extend([pats[k] + rng.integers(-2, 3, pats[k].shape)] * int(rng.integers(1, 4)))
+        seq = np.array(frames)
+        ing[f"{name}/frames"] = seq
+        ing[f"{name}/kept"] = np.array(ref_dc.remove_bad_images(seq), dtype=np.int64)
+        print("remove_bad_images", name, len(seq), "->", len(ing[f"{name}/kept"]))
+    np.savez_compressed(os.path.join(HERE, "ingest.npz"), **ing)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -547,3 +547,33 @@ def test_scan_to_cloud_matches_reference_pipeline(calib):
             assert np.array_equal(out["colors"], ecol)
     out = scan_to_cloud(run0, K, calib["cam_dist"], psize, pcal, pm, calib["proj_dist"], R, T)      # no colours, no filter
     assert out["colors"] is None and out["pts"].shape[1] == out["n_unfiltered"] > 100
+
+
+# ----------------------------------------------------------------------------------------- ingest ("next" rows)
+def test_remove_bad_images_and_diff_counts(ctx):
+    from conftest import load_cases
+    from scanner.grayCode.decode_codes import remove_bad_images
+    for name, c in load_cases("ingest.npz").items():
+        fr = c["frames"]
+        assert np.array_equal(ctx.frame_diff_counts(fr, 50), onp.frame_diff_counts(fr, 50)), name
+        assert remove_bad_images(fr, ctx=ctx) == list(c["kept"]), name                   # the reference's own output
+        u8 = np.clip(fr, 0, 255).astype(np.uint8)
+        assert np.array_equal(ctx.frame_diff_counts(u8, 50), onp.frame_diff_counts(u8, 50)), name
+    rng = np.random.default_rng(41)
+    big = rng.integers(0, 256, (5, 301, 517, 3), dtype=np.uint8)
+    assert np.array_equal(ctx.frame_diff_counts(big, 50), onp.frame_diff_counts(big, 50))
+    assert ctx.frame_diff_counts(big[:1], 50).shape == (0,)
+
+
+def test_to_gray_fixed_point_luma(ctx):
+    """OpenCV's BGR2GRAY arithmetic (parity with cv2 itself is unpinned: OpenCV is not installed in the build container)."""
+    from scanner.grayCode.decode_codes import to_gray
+    rng = np.random.default_rng(42)
+    for shape in ((3, 40, 64, 3), (2, 37, 53, 3), (1, 1, 1, 3)):
+        im = rng.integers(0, 256, shape, dtype=np.uint8)
+        for bits in (15, 14):
+            assert np.array_equal(ctx.to_gray(im, bits), onp.bgr_to_gray(im, bits))
+    im = np.zeros((1, 2, 4, 3), np.uint8)
+    im[0, 0] = [[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
+    g = to_gray(im.astype(np.float64), ctx=ctx)
+    assert g.dtype == np.float64 and list(g[0, 0]) == [255.0, 29.0, 150.0, 76.0]
