@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
+    ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
+                    help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default), or all-gatherv "
+                         "compacted 16-byte XYZ+key records")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
     ap.add_argument("--buffers", type=int, default=2, help="distinct input stacks rotated between steps")
     args = ap.parse_args()
@@ -198,6 +201,9 @@ def main():
             except OSError:
                 pass
 
+    if use_comm:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints its version banner through C stdio: flush it now so rank 0's JSON stays the last line
     band_px = rows * cam_w
     plane = band_px                         # each rank holds only its row band of every frame
     stacks = []
@@ -212,7 +218,7 @@ def main():
     if use_comm:
         from scanner import sharded
         sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(cam_h, cam_w, G),
-                                                 (proj_w, proj_h), N, mode=mode)
+                                                 (proj_w, proj_h), N, mode=mode, exchange_kind=args.exchange)
     ctx.synchronize()
 
     def step(i, counted=False, mode=mode):
@@ -259,8 +265,14 @@ def main():
         step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
         ctx.synchronize()
         valid = int(count.download((1,), np.uint64)[0])
-    else:
+    elif args.exchange == "records":
         valid = float(total_pts)
+    else:                                                       # maps exchange: count the reassembled dense cloud once, untimed
+        count.zero()
+        ctx.triangulate_maps_dev(sharded_scanner.h_full.ptr, sharded_scanner.v_full.ptr, cam_h, cam_w, 0, (proj_w, proj_h),
+                                 sharded_scanner.xyz_full.ptr, count.ptr, mode=mode & 3)
+        ctx.synchronize()
+        valid = int(count.download((1,), np.uint64)[0])
     if rank == 0:
         mpix_per_step = cam_w * cam_h / 1e6
         ms_per_step = elapsed / args.steps * 1e3
@@ -281,10 +293,13 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
                                    + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
+                       **({} if not use_comm else {"exchange": ("int16 map bands all-gathered, every rank triangulates the full maps"
+                                                                if args.exchange == "maps" else
+                                                                "compacted 16-byte XYZ+key records all-gathered")}),
                        "pipeline": args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)"),
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks),
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
-                                  + ("" if not use_comm else "; compacted XYZ+key all-gathered to every rank")},
+                                  + ("" if not use_comm else "; whole cloud reassembled on every rank")},
             "roofline": kernel_roofline(args.pipeline, dec_ms, dec_n),
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
@@ -318,6 +333,9 @@ def main():
                                       "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "scaling": "weak"}
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, 2048, 1024, calib, (proj_w, proj_h))
+        if use_comm:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if G > 1:
         ctx.comm_barrier()

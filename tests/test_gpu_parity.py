@@ -404,8 +404,15 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
     hp, vp, ref = oc.scan_dense(st, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
     ctx.comm_init(0, 1, _native.Context.comm_unique_id())
     try:
-        sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT)
         stack = ctx.alloc(st.nbytes).upload(st)
+        scm = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT)
+        assert scm.scan(stack.ptr, H * W) is None                                           # default: map-band exchange
+        gh, gv, gx = scm.fetch_dense()
+        okm = (hp != -1) & (vp != -1)
+        assert np.array_equal(gh, hp) and np.array_equal(gv, vp) and np.array_equal(np.isfinite(gx[..., 0]), okm)
+        np.testing.assert_allclose(gx[okm], np.moveaxis(ref, 0, -1)[okm], rtol=XYZ_RTOL, atol=0)
+        sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT,
+                                    exchange_kind="records")
         total = sc.scan(stack.ptr, H * W)
         rec = sc.fetch(total)
         ok = (hp != -1) & (vp != -1)

@@ -96,6 +96,17 @@ def _worker(rank, world, port, H, W, N, q):
         cam, P = sharded.to_reference_lists(all_rec[:total], W, H)
         rcam, _, _ = oc.cam_proj_pts(fh, fv, (W, H), psize, None, order="x")
         assert np.array_equal(cam, rcam) and P.shape == (3, total) and P.dtype == np.float64
+        # ---- default strategy: in-place all-gatherv of the int16 map bands, then every rank triangulates the full maps
+        h_full = np.full((H, W), -7, np.int16)
+        v_full = np.full((H, W), -7, np.int16)
+        if rows:
+            h_full[row0:row0 + rows] = hp
+            v_full[row0:row0 + rows] = vp
+        mc, md = sharded.map_band_layout(plan)
+        assert sum(mc) == H * W * 2 and md[rank] == row0 * W * 2
+        sharded.exchange_map_bands(ex, plan, h_full, v_full, lambda buf, o: buf.reshape(-1).view(np.uint8)[o:])
+        ex.barrier()
+        assert np.array_equal(h_full, fh) and np.array_equal(v_full, fv)                  # bit-exact maps on every rank
         dist.destroy_process_group()
         q.put((rank, "ok", counts))
     except Exception as e:  # noqa: BLE001
