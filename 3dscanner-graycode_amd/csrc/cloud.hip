@@ -1,0 +1,204 @@
+// cloud.hip -- point-cloud post-processing after the path:
+// the arithmetic of Open3D's remove_statistical_outlier(nb_neighbors, std_ratio) as called at
+// scanner/utils/visualize.py:104 -- for every point the mean distance to its nb_neighbors nearest points (the point itself
+// included, as Open3D's KD-tree query returns it).  Open3D is third-party and not installed in the build container:
+// parity with Open3D is UNPINNED; the kernel is exact k-NN and is checked against scipy's cKDTree.
+//
+// K7  uniform-grid exact k-NN: points are binned into cubic cells of edge s (counting sort: atomics + hipcub scan), every
+//     query scans the 3x3x3 block around its cell keeping the K smallest squared distances in registers (static insertion
+//     network, no dynamic register indexing).  A result is exact when its k-th distance <= s (nothing outside the block can
+//     be closer); the others are retried with the cell edge doubled until all are exact.
+#include <hipcub/hipcub.hpp>
+
+#include "slgc_internal.h"
+
+namespace {
+
+struct Grid {
+    float ox, oy, oz, inv_s;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_s, int n)
+{
+    const int c = (int)((v - o) * inv_s);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__global__ void __launch_bounds__(256) k_cell_count(const float *__restrict__ pts, size_t M, Grid g, unsigned *__restrict__ counts,
+                                                    unsigned *__restrict__ cell_of)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int cx = cell_coord(pts[3 * i], g.ox, g.inv_s, g.nx), cy = cell_coord(pts[3 * i + 1], g.oy, g.inv_s, g.ny),
+              cz = cell_coord(pts[3 * i + 2], g.oz, g.inv_s, g.nz);
+    const unsigned c = ((unsigned)cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+    atomicAdd(counts + c, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_cell_fill(const float *__restrict__ pts, size_t M, const unsigned *__restrict__ cell_of,
+                                                   const unsigned *__restrict__ cell_start, unsigned *__restrict__ cursor,
+                                                   float4 *__restrict__ sorted)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const unsigned c = cell_of[i];
+    const unsigned slot = cell_start[c] + atomicAdd(cursor + c, 1u);
+    sorted[slot] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+}
+
+// queries: indices of the points still to be resolved (nullptr = all points 0..nq-1)
+template <int K>
+__global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts, const unsigned *__restrict__ queries, size_t nq, Grid g,
+                                                  float s, const unsigned *__restrict__ cell_start, const unsigned *__restrict__ cell_end,
+                                                  const float4 *__restrict__ sorted, int k, double *__restrict__ mean_dist,
+                                                  unsigned *__restrict__ unresolved, unsigned *__restrict__ n_unresolved)
+{
+    const size_t t = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (t >= nq) return;
+    const unsigned i = queries ? queries[t] : (unsigned)t;
+    const double qx = pts[3 * (size_t)i], qy = pts[3 * (size_t)i + 1], qz = pts[3 * (size_t)i + 2];
+    const int cx = cell_coord((float)qx, g.ox, g.inv_s, g.nx), cy = cell_coord((float)qy, g.oy, g.inv_s, g.ny),
+              cz = cell_coord((float)qz, g.oz, g.inv_s, g.nz);
+    double best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = 1e300;
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.ny) continue;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+            const unsigned b = cell_start[row + x0], e = cell_end[row + x1];     // the x-run of cells is contiguous in the sorted array
+            for (unsigned p = b; p < e; ++p) {
+                const float4 c = sorted[p];
+                const double ddx = (double)c.x - qx, ddy = (double)c.y - qy, ddz = (double)c.z - qz;
+                double d = ddx * ddx + ddy * ddy + ddz * ddz;
+                if (d < best[K - 1]) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {          // static insertion network: best[] stays sorted ascending
+                        const double lo = d < best[j] ? d : best[j], hi = d < best[j] ? best[j] : d;
+                        best[j] = lo;
+                        d = hi;
+                    }
+                }
+            }
+        }
+    }
+    // exact iff the k-th neighbour lies within s of the query (the 3x3x3 block contains the ball of radius s)
+    double kth = 0.0, sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (j < k) {
+            sum += sqrt(best[j]);
+            kth = best[j];
+        }
+    if (kth <= (double)s * (double)s) {
+        mean_dist[i] = sum / (double)k;
+    } else {
+        unresolved[atomicAdd(n_unresolved, 1u)] = i;
+    }
+}
+
+template <int K>
+void launch_knn(slgc_ctx *ctx, const float *d_pts, const unsigned *d_q, size_t nq, const Grid &g, float s, const unsigned *cs, const unsigned *ce,
+                const float4 *sorted, int k, double *d_mean, unsigned *d_unres, unsigned *d_nun)
+{
+    hipLaunchKernelGGL((k_knn_mean<K>), dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, ctx->stream, d_pts, d_q, nq, g, s, cs, ce, sorted, k, d_mean,
+                       d_unres, d_nun);
+}
+
+}  // namespace
+
+// mean distance of every point to its k nearest points (itself included).  pts: host float32 [M][3]; mean: host float64 [M].
+extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, double *mean)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "hipSetDevice failed");
+    if (M < 0 || k < 1 || k > 64 || (M && (!pts || !mean))) return slgc_fail(ctx, SLGC_EINVAL, "bad arguments (1 <= k <= 64)");
+    if (M == 0) return SLGC_OK;
+    if (M > 0x7fffffffll) return slgc_fail(ctx, SLGC_EINVAL, "too many points");
+    // bounding box on the host (the points come from the host anyway)
+    float lo[3] = {pts[0], pts[1], pts[2]}, hi[3] = {pts[0], pts[1], pts[2]};
+    for (int64_t i = 0; i < M; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[3 * i + c];
+            if (!(v == v) || v > 3e38f || v < -3e38f) return slgc_fail(ctx, SLGC_EINVAL, "non-finite coordinate at point %lld", (long long)i);
+            lo[c] = v < lo[c] ? v : lo[c];
+            hi[c] = v > hi[c] ? v : hi[c];
+        }
+    const double ext[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
+    double e_sorted[3] = {ext[0], ext[1], ext[2]};
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (e_sorted[b] > e_sorted[a]) { const double t = e_sorted[a]; e_sorted[a] = e_sorted[b]; e_sorted[b] = t; }
+    // scanner clouds are surfaces: estimate the 2-D density from the two largest extents; radius holding ~k points, x1.5
+    const double area = (e_sorted[0] > 0 ? e_sorted[0] : 1e-6) * (e_sorted[1] > 0 ? e_sorted[1] : 1e-6);
+    double s = 1.5 * sqrt((double)k / (3.141592653589793 * ((double)M / area)));
+    if (!(s > 0)) s = 1e-6;
+
+    void *d_pts, *d_mean, *d_sorted, *d_cellof, *d_unres[2], *d_nun;
+    int rc;
+    if ((rc = slgc_ws(ctx, 0, (size_t)M * 12, &d_pts))) return rc;
+    if ((rc = slgc_ws(ctx, 1, (size_t)M * 8, &d_mean))) return rc;
+    if ((rc = slgc_ws(ctx, 2, (size_t)M * 16, &d_sorted))) return rc;
+    if ((rc = slgc_ws(ctx, 3, (size_t)M * 4, &d_cellof))) return rc;
+    if ((rc = slgc_ws(ctx, 8, (size_t)M * 4, &d_unres[0]))) return rc;
+    if ((rc = slgc_ws(ctx, 9, (size_t)M * 4, &d_unres[1]))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_nun))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts, (size_t)M * 12, hipMemcpyHostToDevice, ctx->stream));
+
+    size_t nq = (size_t)M;
+    const unsigned *d_q = nullptr;
+    int cur = 0;
+    for (int round = 0; round < 40 && nq; ++round, s *= 2.0) {
+        Grid g;
+        g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+        // keep the grid below 2^25 cells; growing s only makes the search more conservative
+        for (;;) {
+            const double nx = floor(ext[0] / s) + 1, ny = floor(ext[1] / s) + 1, nz = floor(ext[2] / s) + 1;
+            if (nx * ny * nz <= 33554432.0) { g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; break; }
+            s *= 1.26;
+        }
+        g.inv_s = (float)(1.0 / s);
+        const size_t ncell = (size_t)g.nx * g.ny * g.nz;
+        void *d_counts, *d_start, *d_tmp;
+        if ((rc = slgc_ws(ctx, 4, (ncell + 1) * 4, &d_counts))) return rc;
+        if ((rc = slgc_ws(ctx, 5, (ncell + 1) * 4, &d_start))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, g,
+                           (unsigned *)d_counts, (unsigned *)d_cellof);
+        size_t tmp_bytes = 0;
+        HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (unsigned *)d_counts, (unsigned *)d_start, (int)(ncell + 1), ctx->stream));
+        if ((rc = slgc_ws(ctx, 6, tmp_bytes + 16, &d_tmp))) return rc;
+        HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (unsigned *)d_counts, (unsigned *)d_start, (int)(ncell + 1), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));          // reused as the fill cursor
+        hipLaunchKernelGGL(k_cell_fill, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M,
+                           (const unsigned *)d_cellof, (const unsigned *)d_start, (unsigned *)d_counts, (float4 *)d_sorted);
+        HIP_TRY(ctx, hipMemsetAsync(d_nun, 0, 4, ctx->stream));
+        const unsigned *cs = (const unsigned *)d_start, *ce = cs + 1;                     // cell_end[c] = cell_start[c + 1]
+        unsigned *d_out = (unsigned *)d_unres[cur];
+        const float s_safe = (float)(0.999 / (double)g.inv_s);      // the radius the 3x3x3 block is guaranteed to cover, float rounding included
+        if (k <= 20) launch_knn<20>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
+        else if (k <= 32) launch_knn<32>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
+        else launch_knn<64>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
+        HIP_TRY(ctx, hipGetLastError());
+        unsigned nun = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&nun, d_nun, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((int64_t)k > M && g.nx == 1 && g.ny == 1 && g.nz == 1)
+            return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
+        nq = nun;
+        d_q = d_out;
+        cur ^= 1;
+        if (g.nx == 1 && g.ny == 1 && g.nz == 1 && nq) return slgc_fail(ctx, SLGC_EINVAL, "k-NN did not converge (k > number of points?)");
+    }
+    if (nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN left %zu points unresolved", nq);
+    HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pend_M = ctx->filt_M = ctx->pipe_M = -1;   // workspace slots were reused
+    return SLGC_OK;
+}

@@ -51,6 +51,7 @@ SIGNATURES = {
     "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slgc_to_gray_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "slgc_frame_diff_counts": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
+    "slgc_knn_mean_distance": (_i, [_vp, _vp, _i64, _i, _vp]),
     "slgc_pipeline_count": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64)]),
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -341,6 +342,12 @@ class Context:
         elems = int(np.prod(fr.shape[1:])) if n else 0
         out = np.zeros(max(n - 1, 0), np.int64)
         self._ck(lib().slgc_frame_diff_counts(self._h, _ptr(fr), U8 if fr.dtype == np.uint8 else F64, n, elems, float(thresh), _ptr(out)))
+        return out
+
+    def knn_mean_distance(self, pts, k=20):
+        p = np.ascontiguousarray(np.asarray(pts, dtype=np.float32).reshape(-1, 3))
+        out = np.empty(len(p), np.float64)
+        self._ck(lib().slgc_knn_mean_distance(self._h, _ptr(p), len(p), int(k), _ptr(out)))
         return out
 
     def pipeline(self, runs, proj_size, img_white=None, threshold=None, eps=1, m=10, order=ORDER_X, mode=TRI_EXACT,

@@ -121,6 +121,11 @@ int slgc_to_gray_dev(slgc_ctx *ctx, const uint8_t *d_bgr, size_t npix, int coeff
 int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
                            int64_t *counts);
 
+/* Point-cloud post-processing: mean distance of every point to its k nearest points, itself
+ * included -- the arithmetic of Open3D's remove_statistical_outlier as called at scanner/utils/visualize.py:104 (exact k-NN on
+ * a uniform grid; Open3D itself is absent from the build container, parity with it is UNPINNED).  pts float32 [M][3], 1<=k<=64. */
+int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, double *mean);
+
 /* ------------------------------------------------------------------ whole pipeline, one upload */
 
 /* The reference's driver glue in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, max-merge,

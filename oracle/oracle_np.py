@@ -443,3 +443,20 @@ def bgr_to_gray(images, coeff_bits=15):
     im = np.asarray(images).astype(np.int64)
     ry, gy, by = (9798, 19235, 3735) if coeff_bits == 15 else (4899, 9617, 1868)
     return ((im[..., 0] * by + im[..., 1] * gy + im[..., 2] * ry + (1 << (coeff_bits - 1))) >> coeff_bits).astype(np.uint8)
+
+
+def knn_mean_distance(points, k=20):
+    """Mean distance to the k nearest points (self included), exact k-NN through scipy's cKDTree -- the arithmetic of Open3D's
+    remove_statistical_outlier (PARITY with Open3D UNPINNED: not installed).  points float32 [M,3]; float64 distances."""
+    from scipy.spatial import cKDTree
+    p = np.asarray(points, dtype=np.float32).astype(np.float64)
+    d, _ = cKDTree(p).query(p, k=k)
+    return d.reshape(len(p), -1).mean(axis=1)
+
+
+def remove_statistical_outlier(points, nb_neighbors=20, std_ratio=0.5):
+    avg = knn_mean_distance(points, nb_neighbors)
+    valid = avg > 0
+    mean = avg[valid].sum() / valid.sum()
+    std = np.sqrt(((avg[valid] - mean) ** 2).sum() / (valid.sum() - 1))
+    return np.nonzero(valid & (avg < mean + std_ratio * std))[0]

@@ -584,3 +584,34 @@ def test_to_gray_fixed_point_luma(ctx):
     im[0, 0] = [[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255]]
     g = to_gray(im.astype(np.float64), ctx=ctx)
     assert g.dtype == np.float64 and list(g[0, 0]) == [255.0, 29.0, 150.0, 76.0]
+
+
+def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
+    """k-NN mean distances vs scipy's exact cKDTree on a scanner-like surface with outliers, clusters and duplicates."""
+    from scanner.utils import pointcloud as pc
+    rng = np.random.default_rng(51)
+    yy, xx = np.mgrid[0:240, 0:320]
+    surf = np.stack([xx * 1e-3, yy * 1e-3, 0.4 + 0.05 * np.sin(xx / 40.0) * np.cos(yy / 30.0)], -1).reshape(-1, 3)
+    surf = surf[rng.random(len(surf)) < 0.8] + rng.normal(0, 2e-5, (1, 3))
+    out = rng.uniform([-0.1, -0.1, 0.2], [0.45, 0.35, 0.7], (400, 3))                 # sparse outliers
+    clump = rng.normal([0.5, 0.5, 0.5], 1e-6, (300, 3))                               # one dense far-away clump
+    pts = np.concatenate([surf, out, clump, surf[:50]]).astype(np.float32)            # + exact duplicates
+    pts = pts[rng.permutation(len(pts))]
+    for k in (20, 8, 33):
+        got = ctx.knn_mean_distance(pts, k)
+        ref = onp.knn_mean_distance(pts, k)
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
+    inl, ind = pc.remove_statistical_outlier(pts.T, 20, 0.5, ctx=ctx)                 # (3,M) like triangulate() returns
+    rind = onp.remove_statistical_outlier(pts, 20, 0.5)
+    assert np.array_equal(ind, rind) and inl.shape == (len(ind), 3) and inl.dtype == np.float64
+    assert 0.5 * len(pts) < len(ind) < len(pts)
+    col = rng.random((len(pts), 3))
+    p2, c2, i2 = pc.save_point_cloud(pts.T.astype(np.float64), col, str(tmp_path), ctx=ctx)
+    raw = open(tmp_path / "cloud.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert f"element vertex {len(i2)}".encode() in head and b"property double x" in head and b"property uchar blue" in head
+    rec = np.frombuffer(body, dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("r", "u1"), ("g", "u1"), ("b", "u1")]))
+    assert len(rec) == len(i2) and np.array_equal(rec["x"], p2[:, 0]) and np.array_equal(rec["g"], np.round(c2[:, 1] * 255).astype(np.uint8))
+    with pytest.raises(ValueError):
+        ctx.knn_mean_distance(pts[:5], 20)                                           # k > number of points
+    assert ctx.knn_mean_distance(np.zeros((0, 3), np.float32), 20).shape == (0,)
