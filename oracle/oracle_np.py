@@ -66,10 +66,11 @@ def direct_indirect(stack: np.ndarray):
     with np.errstate(invalid="ignore", divide="ignore"):
         b_inv = white / (white + black)                      # :113
     pat = st[2:]
-    l_max = pat[hid].max(axis=0)                             # :116
-    l_min = pat[vid].min(axis=0)                             # :117
-    l_d = (l_max - l_min) * b_inv                            # :119
-    l_g = 2.0 * (l_max - l_d) * b_inv                        # :120 -> (2*(..))*b_inv
+    with np.errstate(invalid="ignore"):                      # inf - inf etc. on float64 stacks: NaN, silently, like the reference
+        l_max = pat[hid].max(axis=0)                         # :116
+        l_min = pat[vid].min(axis=0)                         # :117
+        l_d = (l_max - l_min) * b_inv                        # :119
+        l_g = 2.0 * (l_max - l_d) * b_inv                    # :120 -> (2*(..))*b_inv
     return l_d, l_g
 
 
