@@ -615,3 +615,30 @@ def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
     with pytest.raises(ValueError):
         ctx.knn_mean_distance(pts[:5], 20)                                           # k > number of points
     assert ctx.knn_mean_distance(np.zeros((0, 3), np.float32), 20).shape == (0,)
+
+
+def test_decode_randomised_configurations(ctx):
+    """40 random (N, H, W, runs, eps, dtype) draws through the host API and the device API against the C oracle."""
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        N = int(rng.integers(14, 66))
+        H, W = int(rng.integers(1, 70)), int(rng.integers(1, 150))
+        R = int(rng.integers(1, 4))
+        eps = [1, 1, 1, 0, 2, 7, 0.5, 1.25][int(rng.integers(0, 8))]
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            st = rng.integers(0, 256, (R, N, H, W), dtype=np.uint8)
+        elif kind == 1:
+            st = np.stack([onp.synth_scene(N, H, W, seed=int(rng.integers(1, 1000)), noise=int(rng.integers(0, 12))) for _ in range(R)])
+        else:
+            st = rng.integers(0, 256, (R, N, H, W), dtype=np.uint8)
+            st[:, 0] = rng.integers(0, 3, (R, H, W))
+            st[:, 1] = rng.integers(0, 3, (R, H, W))              # many 0/0 and tie pixels
+        ref = oc.decode(st, eps=eps)
+        as_f64 = bool(rng.integers(0, 2))
+        runs = [s.astype(np.float64) if as_f64 else s for s in st]
+        hp, vp = ctx.decode(runs if R > 1 else runs[0], eps=eps)
+        assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1]), (trial, N, H, W, R, eps, kind, as_f64)
+        if float(eps).is_integer() and eps >= 0:
+            h, v = dev_decode(ctx, st, 0, eps=eps)
+            assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1]), (trial, N, H, W, R, eps, kind)
