@@ -87,6 +87,39 @@ def exchange_records(exchange, send_records, count: int, recv_records):
     return counts, sum(counts)
 
 
+def share_unique_id(rank: int, make_uid, key: str = None, timeout_s: float = 300.0, directory: str = "/tmp"):
+    """Hand rank 0's RCCL unique id (128 bytes) to the other ranks of one node through a file.
+
+    ``torch.distributed.run`` starts the ranks as children of one agent process and exports MASTER_PORT, so
+    ``MASTER_PORT + parent pid`` names a rendezvous that is unique per launch (no torch import needed in the workers).
+    Rank 0 writes ``<file>.tmp`` and renames it (atomic), the others poll.  Returns (uid, path); rank 0 should remove the file
+    once every rank has passed its first collective."""
+    import os
+    import time
+    if key is None:
+        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    path = os.path.join(directory, f"slgc_uid_{key}")
+    if rank == 0:
+        uid = make_uid()
+        if len(uid) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+        return uid, path
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.02)
+    raise RuntimeError(f"timed out waiting for the RCCL unique id from rank 0 ({path})")
+
+
 class RcclExchange:
     """RCCL over xGMI through libslgc.so (one context = one rank = one GPU)."""
 

@@ -59,25 +59,8 @@ def calibration(cam_w, cam_h, proj_w, proj_h):
 
 def rendezvous_uid(rank, world):
     """Share the RCCL unique id between the ranks torch.distributed.run started (same parent pid)."""
-    from scanner import _native
-    path = f"/tmp/slgc_uid_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-    if rank == 0:
-        uid = _native.Context.comm_unique_id()
-        with open(path + ".tmp", "wb") as f:
-            f.write(uid)
-        os.replace(path + ".tmp", path)
-        return uid, path
-    t0 = time.time()
-    while time.time() - t0 < 300:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == _native.UNIQUE_ID_BYTES:
-                return uid, path
-        except FileNotFoundError:
-            pass
-        time.sleep(0.05)
-    raise RuntimeError("timed out waiting for the RCCL unique id from rank 0")
+    from scanner import _native, sharded
+    return sharded.share_unique_id(rank, _native.Context.comm_unique_id)
 
 
 def cpu_baseline(N, crop_w, crop_h, calib, proj_size):

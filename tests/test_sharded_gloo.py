@@ -147,3 +147,37 @@ def test_shard_plan_and_layout():
     keys = np.array([0 * 4 + 1, 0 * 4 + 3, 1 * 4 + 0, 2 * 4 + 1], dtype=np.uint32)      # W=4: (x,y) = (1,0),(3,0),(0,1),(1,2)
     perm = sharded.x_major_permutation(keys, 4, 3)
     assert list(perm) == [2, 0, 3, 1]                                                     # x=0 | x=1 (y=0,2) | x=3
+
+
+def _uid_worker(rank, key, tmpdir, q):
+    try:
+        sys.path.insert(0, PKG)
+        from scanner import sharded
+        uid, path = sharded.share_unique_id(rank, lambda: bytes(range(128)), key=key, timeout_s=30, directory=tmpdir)
+        q.put((rank, uid == bytes(range(128)), path))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, False, repr(e)))
+
+
+def test_unique_id_rendezvous_file(tmp_path):
+    """The torch-free rendezvous bench.py uses under torch.distributed.run: rank 0 publishes atomically, late and early ranks poll."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uid_worker, args=(r, "testkey", str(tmp_path), q)) for r in (2, 1)]     # non-zero ranks first
+    for p in procs:
+        p.start()
+    time.sleep(0.5)
+    p0 = ctx.Process(target=_uid_worker, args=(0, "testkey", str(tmp_path), q))
+    p0.start()
+    res = [q.get(timeout=60) for _ in range(3)]
+    for p in procs + [p0]:
+        p.join(timeout=30)
+    assert all(ok for _, ok, _ in res), res
+    assert len({path for _, _, path in res}) == 1
+    from scanner import sharded
+    with pytest.raises(RuntimeError, match="timed out"):
+        sharded.share_unique_id(1, None, key="nobody", timeout_s=0.2, directory=str(tmp_path))
+    with pytest.raises(ValueError):
+        sharded.share_unique_id(0, lambda: b"short", key="bad", directory=str(tmp_path))
