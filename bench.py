@@ -37,6 +37,8 @@ WORKLOADS = {
     "c3_4096x3000x44": (4096, 3000, 1920, 1200, 44),
     "c2_1920x1080x44": (1920, 1080, 1920, 1080, 44),
     "c3_4096x3000x46": (4096, 3000, 1920, 1200, 46),
+    "c1_1280x720x42": (1280, 720, 1280, 800, 42),
+    "c2_1920x1080x46": (1920, 1080, 1920, 1080, 46),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -89,41 +91,50 @@ def cpu_baseline(N, crop_w, crop_h, calib, proj_size):
             "c_oracle_value": round(mpix / dt_c, 3), "c_oracle_note": "plain-C scalar oracle, 1 thread, same crop"}
 
 
-def throughput_mode(ctx, _native, G, steps, mode):
+def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
     """BASELINE.json configs[4]: 16 independent 1920x1080x44 scans per step, spread over the G GPUs, no collective
-    (replicas only -- SURVEY.md 8(e)).  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
+    (replicas only -- SURVEY.md 8(e)).  Each GPU streams its scans back to back over `n_streams` contexts (HIP streams) so the
+    tail of one scan's kernel overlaps the head of the next.  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
     cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
     per_rank = max(1, 16 // G)
-    ctx.set_calibration(*calibration(cw, ch, pw, ph))
     px = cw * ch
-    stacks = []
-    for b in range(max(per_rank, 4)):                       # >= 4 distinct stacks (364 MB) so the Infinity Cache cannot serve repeats
-        s = ctx.alloc(n * px)
-        ctx.synth_scene_dev(s.ptr, px, n, ch, cw, seed=11 + b)
-        stacks.append(s)
-    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    lanes = []
+    for sidx in range(max(1, n_streams)):
+        c = _native.Context(device)
+        c.set_calibration(*calibration(cw, ch, pw, ph))
+        stacks = []
+        for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):   # >= 4 distinct stacks in total (364 MB > Infinity Cache)
+            st = c.alloc(n * px)
+            c.synth_scene_dev(st.ptr, px, n, ch, cw, seed=11 + 7 * sidx + b)
+            stacks.append(st)
+        lanes.append((c, stacks, c.alloc(px * 4), c.alloc(px * 12)))
 
     def one_step(i):
         for j in range(per_rank):
-            s = stacks[(i * per_rank + j) % len(stacks)]
-            ctx.scan_dev(s.ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+            c, stacks, maps, xyz = lanes[j % len(lanes)]
+            st = stacks[(i * per_rank + j) // len(lanes) % len(stacks)]
+            c.scan_dev(st.ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+
+    def sync_all():
+        for c, _, _, _ in lanes:
+            c.synchronize()
 
     for i in range(3):
         one_step(i)
-    ctx.synchronize()
+    sync_all()
     if G > 1:
         ctx.comm_barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         one_step(i)
-    ctx.synchronize()
+    sync_all()
     if G > 1:
         ctx.comm_barrier()
     el = time.perf_counter() - t0
     if G > 1:
         el = ctx.comm_allreduce_max(el)
-    for b in stacks + [maps, xyz]:
-        b.free()
+    for c, _, _, _ in lanes:
+        c.close()
     return el, per_rank * G, px / 1e6
 
 
@@ -140,12 +151,14 @@ def main():
     ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams (contexts) per GPU in the throughput-mode measurement")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
     ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default), or all-gatherv "
                          "compacted 16-byte XYZ+key records")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
-    ap.add_argument("--buffers", type=int, default=2, help="distinct input stacks rotated between steps")
+    ap.add_argument("--buffers", type=int, default=0,
+                    help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,6 +203,8 @@ def main():
     band_px = rows * cam_w
     plane = band_px                         # each rank holds only its row band of every frame
     stacks = []
+    if args.buffers <= 0:                                   # enough distinct stacks to exceed the 256 MB Infinity Cache
+        args.buffers = max(2, -(-300_000_000 // (N * plane)))
     for b in range(max(1, args.buffers)):
         s = ctx.alloc(N * plane)
         ctx.synth_scene_dev(s.ptr, plane, N, cam_h, cam_w, row0=row0, rows=rows, seed=1 + b, noise=3, shadow=True)
@@ -241,8 +256,7 @@ def main():
 
     thr = None
     if not args.no_throughput_mode and args.mode == "algebraic" and args.tri == "lut":
-        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused)
-        ctx.set_calibration(*calib)
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, local_rank, args.streams)
     if not use_comm:
         count.zero()
         step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
@@ -313,7 +327,8 @@ def main():
             out["throughput_mode"] = {"value": round(t_scans * t_mpix * t_steps / t_el, 1), "unit": "Mpixels/s",
                                       "config": f"{t_scans} independent 1920x1080x44 scans per step ({t_scans // G} per GPU), no collective "
                                                 "(BASELINE.json configs[4], replicas only)",
-                                      "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "scaling": "weak"}
+                                      "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "streams_per_gpu": args.streams,
+                                      "scaling": "weak"}
         if G == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, 2048, 1024, calib, (proj_w, proj_h))
         if use_comm:
