@@ -293,11 +293,13 @@ def main():
                        **({} if not use_comm else {"exchange": ("int16 map bands all-gathered, every rank triangulates the full maps"
                                                                 if args.exchange == "maps" else
                                                                 "compacted 16-byte XYZ+key records all-gathered")}),
-                       "pipeline": args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)"),
+                       "pipeline": ("decode kernel per band + full-image triangulation kernel per rank" if (use_comm and args.exchange == "maps")
+                                    else args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)")),
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks),
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
                                   + ("" if not use_comm else "; whole cloud reassembled on every rank")},
-            "roofline": kernel_roofline(args.pipeline, dec_ms, dec_n),
+            # the kernel bracketed by the event pairs: the fused scan kernel, or (split / sharded "maps" strategy) the decode kernel
+            "roofline": kernel_roofline("split" if (use_comm and args.exchange == "maps") else args.pipeline, dec_ms, dec_n),
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
         }
