@@ -212,6 +212,33 @@ def main():
         print("remove_bad_images", name, len(seq), "->", len(ing[f"{name}/kept"]))
     np.savez_compressed(os.path.join(HERE, "ingest.npz"), **ing)
 
+    # ------------------------------------------------------------------ config 1 at full size: 1280x720 camera, 1280x800 projector, 42 frames
+    # (BASELINE.json configs[0]; the repo's own capture is not in the repo -- SURVEY.md D4 -- so the scene is synthetic, the
+    # intrinsics are the repo's).  The reference itself decodes and triangulates it; only outputs are stored (the input is
+    # regenerated from its seed and guarded by a SHA-256).
+    import hashlib
+    N1, H1, W1 = 42, 720, 1280
+    stack1, _, _ = onp.synth_scene_int(N1, H1, W1, seed=5, noise=3, shadow=True)
+    hc, vc = ref_dc.get_codes(stack1.astype(np.float64))
+    hp1, vp1 = ref_pixels(hc, vc)
+    white1 = np.repeat(stack1[1][:, :, None], 3, axis=2)
+    th = np.deg2rad(-20.0)
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    T = np.array([[0.25], [0.02], [0.04]])
+    pm1 = cal["proj_mtx"].copy()
+    t1 = RefTriangulate(hp1, vp1, (W1, H1), cal["cam_mtx"], cal["cam_dist"], (1280, 800), (1920, 1080), pm1, cal["proj_dist"], R, T, None)
+    cam1, proj1, col1 = t1.get_cam_proj_pts(white1)
+    pts1 = t1.triangulate(cam1, proj1)
+    fp1, fc1 = t1.filter_3d_pts(pts1, col1, threshold=0.5)
+    sel = np.arange(0, pts1.shape[1], 97)
+    np.savez_compressed(os.path.join(HERE, "config1.npz"), params=np.array([N1, H1, W1, 5, 3]),
+                        stack_sha256=np.frombuffer(hashlib.sha256(stack1.tobytes()).digest(), dtype=np.uint8),
+                        h_pixels=hp1.astype(np.int16), v_pixels=vp1.astype(np.int16), M=np.array([cam1.shape[0], fp1.shape[1]]),
+                        cam_sha256=np.frombuffer(hashlib.sha256(cam1.tobytes()).digest(), dtype=np.uint8),
+                        proj_sha256=np.frombuffer(hashlib.sha256(proj1.tobytes()).digest(), dtype=np.uint8),
+                        sample_index=sel, pts_sample=pts1[:, sel], colors_sample=col1[sel], R=R, T=T)
+    print("config1: M =", cam1.shape[0], "kept", fp1.shape[1])
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

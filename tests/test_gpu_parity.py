@@ -642,3 +642,28 @@ def test_decode_randomised_configurations(ctx):
         if float(eps).is_integer() and eps >= 0:
             h, v = dev_decode(ctx, st, 0, eps=eps)
             assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1]), (trial, N, H, W, R, eps, kind)
+
+
+def test_config1_full_size_against_the_reference(calib):
+    """BASELINE.json configs[0] at full size through the one-call pipeline, against outputs of the reference itself."""
+    import hashlib
+    from scanner import scan_to_cloud
+    z = np.load(os.path.join(GOLDEN, "config1.npz"))
+    N, H, W, seed, noise = (int(x) for x in z["params"])
+    stack, _, _ = onp.synth_scene_int(N, H, W, seed=seed, noise=noise, shadow=True)
+    assert hashlib.sha256(stack.tobytes()).digest() == z["stack_sha256"].tobytes()
+    white = np.repeat(stack[1][:, :, None], 3, axis=2)
+    for st in (stack, stack.astype(np.float64)):
+        out = scan_to_cloud(st, calib["cam_mtx"], calib["cam_dist"], (1280, 800), (1920, 1080), calib["proj_mtx"], calib["proj_dist"],
+                            z["R"], z["T"], img_white=white, return_lists=True)
+        assert np.array_equal(out["h_pixels"], z["h_pixels"]) and np.array_equal(out["v_pixels"], z["v_pixels"])
+        assert out["pts"].shape == (3, int(z["M"][0]))
+        assert hashlib.sha256(out["cam_pts"].tobytes()).digest() == z["cam_sha256"].tobytes()
+        assert hashlib.sha256(out["proj_pts"].tobytes()).digest() == z["proj_sha256"].tobytes()
+        sel = z["sample_index"]
+        np.testing.assert_allclose(out["pts"][:, sel], z["pts_sample"], rtol=XYZ_RTOL, atol=0)
+        np.testing.assert_allclose(out["pts"][:, sel], z["pts_sample"], rtol=1e-9, atol=1e-12)
+        assert np.array_equal(out["colors"][sel], z["colors_sample"])
+    kept = scan_to_cloud(stack, calib["cam_mtx"], calib["cam_dist"], (1280, 800), (1920, 1080), calib["proj_mtx"], calib["proj_dist"],
+                         z["R"], z["T"], threshold=0.5)
+    assert kept["pts"].shape[1] == int(z["M"][1])
