@@ -60,6 +60,17 @@ int need_comm(slgc_ctx *ctx)
     return SLGC_OK;
 }
 
+// All collectives run on ctx->comm_stream.  Before one is enqueued the communication stream is made to wait for everything
+// the caller has enqueued on the compute stream so far (its inputs), so collectives stay ordered after the kernels that
+// produce their data while later kernels on the compute stream are free to overlap with them.
+int comm_after_compute(slgc_ctx *ctx)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_compute, 0));
+    return SLGC_OK;
+}
+
 }  // namespace
 
 extern "C" int slgc_comm_unique_id(void *id128)
@@ -87,6 +98,9 @@ extern "C" int slgc_comm_init(slgc_ctx *ctx, int rank, int nranks, const void *i
     ctx->rank = rank;
     ctx->nranks = nranks;
     HIP_TRY(ctx, hipMalloc(&ctx->comm_scratch, 8 * (size_t)(nranks + 1)));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done[i], hipEventDisableTiming));
     return SLGC_OK;
 }
 
@@ -95,8 +109,15 @@ extern "C" int slgc_comm_destroy(slgc_ctx *ctx)
     if (!ctx) return SLGC_EINVAL;
     if (ctx->comm) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
         rccl().CommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
+    }
+    if (ctx->comm_stream) {
+        (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_stream = nullptr;
+        (void)hipEventDestroy(ctx->ev_compute);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_comm_done[i]);
     }
     if (ctx->comm_scratch) {
         (void)hipFree(ctx->comm_scratch);
@@ -111,10 +132,11 @@ extern "C" int slgc_comm_allreduce_max_f64(slgc_ctx *ctx, double *value)
     int rc = need_comm(ctx);
     if (rc) return rc;
     if (!value) return slgc_fail(ctx, SLGC_EINVAL, "null value");
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_scratch, value, 8, hipMemcpyHostToDevice, ctx->stream));
-    NCCL_TRY(ctx, rccl().AllReduce(ctx->comm_scratch, ctx->comm_scratch, 1, ncclFloat64, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(value, ctx->comm_scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = comm_after_compute(ctx))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->comm_scratch, value, 8, hipMemcpyHostToDevice, ctx->comm_stream));
+    NCCL_TRY(ctx, rccl().AllReduce(ctx->comm_scratch, ctx->comm_scratch, 1, ncclFloat64, ncclMax, (ncclComm_t)ctx->comm, ctx->comm_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(value, ctx->comm_scratch, 8, hipMemcpyDeviceToHost, ctx->comm_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     return SLGC_OK;
 }
 
@@ -130,31 +152,51 @@ extern "C" int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all
     if (rc) return rc;
     if (!all) return slgc_fail(ctx, SLGC_EINVAL, "null output");
     int64_t *scratch = (int64_t *)ctx->comm_scratch;  // [0] = mine, [1..nranks] = gathered
-    HIP_TRY(ctx, hipMemcpyAsync(scratch, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
-    NCCL_TRY(ctx, rccl().AllGather(scratch, scratch + 1, 1, ncclInt64, (ncclComm_t)ctx->comm, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(all, scratch + 1, 8 * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = comm_after_compute(ctx))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(scratch, &mine, 8, hipMemcpyHostToDevice, ctx->comm_stream));
+    NCCL_TRY(ctx, rccl().AllGather(scratch, scratch + 1, 1, ncclInt64, (ncclComm_t)ctx->comm, ctx->comm_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(all, scratch + 1, 8 * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->comm_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     return SLGC_OK;
 }
 
-extern "C" int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs)
+extern "C" int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot)
 {
     int rc = need_comm(ctx);
     if (rc) return rc;
-    if (!d_recv || !counts || !displs) return slgc_fail(ctx, SLGC_EINVAL, "null argument");
+    if (!d_recv || !counts || !displs || slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "null argument / slot outside 0..3");
     for (int r = 0; r < ctx->nranks; ++r)
         if (counts[r] < 0 || displs[r] < 0) return slgc_fail(ctx, SLGC_EINVAL, "negative count/displacement");
+    if ((rc = comm_after_compute(ctx))) return rc;
     NCCL_TRY(ctx, rccl().GroupStart());
     for (int r = 0; r < ctx->nranks; ++r) {
         if (counts[r] == 0) continue;  // same decision on every rank (counts are global)
         char *dst = (char *)d_recv + displs[r];
         const void *src = (r == ctx->rank) ? d_send : dst;
-        ncclResult_t e = rccl().Broadcast(src, dst, (size_t)counts[r], ncclUint8, r, (ncclComm_t)ctx->comm, ctx->stream);
+        ncclResult_t e = rccl().Broadcast(src, dst, (size_t)counts[r], ncclUint8, r, (ncclComm_t)ctx->comm, ctx->comm_stream);
         if (e != ncclSuccess) {
             rccl().GroupEnd();
             return slgc_fail(ctx, SLGC_ECOMM, "ncclBroadcast(root %d): %s", r, rccl().GetErrorString(e));
         }
     }
     NCCL_TRY(ctx, rccl().GroupEnd());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done[slot], ctx->comm_stream));
     return SLGC_OK;
+}
+
+extern "C" int slgc_comm_wait(slgc_ctx *ctx, int slot)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "slot outside 0..3");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_done[slot], 0));   // later compute-stream work sees the gathered data
+    return SLGC_OK;
+}
+
+extern "C" int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs)
+{
+    int rc = slgc_comm_allgatherv_begin(ctx, d_send, d_recv, counts, displs, 3);
+    if (rc) return rc;
+    return slgc_comm_wait(ctx, 3);
 }

@@ -73,6 +73,9 @@ struct slgc_ctx {
     void *comm;
     int rank, nranks;
     void *comm_scratch;  // device scratch for small collectives
+    hipStream_t comm_stream;          // every collective runs here, ordered against ctx->stream with events
+    hipEvent_t ev_compute;            // "compute stream reached this point" (recorded before a collective is enqueued)
+    hipEvent_t ev_comm_done[4];       // completion of the collective started in slot s (slgc_comm_allgatherv_begin / _wait)
 };
 
 int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...);

@@ -76,6 +76,8 @@ SIGNATURES = {
     "slgc_comm_allreduce_max_f64": (_i, [_vp, C.POINTER(_d)]),
     "slgc_comm_allgather_i64": (_i, [_vp, _i64, C.POINTER(_i64)]),
     "slgc_comm_allgatherv": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "slgc_comm_allgatherv_begin": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
+    "slgc_comm_wait": (_i, [_vp, _i]),
 }
 
 _lib = None
@@ -453,6 +455,15 @@ class Context:
         c = (C.c_int64 * n)(*[int(x) for x in counts])
         d = (C.c_int64 * n)(*[int(x) for x in displs])
         self._ck(lib().slgc_comm_allgatherv(self._h, d_send, d_recv, c, d))
+
+    def comm_allgatherv_begin(self, d_send: int, d_recv: int, counts, displs, slot: int):
+        n = self.nranks
+        c = (C.c_int64 * n)(*[int(x) for x in counts])
+        d = (C.c_int64 * n)(*[int(x) for x in displs])
+        self._ck(lib().slgc_comm_allgatherv_begin(self._h, d_send, d_recv, c, d, int(slot)))
+
+    def comm_wait(self, slot: int):
+        self._ck(lib().slgc_comm_wait(self._h, int(slot)))
 
 
 _default_ctx = None

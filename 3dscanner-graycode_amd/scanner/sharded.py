@@ -130,9 +130,20 @@ class RcclExchange:
     def allgather_i64(self, value: int):
         return self.ctx.comm_allgather_i64(value)
 
+    @staticmethod
+    def _ptr(b):
+        return b.ptr if hasattr(b, "ptr") else int(b)                   # DeviceBuffer or raw device pointer
+
     def allgatherv(self, d_send, d_recv, byte_counts, byte_displs):
-        ptr = lambda b: b.ptr if hasattr(b, "ptr") else int(b)          # noqa: E731  (DeviceBuffer or raw device pointer)
-        self.ctx.comm_allgatherv(ptr(d_send), ptr(d_recv), byte_counts, byte_displs)
+        self.ctx.comm_allgatherv(self._ptr(d_send), self._ptr(d_recv), byte_counts, byte_displs)
+
+    def allgatherv_begin(self, d_send, d_recv, byte_counts, byte_displs, slot: int):
+        """Enqueue on the communication stream (after the compute stream's work so far) and return; see wait()."""
+        self.ctx.comm_allgatherv_begin(self._ptr(d_send), self._ptr(d_recv), byte_counts, byte_displs, slot)
+
+    def wait(self, slot: int):
+        """Make the compute stream wait for the exchange started in ``slot``."""
+        self.ctx.comm_wait(slot)
 
     def barrier(self):
         self.ctx.comm_barrier()
@@ -155,7 +166,10 @@ def exchange_map_bands(exchange, plan: ShardPlan, h_full, v_full, band_view):
 
 
 class ShardedScanner:
-    """Device-resident sharded scan: owns the per-rank buffers, runs one band per call."""
+    """Device-resident sharded scan: owns the per-rank buffers, runs one band per call.
+
+    With the "maps" strategy consecutive scans can be pipelined (:meth:`submit` / :meth:`flush`): the all-gatherv of scan i runs
+    on the communication stream while the compute stream triangulates scan i-1 and decodes scan i+1 (two sets of map buffers)."""
 
     def __init__(self, ctx, exchange, plan: ShardPlan, proj_size, n_frames: int, mode: int = 1, exchange_kind: str = "maps"):
         if exchange_kind not in ("maps", "records"):
@@ -168,9 +182,11 @@ class ShardedScanner:
         self.count = ctx.alloc(8)
         self.last_counts = None
         if exchange_kind == "maps":
-            self.h_full = ctx.alloc(max(16, full_px * 2))
-            self.v_full = ctx.alloc(max(16, full_px * 2))
+            self._sets = [(ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 2))) for _ in range(2)]
+            self.h_full, self.v_full = self._sets[0]                 # where scan_maps() / the last finished submit() left the maps
             self.xyz_full = ctx.alloc(max(16, full_px * 12))
+            self._submitted = 0
+            self._pending = None
         else:
             self.maps = ctx.alloc(max(16, band_px * 4))
             self.xyz = ctx.alloc(max(16, band_px * 12))
@@ -181,11 +197,46 @@ class ShardedScanner:
         """Band decode -> map all-gatherv -> full-image triangulation on every rank.  Nothing here synchronises with the host.
         Leaves int16 maps (h_full, v_full) and dense float32 XYZ [H][W][3] (NaN = undecodable) on every rank."""
         c, W, H = self.ctx, self.plan.W, self.plan.H
+        self.flush()
+        self.h_full, self.v_full = self._sets[0]
         off = self.row0 * W * 2
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      self.h_full.at(off), self.v_full.at(off), eps=eps)
         exchange_map_bands(self.exchange, self.plan, self.h_full, self.v_full, lambda buf, o: buf.at(o))
         c.triangulate_maps_dev(self.h_full.ptr, self.v_full.ptr, H, W, 0, self.proj_size, self.xyz_full.ptr, None, mode=self.mode & 3)
+
+    def submit(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
+        """Pipelined "maps" scan: decode this scan's band, start its exchange on the communication stream, then finish the
+        PREVIOUS scan (wait for its exchange, triangulate).  Call :meth:`flush` after the last one.  No host synchronisation."""
+        if self.kind != "maps":
+            raise ValueError("submit()/flush() pipeline the 'maps' strategy")
+        c, W = self.ctx, self.plan.W
+        s = self._submitted % 2
+        h_full, v_full = self._sets[s]
+        off = self.row0 * W * 2
+        c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
+                     h_full.at(off), v_full.at(off), eps=eps)
+        counts, displs = map_band_layout(self.plan)
+        self.exchange.allgatherv_begin(h_full.at(displs[self.rank]), h_full, counts, displs, 2 * s)
+        self.exchange.allgatherv_begin(v_full.at(displs[self.rank]), v_full, counts, displs, 2 * s + 1)
+        if self._pending is not None:
+            self._finish(self._pending)
+        self._pending = s
+        self._submitted += 1
+
+    def _finish(self, s: int):
+        h_full, v_full = self._sets[s]
+        self.exchange.wait(2 * s)
+        self.exchange.wait(2 * s + 1)
+        self.ctx.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, self.plan.W, 0, self.proj_size, self.xyz_full.ptr, None,
+                                      mode=self.mode & 3)
+        self.h_full, self.v_full = h_full, v_full
+
+    def flush(self):
+        """Finish the scan still in flight (its maps end up in h_full / v_full, its cloud in xyz_full)."""
+        if self.kind == "maps" and self._pending is not None:
+            self._finish(self._pending)
+            self._pending = None
 
     def scan(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
         """d_band_stack points at this rank's first row of frame 0.  "records": returns the total number of points (all

@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default), or all-gatherv "
                          "compacted 16-byte XYZ+key records")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded 'maps' mode: do not pipeline the exchange with the neighbouring scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
     ap.add_argument("--buffers", type=int, default=0,
                     help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
@@ -221,6 +222,8 @@ def main():
 
     def step(i, counted=False, mode=mode):
         s = stacks[i % len(stacks)]
+        if use_comm and args.exchange == "maps" and not args.no_overlap:
+            return sharded_scanner.submit(s.ptr, plane)      # pipelined: exchange of this scan overlaps the neighbours' kernels
         if use_comm:
             return sharded_scanner.scan(s.ptr, plane)        # band scan + compaction + counts + RCCL all-gatherv
         ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
@@ -230,6 +233,8 @@ def main():
     def timed(K, W_, **kw):
         for i in range(W_):
             step(i, **kw)
+        if sharded_scanner is not None:
+            sharded_scanner.flush()
         ctx.synchronize()
         if G > 1:
             ctx.comm_barrier()
@@ -238,6 +243,8 @@ def main():
         tot = None
         for i in range(K):
             tot = step(i, **kw)
+        if sharded_scanner is not None:
+            sharded_scanner.flush()                          # the K-th scan's exchange + triangulation are inside the timed region
         ctx.synchronize()
         if G > 1:
             ctx.comm_barrier()
@@ -291,6 +298,7 @@ def main():
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
                                    + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
                        **({} if not use_comm else {"exchange": ("int16 map bands all-gathered, every rank triangulates the full maps"
+                                                                + ("" if args.no_overlap else "; exchange of scan i overlaps triangulation of i-1 and decode of i+1")
                                                                 if args.exchange == "maps" else
                                                                 "compacted 16-byte XYZ+key records all-gathered")}),
                        "pipeline": ("decode kernel per band + full-image triangulation kernel per rank" if (use_comm and args.exchange == "maps")

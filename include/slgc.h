@@ -196,6 +196,11 @@ int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all);        /
 /* all-gatherv of byte records: rank r contributes counts[r] bytes from d_send; every rank receives all of them at
  * d_recv + displs[r].  Grouped ncclBroadcast (RCCL has no native all-gatherv). */
 int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs);
+/* Split form for overlap: collectives run on the context's own communication stream, ordered after everything enqueued on
+ * the compute stream at the time of the call.  _begin enqueues the all-gatherv and returns; kernels enqueued afterwards overlap
+ * with it; slgc_comm_wait(slot) makes the compute stream wait for the exchange started in that slot (0..3). */
+int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot);
+int slgc_comm_wait(slgc_ctx *ctx, int slot);
 
 #ifdef __cplusplus
 }

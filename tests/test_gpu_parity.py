@@ -411,6 +411,21 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
         okm = (hp != -1) & (vp != -1)
         assert np.array_equal(gh, hp) and np.array_equal(gv, vp) and np.array_equal(np.isfinite(gx[..., 0]), okm)
         np.testing.assert_allclose(gx[okm], np.moveaxis(ref, 0, -1)[okm], rtol=XYZ_RTOL, atol=0)
+        # pipelined form: three different captures in flight, results must come out in order
+        caps = [onp.synth_scene_int(N, H, W, seed=60 + j, noise=3 + j)[0] for j in range(3)]
+        bufs = [ctx.alloc(cp.nbytes).upload(cp) for cp in caps]
+        outs = []
+        for j, b in enumerate(bufs):
+            scm.submit(b.ptr, H * W)
+            if j:
+                outs.append(scm.fetch_dense())                       # scan j-1 is complete once submit(j) returned its stream work
+        scm.flush()
+        outs.append(scm.fetch_dense())
+        for cp, (gh2, gv2, gx2) in zip(caps, outs):
+            rh2, rv2, rx2 = oc.scan_dense(cp, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+            ok2 = (rh2 != -1) & (rv2 != -1)
+            assert np.array_equal(gh2, rh2) and np.array_equal(gv2, rv2) and np.array_equal(np.isfinite(gx2[..., 0]), ok2)
+            np.testing.assert_allclose(gx2[ok2], np.moveaxis(rx2, 0, -1)[ok2], rtol=XYZ_RTOL, atol=0)
         sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT,
                                     exchange_kind="records")
         total = sc.scan(stack.ptr, H * W)

@@ -45,6 +45,12 @@ class GlooExchange:
             t = self.torch.from_numpy(rb[byte_displs[r]:byte_displs[r] + n])
             self.dist.broadcast(t, src=r)
 
+    def allgatherv_begin(self, send, recv, byte_counts, byte_displs, slot):
+        self.allgatherv(send, recv, byte_counts, byte_displs)          # CPU double: completes immediately
+
+    def wait(self, slot):
+        pass
+
     def barrier(self):
         self.dist.barrier()
 
