@@ -261,6 +261,16 @@ def main():
         om = mode_fused if args.pipeline == "split" else mode_split
         other = timed(args.steps, max(2, args.warmup // 2), mode=om)
 
+    dec_alone = None
+    if G == 1 and not use_comm:
+        # the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way)
+        for i in range(3):
+            ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        ctx.synchronize()
+        ctx.prof_begin(args.steps + 8)
+        for i in range(args.steps):
+            ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        dec_alone = ctx.prof_end()
     thr = None
     if not args.no_throughput_mode and args.mode == "algebraic" and args.tri == "lut":
         thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, local_rank, args.streams)
@@ -331,6 +341,11 @@ def main():
                                          "roofline": kernel_roofline(o_name, o_kms, o_kn),
                                          "note": "same scan, same run, timed right after the main region"}
             add_traffic(out[o_name + "_pipeline"]["roofline"], o_name)
+        if dec_alone is not None:
+            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", dec_alone[0], dec_alone[1]),
+                                          "note": "decode kernel launched back to back on the rotated stacks, same run (the north star's "
+                                                  ">= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
+            add_traffic(out["decode_kernel_alone"]["roofline"], "split")
         if thr is not None:
             t_el, t_scans, t_mpix = thr
             t_steps = max(5, args.steps // 4)
