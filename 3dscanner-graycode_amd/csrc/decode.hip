@@ -16,6 +16,8 @@
 //
 // Compiled with -ffp-contract=off: the reference's fp64 rounding sequence is part of its
 // behaviour (L_max - D*b_inv must not become an FMA).
+#include <cstdlib>
+
 #include "slgc_internal.h"
 #include "tri_math.h"
 
@@ -442,7 +444,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
         if (live) {
-            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + off);
+            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
             const float4 c01 = cl[0], c23 = cl[1];
             cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
             const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const uint32_t i = s_idx1[it * BLOCK + tid];
-            s_ray[it * BLOCK + tid] = (i != 0xffffffffu) ? a.f.proj_lut[i] : make_float2(0.f, 0.f);
+            s_ray[it * BLOCK + tid] = (i != 0xffffffffu && ABL != 6) ? a.f.proj_lut[i] : make_float2(0.1f, 0.2f);
         }
         __syncthreads();
         const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
         for (int it = 0; it < 3; ++it)
-            if ((uint32_t)(it * BLOCK + tid) < nvec) dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
+            if ((uint32_t)(it * BLOCK + tid) < nvec && (ABL != 5 || s_buf[it * BLOCK + tid].x == 12345.678f)) dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
     }
 }
 
@@ -674,7 +676,12 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + 127) / 128;
-    if (g.n_runs > 1)
+    const char *abl_env = getenv("SLGC_FUSE_ABL");
+    const int fabl = abl_env ? atoi(abl_env) : 0;
+    if (fabl == 5) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+    else if (fabl == 6) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+    else if (fabl == 7) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+    else if (g.n_runs > 1)
         hipLaunchKernelGGL((k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
     else
         hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
