@@ -515,7 +515,7 @@ def test_scan_dev_ragged_sizes(ctx, calib):
     psize = (200, 150)
     pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
     R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
-    for (H, W) in ((7, 33), (5, 64), (9, 130)):
+    for (H, W) in ((7, 33), (5, 64), (9, 130), (4, 33), (8, 131), (12, 17)):      # the last three: fused kernel, 4-pixel groups straddle rows
         st, _, _ = onp.synth_scene_int(N, H, W, seed=H)
         K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 150.0, 150.0
         ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
