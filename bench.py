@@ -181,7 +181,9 @@ def main():
     mode_split, mode_fused = mode | _native.TRI_SPLIT, mode & ~_native.TRI_SPLIT
     mode = mode_split if args.pipeline == "split" else mode_fused
 
-    ctx = _native.Context(local_rank)
+    n_dev = max(1, _native.device_count())
+    device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
+    ctx = _native.Context(device)
     calib = calibration(cam_w, cam_h, proj_w, proj_h)
     ctx.set_calibration(*calib)
     uid_path = None
@@ -273,7 +275,7 @@ def main():
         dec_alone = ctx.prof_end()
     thr = None
     if not args.no_throughput_mode and args.mode == "algebraic" and args.tri == "lut":
-        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, local_rank, args.streams)
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams)
     if not use_comm:
         count.zero()
         step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
