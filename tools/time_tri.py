@@ -19,4 +19,4 @@ for mode in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,0").split
     for i in range(20):
         ctx.triangulate_maps_dev(maps.at(0), maps.at(W * H * 2), H, W, 0, (PW, PH), xyz.ptr, None, mode=mode)
     ctx.event_record(1)
-    print(f"mode {mode} abl {os.environ.get('SLGC_TRI_ABL', '0')}: {ctx.event_elapsed_ms(0, 1) / 20 * 1e3:.1f} us", flush=True)
+    print(f"mode {mode}: {ctx.event_elapsed_ms(0, 1) / 20 * 1e3:.1f} us", flush=True)
