@@ -109,3 +109,23 @@ def test_product_never_touches_oracle_or_torch():
             continue
         text = open(os.path.join(PKG, "csrc", f)).read()
         assert "slgc_oracle" not in text and "orc_" not in text, f
+
+
+def test_host_only_helpers(tmp_path):
+    """Helpers that need no GPU: PLY layout, read_images file order, shard plan."""
+    from scanner.grayCode.decode_codes import read_images_order
+    from scanner.utils import pointcloud as pc
+    names = ["frame_10.jpg", "frame_2.jpg", "frame_1.jpg", "frame_100.jpg", "frame_11.jpg"]
+    assert read_images_order(names) == ["frame_2.jpg", "frame_1.jpg", "frame_10.jpg", "frame_11.jpg", "frame_100.jpg"]   # stable, by length only
+    pts = np.array([[0.0, 0.5, -1.25], [1.0, 2.0, 3.0]])
+    col = np.array([[0.0, 0.5, 1.0], [1.2, -0.1, 0.25]])
+    n = pc.write_ply(tmp_path / "c.ply", pts.T, col)                       # (3,M) input like triangulate() returns
+    raw = open(tmp_path / "c.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert n == 2 and b"format binary_little_endian 1.0" in head and b"element vertex 2" in head
+    rec = np.frombuffer(body, dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("r", "u1"), ("g", "u1"), ("b", "u1")]))
+    assert list(rec["z"]) == [-1.25, 3.0] and list(rec["r"]) == [0, 255] and list(rec["g"]) == [128, 0] and list(rec["b"]) == [255, 64]
+    n = pc.write_ply(tmp_path / "n.ply", pts)
+    assert b"red" not in open(tmp_path / "n.ply", "rb").read().split(b"end_header")[0]
+    with pytest.raises(ValueError):
+        pc.write_ply(tmp_path / "bad.ply", pts, col[:1])
