@@ -28,27 +28,31 @@ __global__ void __launch_bounds__(256) k_xmajor_count(const int64_t *__restrict_
     counts[(size_t)chunk * W + x] = c;
 }
 
-// ---- x-major: pass B, one workgroup: within-column prefix over chunks, then exclusive scan over columns ----
-__global__ void __launch_bounds__(1024) k_xmajor_offsets(unsigned *__restrict__ counts, int W, int nchunks,
-                                                         unsigned long long *__restrict__ colstart,
-                                                         unsigned long long *__restrict__ total)
+// ---- x-major: pass B1, one thread per column: prefix over the row chunks (lanes along x: coalesced), column totals ----
+__global__ void __launch_bounds__(256) k_xmajor_colprefix(unsigned *__restrict__ counts, int W, int nchunks,
+                                                          unsigned long long *__restrict__ colstart)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    unsigned run = 0;
+#pragma unroll 8
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned n = counts[(size_t)c * W + x];
+        counts[(size_t)c * W + x] = run;  // valid pixels above this chunk in column x
+        run += n;
+    }
+    colstart[x] = run;  // column total for now
+}
+
+// ---- x-major: pass B2, one workgroup: exclusive scan of the column totals ----
+__global__ void __launch_bounds__(1024) k_xmajor_colscan(int W, unsigned long long *__restrict__ colstart, unsigned long long *__restrict__ total)
 {
     __shared__ unsigned long long part[1024];
     const int t = threadIdx.x;
-    // each thread owns a contiguous slab of columns so the scan over columns stays ordered
-    const int per = (W + 1023) / 1024;
+    const int per = (W + 1023) / 1024;                 // each thread owns a contiguous slab of columns: the scan stays ordered
     const int x0 = min(W, t * per), x1 = min(W, x0 + per);
     unsigned long long mine = 0;
-    for (int x = x0; x < x1; ++x) {
-        unsigned run = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            const unsigned n = counts[(size_t)c * W + x];
-            counts[(size_t)c * W + x] = run;  // valid pixels above this chunk in column x
-            run += n;
-        }
-        colstart[x] = run;  // column total for now
-        mine += run;
-    }
+    for (int x = x0; x < x1; ++x) mine += colstart[x];
     part[t] = mine;
     __syncthreads();
     if (t == 0) {
@@ -69,32 +73,63 @@ __global__ void __launch_bounds__(1024) k_xmajor_offsets(unsigned *__restrict__ 
     }
 }
 
-// ---- x-major: pass C, scatter ----
+// ---- x-major: pass C, scatter through an LDS transpose ----
+// A workgroup owns a tile of kChunkRows (32) rows x 64 columns.  Phase 1 reads it with lanes along x (coalesced 512-byte rows
+// of the int64 maps) and parks the clamped projector coordinates (and the packed colour) in LDS.  Phase 2 turns the tile: a
+// half-wave takes one column, its 32 lanes are the 32 rows, a ballot gives every valid pixel its rank inside the column
+// segment, and the segment leaves as one contiguous run of records (x-major order = column after column, rows ascending).
+constexpr int kTileCols = 64;
+constexpr int kInvalid = (int)0x80000000;
+
 __global__ void __launch_bounds__(256) k_xmajor_scatter(const int64_t *__restrict__ h, const int64_t *__restrict__ v, int W, int H,
                                                         int proj_w, int proj_h, const uint8_t *__restrict__ white,
                                                         const unsigned *__restrict__ counts,
                                                         const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
                                                         float *__restrict__ proj, double *__restrict__ colors)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int chunk = blockIdx.y;
-    if (x >= W) return;
-    const int y0 = chunk * kChunkRows, y1 = min(H, y0 + kChunkRows);
-    unsigned long long o = colstart[x] + counts[(size_t)chunk * W + x];
-    for (int y = y0; y < y1; ++y) {
-        const size_t p = (size_t)y * W + x;
-        const int64_t hv = h[p], vv = v[p];
-        if (!decodable(hv, vv)) continue;
-        cam[2 * o] = (float)x;                                         // :59 [i, j] = (x, y)
-        cam[2 * o + 1] = (float)y;
-        proj[2 * o] = (float)(hv < proj_w - 1 ? hv : proj_w - 1);      // :60
-        proj[2 * o + 1] = (float)(vv < proj_h - 1 ? vv : proj_h - 1);  // :61
-        if (colors) {
-            colors[3 * o] = (double)white[3 * p] / 255.0;              // :64, :69
-            colors[3 * o + 1] = (double)white[3 * p + 1] / 255.0;
-            colors[3 * o + 2] = (double)white[3 * p + 2] / 255.0;
+    __shared__ int s_pu[kChunkRows][kTileCols + 1], s_pv[kChunkRows][kTileCols + 1];
+    __shared__ unsigned s_rgb[kChunkRows][kTileCols + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x_tile = blockIdx.x * kTileCols, chunk = blockIdx.y, y_tile = chunk * kChunkRows;
+#pragma unroll
+    for (int s = 0; s < kChunkRows / 4; ++s) {
+        const int r = s * 4 + wave, x = x_tile + lane, y = y_tile + r;
+        int pu = kInvalid, pv = 0;
+        unsigned rgb = 0;
+        if (x < W && y < H) {
+            const size_t p = (size_t)y * W + x;
+            const int64_t hv = h[p], vv = v[p];
+            if (decodable(hv, vv)) {
+                pu = (int)(hv < proj_w - 1 ? hv : proj_w - 1);                  // triangulate.py:60 (maps from this library fit 32 bits)
+                pv = (int)(vv < proj_h - 1 ? vv : proj_h - 1);                  // :61
+                if (pu == kInvalid) pu = kInvalid + 1;
+                if (colors) rgb = (unsigned)white[3 * p] | ((unsigned)white[3 * p + 1] << 8) | ((unsigned)white[3 * p + 2] << 16);
+            }
         }
-        ++o;
+        s_pu[r][lane] = pu;
+        s_pv[r][lane] = pv;
+        s_rgb[r][lane] = rgb;
+    }
+    __syncthreads();
+    const int half = lane >> 5, r = lane & 31;
+#pragma unroll 2
+    for (int s = 0; s < kTileCols / 8; ++s) {
+        const int c = wave * (kTileCols / 4) + 2 * s + half, x = x_tile + c;    // this half-wave's column
+        const int pu = s_pu[r][c];
+        const bool ok = pu != kInvalid;
+        const unsigned long long m = __ballot(ok);
+        const unsigned mh = (unsigned)(half ? (m >> 32) : m);
+        if (ok && x < W) {
+            const unsigned long long o = colstart[x] + counts[(size_t)chunk * W + x] + (unsigned)__popc(mh & ((1u << r) - 1u));
+            reinterpret_cast<float2 *>(cam)[o] = make_float2((float)x, (float)(y_tile + r));                    // :59 [i, j] = (x, y)
+            reinterpret_cast<float2 *>(proj)[o] = make_float2((float)pu, (float)s_pv[r][c]);
+            if (colors) {
+                const unsigned rgb = s_rgb[r][c];
+                colors[3 * o] = (double)(rgb & 0xffu) / 255.0;                   // :64, :69
+                colors[3 * o + 1] = (double)((rgb >> 8) & 0xffu) / 255.0;
+                colors[3 * o + 2] = (double)((rgb >> 16) & 0xffu) / 255.0;
+            }
+        }
     }
 }
 
@@ -297,11 +332,13 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
     if (rc) return rc;
     const dim3 grid((cam_w + 255) / 256, nchunks);
     if (npix) hipLaunchKernelGGL(k_xmajor_count, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
-    hipLaunchKernelGGL(k_xmajor_offsets, dim3(1), dim3(1024), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
-                       (unsigned long long *)colstart, d_total);
+    if (cam_w)
+        hipLaunchKernelGGL(k_xmajor_colprefix, dim3((cam_w + 255) / 256), dim3(256), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
+                           (unsigned long long *)colstart);
+    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
     if (npix)
-        hipLaunchKernelGGL(k_xmajor_scatter, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white,
-                           (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj,
+        hipLaunchKernelGGL(k_xmajor_scatter, dim3((cam_w + kTileCols - 1) / kTileCols, nchunks), dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h,
+                           proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj,
                            d_white ? d_colors : nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
