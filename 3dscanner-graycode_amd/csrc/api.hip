@@ -687,8 +687,8 @@ extern "C" int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t byte
 static int prof_mark(slgc_ctx *ctx, int phase)
 {
     if (!ctx->prof_on) return SLGC_OK;
-    if (phase == 0 && ctx->prof_n >= ctx->prof_cap) return SLGC_OK;  // ring full: later launches are not sampled
-    if (phase == 1 && ctx->prof_n >= ctx->prof_cap) return SLGC_OK;
+    if (phase == 0) ctx->prof_sampling = (ctx->prof_seen++ % ctx->prof_stride) == 0 && ctx->prof_n < ctx->prof_cap;
+    if (!ctx->prof_sampling) return SLGC_OK;      // not a sampled launch (stride) or ring full
     HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + phase], ctx->stream));
     if (phase == 1) ++ctx->prof_n;
     return SLGC_OK;
@@ -703,11 +703,14 @@ static int decode_fast_timed(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &
     return prof_mark(ctx, 1);
 }
 
-extern "C" int slgc_prof_begin(slgc_ctx *ctx, int max_launches)
+extern "C" int slgc_prof_begin(slgc_ctx *ctx, int max_launches, int stride)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if (max_launches < 1 || max_launches > 65536) return slgc_fail(ctx, SLGC_EINVAL, "max_launches out of range");
+    if (max_launches < 1 || max_launches > 65536 || stride < 1) return slgc_fail(ctx, SLGC_EINVAL, "max_launches / stride out of range");
+    ctx->prof_stride = stride;
+    ctx->prof_seen = 0;
+    ctx->prof_sampling = false;
     if (ctx->prof_cap < max_launches) {
         hipEvent_t *ev = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
         if (!ev) return slgc_fail(ctx, SLGC_ENOMEM, "event ring");

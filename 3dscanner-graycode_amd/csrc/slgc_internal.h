@@ -69,6 +69,8 @@ struct slgc_ctx {
     bool prof_on;
     hipEvent_t *prof_ev;   // pairs: [2i] before, [2i+1] after the decode launch
     int prof_cap, prof_n;
+    int prof_stride, prof_seen;   // every prof_stride-th launch is bracketed (an event pair costs ~1.5 % of a 160 us kernel)
+    bool prof_sampling;
     // communicator (comm.cpp)
     void *comm;
     int rank, nranks;

@@ -67,7 +67,7 @@ SIGNATURES = {
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
-    "slgc_prof_begin": (_i, [_vp, _i]),
+    "slgc_prof_begin": (_i, [_vp, _i, _i]),
     "slgc_prof_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "slgc_comm_unique_id": (_i, [_vp]),
     "slgc_comm_init": (_i, [_vp, _i, _i, _vp]),
@@ -411,8 +411,8 @@ class Context:
         rows = H if rows is None else rows
         self._ck(lib().slgc_synth_scene_dev(self._h, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, int(bool(shadow))))
 
-    def prof_begin(self, max_launches: int = 4096):
-        self._ck(lib().slgc_prof_begin(self._h, int(max_launches)))
+    def prof_begin(self, max_launches: int = 4096, stride: int = 1):
+        self._ck(lib().slgc_prof_begin(self._h, int(max_launches), int(stride)))
 
     def prof_end(self):
         """-> (summed decode-kernel milliseconds, launches sampled)"""

@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket every n-th kernel launch of the timed region with a HIP event pair (1 = all; each pair costs ~1.5 %% of a step)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (contexts) per GPU in the throughput-mode measurement")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
     ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
@@ -240,7 +242,7 @@ def main():
         ctx.synchronize()
         if G > 1:
             ctx.comm_barrier()
-        ctx.prof_begin(K + 8)
+        ctx.prof_begin(K + 8, args.event_stride)     # HIP-event pair around every event_stride-th kernel launch of the region
         t0 = time.perf_counter()
         tot = None
         for i in range(K):

@@ -179,10 +179,10 @@ int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, i
 int slgc_event_record(slgc_ctx *ctx, int id);
 int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms);
 
-/* Per-launch timing of the decode kernel: between _begin and _end every decode launch made through slgc_decode_dev /
- * slgc_scan_dev is bracketed by a HIP event pair on the context's stream (up to max_launches); _end synchronises and
+/* Per-launch timing of the decode kernel: between _begin and _end every stride-th decode launch made through slgc_decode_dev /
+ * slgc_scan_dev is bracketed by a HIP event pair on the context's stream (up to max_launches pairs); _end synchronises and
  * returns the summed kernel time and the number of launches sampled. */
-int slgc_prof_begin(slgc_ctx *ctx, int max_launches);
+int slgc_prof_begin(slgc_ctx *ctx, int max_launches, int stride);
 int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches);
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
