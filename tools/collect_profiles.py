@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-shutil.copy(glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
-print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), glob.glob(os.path.join(src, "kt", "*", "*kernel_trace.csv"))[0],
+shutil.copy(max(glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime), os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
+print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), max(glob.glob(os.path.join(src, "kt", "*", "*kernel_trace.csv")), key=os.path.getmtime),
                       os.path.join(dst, f"{tag}_kernel_stats_by_grid.csv")], capture_output=True, text=True).stdout.split("k_synth")[0])
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(src, "pmc")], capture_output=True)
 shutil.copy(os.path.join(src, "pmc", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_summary_c3.json"))
