@@ -1,0 +1,161 @@
+"""N > 1 path with the real kernels: world_size 2 and 3, one process per rank, all ranks on the one GPU of the test box.
+
+RCCL refuses two ranks on one device ("Duplicate GPU detected", ncclInvalidUsage), so the transport here is a host-staged
+gloo double with the RcclExchange protocol (device band -> host -> gloo broadcast -> device).  Everything else is the
+product path: ShardPlan bands, decode_dev on a band with its row offset, the in-place map layout, triangulate_maps_dev over
+the reassembled maps, scan_dev + compact_records_dev with row0, submit()/flush() pipelining.  Every rank must end up with the
+same maps (bit-exact with the oracle's whole-image decode) and the same cloud (XYZ_RTOL)."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+XYZ_RTOL = 1e-4           # BASELINE.json north_star: XYZ within 1e-4 relative
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class StagedGlooExchange:
+    """RcclExchange protocol over device pointers, moved through the host with torch.distributed(gloo)."""
+
+    def __init__(self, ctx, native, dist, torch):
+        self.ctx, self.native, self.dist, self.torch = ctx, native, dist, torch
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+
+    @staticmethod
+    def _ptr(b):
+        return b.ptr if hasattr(b, "ptr") else int(b)
+
+    def allgather_i64(self, value):
+        out = [self.torch.zeros(1, dtype=self.torch.int64) for _ in range(self.nranks)]
+        self.dist.all_gather(out, self.torch.tensor([int(value)], dtype=self.torch.int64))
+        return [int(x[0]) for x in out]
+
+    def allgatherv(self, d_send, d_recv, byte_counts, byte_displs):
+        lib, h = self.native.lib(), self.ctx._h
+        send, recv = self._ptr(d_send), self._ptr(d_recv)
+        for r in range(self.nranks):
+            n = int(byte_counts[r])
+            if n == 0:
+                continue
+            host = np.empty(n, np.uint8)
+            if r == self.rank:                                   # stream-ordered after the kernels that produced the band
+                self.ctx._ck(lib.slgc_d2h(h, host.ctypes.data_as(C.c_void_p), C.c_void_p(send), n))
+            self.dist.broadcast(self.torch.from_numpy(host), src=r)
+            if r != self.rank or send != recv + int(byte_displs[r]):
+                self.ctx._ck(lib.slgc_h2d(h, C.c_void_p(recv + int(byte_displs[r])), host.ctypes.data_as(C.c_void_p), n))
+
+    def allgatherv_begin(self, d_send, d_recv, byte_counts, byte_displs, slot):
+        self.allgatherv(d_send, d_recv, byte_counts, byte_displs)       # host-staged double: complete on return
+
+    def wait(self, slot):
+        pass
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def _worker(rank, world, port, H, W, N, q):
+    try:
+        for p in (PKG, os.path.join(ROOT, "oracle")):
+            sys.path.insert(0, p)
+        import torch
+        import torch.distributed as dist
+        import oracle_c as oc
+        import oracle_np as onp
+        from scanner import _native, sharded
+        from scanner import reference_calibration as rc
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ctx = _native.Context(0)
+        ex = StagedGlooExchange(ctx, _native, dist, torch)
+        plan = sharded.ShardPlan(H, W, world)
+        row0, rows = plan.band(rank)
+        K = rc.CAM_MTX.copy()
+        K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 250.0, 250.0
+        psize = (160, 120)
+        pk = onp.scale_proj_mtx(rc.PROJ_MTX, psize, (1920, 1080))
+        th = np.deg2rad(-20.0)
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        T = np.array([[0.25], [0.02], [0.04]])
+        ctx.set_calibration(K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
+
+        def reference(st):
+            fh, fv, fx = oc.scan_dense(st, psize, K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
+            return fh, fv, np.moveaxis(fx, 0, -1), (fh != -1) & (fv != -1)
+
+        def check_dense(got, st):
+            gh, gv, gx = got
+            fh, fv, fx, ok = reference(st)
+            assert np.array_equal(gh, fh) and np.array_equal(gv, fv)
+            assert np.array_equal(np.isfinite(gx[..., 0]), ok)
+            np.testing.assert_allclose(gx[ok], fx[ok], rtol=XYZ_RTOL, atol=0)
+
+        def upload_band(st):                                     # this rank holds only its row band of every frame
+            band = np.ascontiguousarray(st[:, row0:row0 + rows])
+            return ctx.alloc(max(16, band.nbytes)).upload(band) if rows else ctx.alloc(16)
+
+        caps = [onp.synth_scene_int(N, H, W, seed=40 + j, noise=3 + j)[0] for j in range(3)]
+        bufs = [upload_band(cp) for cp in caps]
+        plane = max(1, rows * W)
+        # ---- "maps" strategy, one scan at a time
+        scm = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT)
+        assert scm.scan(bufs[0].ptr, plane) is None
+        check_dense(scm.fetch_dense(), caps[0])
+        # ---- pipelined: three captures in flight, results in order
+        outs = []
+        for j, b in enumerate(bufs):
+            scm.submit(b.ptr, plane)
+            if j:
+                outs.append(scm.fetch_dense())
+        scm.flush()
+        outs.append(scm.fetch_dense())
+        for cp, got in zip(caps, outs):
+            check_dense(got, cp)
+        # ---- "records" strategy: counts all-gather + all-gatherv of {xyz, key} records
+        sc = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT, exchange_kind="records")
+        total = sc.scan(bufs[1].ptr, plane)
+        rec = sc.fetch(total)
+        fh, fv, fx, ok = reference(caps[1])
+        assert total == int(ok.sum()) and sum(sc.last_counts) == total and len(sc.last_counts) == world
+        assert np.array_equal(rec["key"], np.nonzero(ok.ravel())[0])                 # band-major concatenation == row-major
+        np.testing.assert_allclose(rec["xyz"], fx[ok], rtol=XYZ_RTOL, atol=0)
+        cam, P = sharded.to_reference_lists(rec, W, H)
+        rcam, _, _ = oc.cam_proj_pts(fh, fv, (W, H), psize, None, order="x")
+        assert np.array_equal(cam, rcam) and P.shape == (3, total)
+        ex.barrier()
+        ctx.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok", list(sc.last_counts)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (4, 3)])
+def test_sharded_scanner_ranks_share_one_gpu(world, H):
+    """(4, 3): more ranks than rows -> one rank owns an empty band."""
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, H, 128, 26, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in results:
+        assert status == "ok", f"rank {rank}: {info}"
+    assert len({tuple(info) for _, _, info in results}) == 1
