@@ -304,7 +304,8 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
-    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t ps = a.plane_stride;
     const int L = a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
         __syncthreads();
-        const uint32_t first = blockIdx.x * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
+        const uint32_t first = bid * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
         const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)BLOCK ? ngroups - first : (uint32_t)BLOCK) * 3u) : 0u;
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll

@@ -127,3 +127,22 @@ int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, in
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
                              unsigned long long *d_counts);
+
+// XCD-aware workgroup -> tile map.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round-robin, and each XCD has
+// its own L2.  With the identity map every XCD sees every 8th tile of the image; with this map XCD x owns the contiguous
+// tile range [x*chunk, (x+1)*chunk) (a band of whole rows), so the projector-ray lines it gathers are shared by neighbouring
+// rows inside one L2.  Ids past 8*chunk (blocks % 8 of them) keep their position.  chunk = 0: identity.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t chunk)
+{
+    return (chunk != 0u && bid < chunk * 8u) ? (bid & 7u) * chunk + (bid >> 3) : bid;
+}
+inline int xcd_env(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+inline uint32_t xcd_chunk_for(unsigned blocks)
+{
+    static const int mode = xcd_env("SLGC_XCD", 1);
+    return (mode && blocks >= 64) ? blocks / 8 : 0u;
+}

@@ -208,12 +208,13 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
                                                               const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
-                                                              unsigned long long *__restrict__ count)
+                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk)
 {
     __shared__ uint4 s_idx[256];
     __shared__ float4 s_buf[768];
     const int tid = threadIdx.x;
-    const size_t g = (size_t)blockIdx.x * 256 + tid;
+    const uint32_t bid = xcd_block(blockIdx.x, xcd_chunk);
+    const size_t g = (size_t)bid * 256 + tid;
     const bool live = g < ngroups;
     uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
     s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
     __syncthreads();
-    const size_t first = (size_t)blockIdx.x * 256;
+    const size_t first = (size_t)bid * 256;
     const size_t nvec = (ngroups - first < 256 ? ngroups - first : 256) * 3;      // float4s this workgroup owns
     float4 *dst = reinterpret_cast<float4 *>(xyz) + first * 3;
 #pragma unroll
@@ -357,10 +358,10 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks));
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks));
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;

@@ -160,6 +160,8 @@ def main():
                          "compacted 16-byte XYZ+key records")
     ap.add_argument("--no-overlap", action="store_true", help="sharded 'maps' mode: do not pipeline the exchange with the neighbouring scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
+    ap.add_argument("--plane-pad", type=int, default=0,
+                    help="extra bytes between frame planes in HBM (multiple of 16; 0 = contiguous [N,H,W] like the reference)")
     ap.add_argument("--buffers", type=int, default=0,
                     help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
     args = ap.parse_args()
@@ -206,7 +208,7 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL prints its version banner through C stdio: flush it now so rank 0's JSON stays the last line
     band_px = rows * cam_w
-    plane = band_px                         # each rank holds only its row band of every frame
+    plane = band_px + args.plane_pad        # each rank holds only its row band of every frame; pad 0 = the reference's contiguous [N,H,W]
     stacks = []
     if args.buffers <= 0:                                   # enough distinct stacks to exceed the 256 MB Infinity Cache
         args.buffers = max(2, -(-300_000_000 // (N * plane)))
@@ -317,7 +319,7 @@ def main():
                                                                 "compacted 16-byte XYZ+key records all-gathered")}),
                        "pipeline": ("decode kernel per band + full-image triangulation kernel per rank" if (use_comm and args.exchange == "maps")
                                     else args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)")),
-                       "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks),
+                       "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks), "plane_pad_bytes": args.plane_pad,
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
                                   + ("" if not use_comm else "; whole cloud reassembled on every rank")},
             # the kernel bracketed by the event pairs: the fused scan kernel, or (split / sharded "maps" strategy) the decode kernel

@@ -508,6 +508,39 @@ def test_decode_extreme_frame_counts_and_eps(ctx, N, eps):
     assert hp.max() <= (1 << int((N - 2) / 4)) - 1
 
 
+@pytest.mark.parametrize("H,W", [(270, 256), (300, 1000), (64, 1024)])
+def test_triangulate_maps_xcd_remap_sizes(ctx, calib, H, W):
+    """Dense triangulation with >= 64 workgroups takes the XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block); sizes
+    whose workgroup count is / is not a multiple of 8, last workgroup partial.  Every pixel must still land in its own slot."""
+    N = 26
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=H)
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 400.0, 400.0
+    psize = (200, 150)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    hp, vp, ref = oc.scan_dense(st, psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+    ok = (hp != -1) & (vp != -1)
+    dh, dv = ctx.alloc(H * W * 2).upload(hp.astype(np.int16)), ctx.alloc(H * W * 2).upload(vp.astype(np.int16))
+    xyz, cnt = ctx.alloc(H * W * 12), ctx.alloc(8)
+    for mode in (0, 1):
+        cnt.zero()
+        xyz.zero()
+        ctx.triangulate_maps_dev(dh.ptr, dv.ptr, H, W, 0, psize, xyz.ptr, cnt.ptr, mode=mode)
+        ctx.synchronize()
+        got = xyz.download((H, W, 3), np.float32)
+        assert int(cnt.download((1,), np.uint64)[0]) == ok.sum()
+        assert np.array_equal(np.isfinite(got[..., 0]), ok) and np.isnan(got[~ok]).all()
+        want = np.moveaxis(ref, 0, -1)
+        # this geometry has a few near-parallel ray pairs (ranges of 1e3..1e4 baselines); the cancelled form is compared on the rest
+        sel = ok if mode == 0 else ok & (np.abs(want).max(axis=-1) < 100.0)
+        assert sel.sum() > 0.99 * ok.sum()
+        np.testing.assert_allclose(got[sel], want[sel], rtol=XYZ_RTOL, atol=0)
+    for b in (dh, dv, xyz, cnt):
+        b.free()
+
+
 def test_scan_dev_ragged_sizes(ctx, calib):
     """Bands whose pixel count is not a multiple of 4 (or whose width is odd) take the two-kernel path with byte-wide tails."""
     N = 26
