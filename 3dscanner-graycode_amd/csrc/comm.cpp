@@ -200,3 +200,37 @@ extern "C" int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_r
     if (rc) return rc;
     return slgc_comm_wait(ctx, 3);
 }
+
+extern "C" int slgc_shard_band(int H, int nranks, int rank, int *row0, int *rows)
+{
+    if (H < 0 || nranks < 1 || rank < 0 || rank >= nranks || !row0 || !rows) return SLGC_EINVAL;
+    const int base = H / nranks, extra = H % nranks;
+    *rows = base + (rank < extra ? 1 : 0);
+    *row0 = rank * base + (rank < extra ? rank : extra);
+    return SLGC_OK;
+}
+
+extern "C" int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack, int n_runs, size_t run_stride, size_t plane_stride,
+                                     int N, int H, int W, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h_full,
+                                     int16_t *d_v_full, float *d_xyz_full)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!d_h_full || !d_v_full || !d_xyz_full) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    if (H < 0 || W < 0 || ctx->nranks > 1024) return slgc_fail(ctx, SLGC_EINVAL, "bad image size / nranks");
+    int64_t counts[1024], displs[1024];
+    int row0 = 0, rows = 0;
+    for (int r = 0; r < ctx->nranks; ++r) {
+        int b0, bn;
+        slgc_shard_band(H, ctx->nranks, r, &b0, &bn);
+        counts[r] = (int64_t)bn * W * 2;          // bytes of one int16 map band
+        displs[r] = (int64_t)b0 * W * 2;
+        if (r == ctx->rank) { row0 = b0; rows = bn; }
+    }
+    int16_t *my_h = d_h_full + (size_t)row0 * W, *my_v = d_v_full + (size_t)row0 * W;
+    if (rows > 0 && (rc = slgc_decode_dev(ctx, d_band_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, m, my_h, my_v, 0))) return rc;
+    if ((rc = slgc_comm_allgatherv_begin(ctx, my_h, d_h_full, counts, displs, 2))) return rc;
+    if ((rc = slgc_comm_allgatherv_begin(ctx, my_v, d_v_full, counts, displs, 3))) return rc;
+    if ((rc = slgc_comm_wait(ctx, 2)) || (rc = slgc_comm_wait(ctx, 3))) return rc;
+    return slgc_triangulate_maps_dev(ctx, d_h_full, d_v_full, H, W, 0, proj_w, proj_h, mode & 3, d_xyz_full, nullptr);
+}

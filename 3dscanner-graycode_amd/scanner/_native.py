@@ -78,6 +78,8 @@ SIGNATURES = {
     "slgc_comm_allgatherv": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "slgc_comm_allgatherv_begin": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_wait": (_i, [_vp, _i]),
+    "slgc_shard_band": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "slgc_scan_sharded_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -100,6 +102,14 @@ def lib():
                 fn.argtypes = args
             _lib = handle
     return _lib
+
+
+def shard_band(H: int, nranks: int, rank: int):
+    """(row0, rows) of a rank's band: slgc_shard_band, the plan slgc_scan_sharded_dev uses."""
+    r0, rn = C.c_int(), C.c_int()
+    if lib().slgc_shard_band(H, nranks, rank, C.byref(r0), C.byref(rn)):
+        raise ValueError("bad H / nranks / rank")
+    return r0.value, rn.value
 
 
 def device_count() -> int:
@@ -464,6 +474,12 @@ class Context:
 
     def comm_wait(self, slot: int):
         self._ck(lib().slgc_comm_wait(self._h, int(slot)))
+
+    def scan_sharded_dev(self, d_band_stack: int, n_runs, run_stride, plane_stride, N, H, W, proj_size, d_h_full: int, d_v_full: int,
+                         d_xyz_full: int, eps=1, m=10, mode=TRI_ALGEBRAIC):
+        """One row-sharded scan in one C call (decode band -> in-place map all-gatherv -> full triangulation), asynchronous."""
+        self._ck(lib().slgc_scan_sharded_dev(self._h, d_band_stack, n_runs, run_stride, plane_stride, N, H, W, proj_size[0], proj_size[1],
+                                             float(eps), float(m), mode, d_h_full, d_v_full, d_xyz_full))
 
 
 _default_ctx = None

@@ -202,6 +202,19 @@ int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const 
 int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot);
 int slgc_comm_wait(slgc_ctx *ctx, int slot);
 
+/* Row-band plan of the sharded scan: contiguous bands, the first H % nranks ranks get one extra
+ * row.  Pure arithmetic, no context needed. */
+int slgc_shard_band(int H, int nranks, int rank, int *row0, int *rows);
+
+/* One row-sharded scan in one call, nothing synchronises with the host ("maps" strategy): decode this rank's band
+ * (d_band_stack = its first row of frame 0, band rows from slgc_shard_band with the context's rank / nranks) into its slot of
+ * the full-size int16 maps, all-gatherv both maps in place over RCCL, triangulate the full maps.  Afterwards every rank
+ * holds d_h_full / d_v_full [H][W] and dense float32 d_xyz_full [H][W][3] (NaN = undecodable) -- the reassembled cloud of
+ * BASELINE.json configs[3].  Replaces, for N GPUs, src/3-capture_decode.py:75-100 + src/4-triangulate.py:50-64. */
+int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack, int n_runs, size_t run_stride, size_t plane_stride,
+                          int N, int H, int W, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h_full,
+                          int16_t *d_v_full, float *d_xyz_full);
+
 #ifdef __cplusplus
 }
 #endif

@@ -426,6 +426,14 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
             ok2 = (rh2 != -1) & (rv2 != -1)
             assert np.array_equal(gh2, rh2) and np.array_equal(gv2, rv2) and np.array_equal(np.isfinite(gx2[..., 0]), ok2)
             np.testing.assert_allclose(gx2[ok2], np.moveaxis(rx2, 0, -1)[ok2], rtol=XYZ_RTOL, atol=0)
+        # the same scan through the one-call C entry point (slgc_scan_sharded_dev)
+        dh, dv, dx = ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 12).zero()
+        ctx.scan_sharded_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, psize, dh.ptr, dv.ptr, dx.ptr, mode=_native.TRI_EXACT)
+        ctx.synchronize()
+        assert np.array_equal(dh.download((H, W), np.int16), hp) and np.array_equal(dv.download((H, W), np.int16), vp)
+        cx = dx.download((H, W, 3), np.float32)
+        assert np.array_equal(np.isfinite(cx[..., 0]), okm)
+        np.testing.assert_allclose(cx[okm], np.moveaxis(ref, 0, -1)[okm], rtol=XYZ_RTOL, atol=0)
         sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT,
                                     exchange_kind="records")
         total = sc.scan(stack.ptr, H * W)

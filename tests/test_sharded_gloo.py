@@ -137,6 +137,17 @@ def test_sharded_exchange_gloo(world, H):
     assert len({tuple(info) for _, _, info in results}) == 1          # every rank saw the same counts
 
 
+def test_c_shard_band_matches_python_plan():
+    """slgc_shard_band (the plan slgc_scan_sharded_dev uses) == ShardPlan.band for every rank, ragged and empty bands."""
+    from scanner import _native, sharded
+    for H in (0, 1, 3, 7, 48, 50, 1080, 3000):
+        for G in (1, 2, 3, 4, 7, 8):
+            plan = sharded.ShardPlan(H, 16, G)
+            assert [_native.shard_band(H, G, r) for r in range(G)] == plan.bands()
+    with pytest.raises(ValueError):
+        _native.shard_band(10, 2, 2)
+
+
 def test_shard_plan_and_layout():
     from scanner import sharded
     for H, G in ((3000, 8), (3000, 7), (5, 8), (1080, 4)):
