@@ -172,6 +172,41 @@ def test_decode_dev_variants(ctx, variant):
     assert np.array_equal(h, rb[0]) and np.array_equal(v, rb[1])
 
 
+def _fuzz_stack(rng, R, N, H, W):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        return rng.integers(0, 256, (R, N, H, W), dtype=np.uint8)
+    if kind == 1:                                               # tiny range: exact ties in (L_max-L_min)*w/(w+b) and in n == i +- eps
+        return rng.integers(0, int(rng.integers(2, 12)), (R, N, H, W), dtype=np.uint8)
+    if kind == 2:                                               # saturated extremes, black == white == 0 (NaN) included
+        return rng.choice(np.array([0, 1, 254, 255], np.uint8), (R, N, H, W))
+    if kind == 3:                                               # two levels + noise: thresholds sit next to the data
+        lo, hi = sorted(int(x) for x in rng.integers(0, 256, 2))
+        st = np.where(rng.integers(0, 2, (R, N, H, W)) == 1, hi, lo) + rng.integers(-2, 3, (R, N, H, W))
+        return np.clip(st, 0, 255).astype(np.uint8)
+    return np.stack([onp.synth_scene_int(N, H, W, seed=int(rng.integers(1 << 30)), noise=int(rng.integers(0, 12)))[0] for _ in range(R)])
+
+
+def test_decode_fuzz_vs_oracle(ctx):
+    """400 seeded random cases over N (14..62), image shape (ragged widths, single rows), run count, eps and five value
+    distributions built to sit on the rule table's boundaries: device-resident kernels and the host API, bit-exact vs the oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(400):
+        N = int(rng.integers(14, 63))
+        H, W = int(rng.integers(1, 24)), int(rng.integers(1, 140))
+        R = int(rng.integers(1, 4))
+        eps = int(rng.choice([0, 1, 1, 1, 2, 5, 40]))
+        st = _fuzz_stack(rng, R, N, H, W)
+        ref = oc.decode(st, eps=eps)
+        tag = f"case {case}: N={N} H={H} W={W} R={R} eps={eps}"
+        if case % 3 == 2:                                       # host API (float64 stack as the reference driver builds it, or uint8)
+            got = ctx.decode(st.astype(np.float64) if case % 2 else st, eps=eps)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), tag
+        else:
+            h, v = dev_decode(ctx, st, 0, eps=eps)
+            assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1]), tag
+
+
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
@@ -547,6 +582,49 @@ def test_triangulate_maps_xcd_remap_sizes(ctx, calib, H, W):
         np.testing.assert_allclose(got[sel], want[sel], rtol=XYZ_RTOL, atol=0)
     for b in (dh, dv, xyz, cnt):
         b.free()
+
+
+def test_scan_dev_fuzz_vs_oracle(ctx, calib):
+    """40 seeded random scans: N, band shape (ragged and 4-aligned), run count, projector size and calibration drawn at
+    random; maps bit-exact, validity identical, XYZ within 1e-4 (exact mode everywhere; the cancelled form away from
+    near-parallel rays), for the fused kernel and for the two-kernel path."""
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        N = int(rng.choice([14, 18, 26, 30, 42, 44, 46]))
+        L = (N - 2) // 4
+        H, W = int(rng.integers(2, 40)), int(rng.integers(8, 200))
+        if case % 2:
+            W = (W + 3) // 4 * 4                                 # fused-kernel eligible
+        R_ = int(rng.integers(1, 3))
+        st = np.stack([onp.synth_scene_int(N, H, W, seed=int(rng.integers(1 << 30)), noise=int(rng.integers(0, 8)))[0] for _ in range(R_)])
+        psize = (int(rng.integers(4, (2 << L) + 8)), int(rng.integers(4, (2 << L) + 8)))      # smaller and larger than the code range (clamp)
+        K = calib["cam_mtx"].copy()
+        f = float(rng.uniform(0.8, 2.0)) * max(W, H)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = f, f * float(rng.uniform(0.95, 1.05)), W / 2 + float(rng.uniform(-3, 3)), H / 2 + float(rng.uniform(-3, 3))
+        pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+        cd = calib["cam_dist"] * float(rng.uniform(0.0, 1.5))
+        pd = calib["proj_dist"] * float(rng.uniform(0.0, 1.5))
+        Rm, T = rot_y(float(rng.uniform(-30, -10))), np.array([[float(rng.uniform(0.15, 0.4))], [float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.05, 0.08))]])
+        ctx.set_calibration(K, cd, pk, pd, Rm, T)
+        hp, vp, ref = oc.scan_dense(st, psize, K, cd, pk, pd, Rm, T)
+        want = np.moveaxis(ref, 0, -1)
+        ok = (hp != -1) & (vp != -1)
+        stack = ctx.alloc(st.nbytes + 64).upload(st)
+        xyz, maps = ctx.alloc(H * W * 12 + 64), ctx.alloc(H * W * 4 + 64)
+        voff = (H * W * 2 + 31) // 32 * 32
+        for mode in (0, 1, 1 | 4):                               # exact (two kernels), algebraic (fused when eligible), algebraic split
+            xyz.zero()
+            maps.zero()
+            ctx.scan_dev(stack.ptr, R_, N * H * W, H * W, N, H, W, 0, psize, xyz.ptr, None, maps.at(0), maps.at(voff), mode=mode)
+            ctx.synchronize()
+            tag = f"case {case} mode {mode}: N={N} H={H} W={W} R={R_} proj={psize}"
+            assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, voff), vp), tag
+            got = xyz.download((H, W, 3), np.float32)
+            assert np.array_equal(np.isfinite(got[..., 0]), ok), tag
+            sel = ok if mode == 0 else ok & (np.abs(want).max(axis=-1) < 100.0)
+            np.testing.assert_allclose(got[sel], want[sel], rtol=XYZ_RTOL, atol=0, err_msg=tag)
+        for b in (stack, xyz, maps):
+            b.free()
 
 
 def test_scan_dev_ragged_sizes(ctx, calib):
