@@ -687,10 +687,20 @@ extern "C" int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t byte
 static int prof_mark(slgc_ctx *ctx, int phase)
 {
     if (!ctx->prof_on) return SLGC_OK;
-    if (phase == 0) ctx->prof_sampling = (ctx->prof_seen++ % ctx->prof_stride) == 0 && ctx->prof_n < ctx->prof_cap;
+    if (phase == 0) {
+        ctx->prof_sampling = (ctx->prof_seen++ % ctx->prof_stride) == 0 && ctx->prof_n < ctx->prof_cap;
+        ctx->prof_bound = false;
+        ctx->prof_cur[0] = ctx->prof_sampling ? ctx->prof_ev[2 * ctx->prof_n] : nullptr;
+        ctx->prof_cur[1] = ctx->prof_sampling ? ctx->prof_ev[2 * ctx->prof_n + 1] : nullptr;
+        return SLGC_OK;       // the launcher binds the pair to the kernel's dispatch (SLGC_LAUNCH) ...
+    }
     if (!ctx->prof_sampling) return SLGC_OK;      // not a sampled launch (stride) or ring full
-    HIP_TRY(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + phase], ctx->stream));
-    if (phase == 1) ++ctx->prof_n;
+    if (!ctx->prof_bound) {   // ... a launcher that does not know about it gets a record after the launch; its start is lost: drop the sample
+        ctx->prof_cur[0] = ctx->prof_cur[1] = nullptr;
+        return SLGC_OK;
+    }
+    ctx->prof_cur[0] = ctx->prof_cur[1] = nullptr;
+    ++ctx->prof_n;
     return SLGC_OK;
 }
 

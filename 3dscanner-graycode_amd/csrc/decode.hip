@@ -624,7 +624,7 @@ int launch_fast_t(slgc_ctx *ctx, FastArgs &a, size_t npix_main)
     a.ngroups = npix_main / PX;
     if (a.ngroups == 0) return SLGC_OK;
     const size_t blocks = (a.ngroups + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL((k_decode_fast<PX, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), 0, ctx->stream, a);
+    SLGC_LAUNCH(ctx, (k_decode_fast<PX, BLOCK>), dim3((unsigned)blocks), dim3(BLOCK), a);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -647,15 +647,15 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + BLOCK - 1) / BLOCK;
     if (abl == 1)
-        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), a);
     else if (abl == 2)
-        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), a);
     else if (abl == 3)
-        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), a);
     else if (a.g.n_runs > 1)
-        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), a);
     else
-        hipLaunchKernelGGL((k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, a);
+        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), a);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -679,13 +679,13 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const unsigned blocks = (groups + 127) / 128;
     const char *abl_env = getenv("SLGC_FUSE_ABL");
     const int fabl = abl_env ? atoi(abl_env) : 0;
-    if (fabl == 5) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
-    else if (fabl == 6) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
-    else if (fabl == 7) hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+    if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), b);
+    else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), b);
+    else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), b);
     else if (g.n_runs > 1)
-        hipLaunchKernelGGL((k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+        SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), b);
     else
-        hipLaunchKernelGGL((k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), 0, ctx->stream, b);
+        SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), b);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libslgc.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -71,6 +72,8 @@ struct slgc_ctx {
     int prof_cap, prof_n;
     int prof_stride, prof_seen;   // every prof_stride-th launch is bracketed (an event pair costs ~1.5 % of a 160 us kernel)
     bool prof_sampling;
+    hipEvent_t prof_cur[2];       // events of the launch being sampled (null otherwise): bound to the kernel's own dispatch by SLGC_LAUNCH
+    bool prof_bound;              // the launcher used them (hipExtLaunchKernelGGL) -> no hipEventRecord needed after the launch
     // communicator (comm.cpp)
     void *comm;
     int rank, nranks;
@@ -146,3 +149,17 @@ inline uint32_t xcd_chunk_for(unsigned blocks)
     static const int mode = xcd_env("SLGC_XCD", 1);
     return (mode && blocks >= 64) ? blocks / 8 : 0u;
 }
+
+// Launch on the context's stream.  When the launch is being sampled (slgc_prof_begin .. _end), the event pair is attached to the
+// kernel's own dispatch packet (hipExtLaunchKernelGGL): its elapsed time is the kernel's begin -> end, the interval rocprofv3's
+// kernel trace reports, without the command-processor time a hipEventRecord pair around the launch adds.
+#define SLGC_LAUNCH(ctx, kernel, grid, block, ...)                                                                        \
+    do {                                                                                                                  \
+        if ((ctx)->prof_cur[0]) {                                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, (ctx)->prof_cur[0], (ctx)->prof_cur[1], 0, __VA_ARGS__); \
+            (ctx)->prof_bound = true;                                                                                     \
+            (ctx)->prof_cur[0] = (ctx)->prof_cur[1] = nullptr; /* one kernel per sample: a ragged-tail launch is not timed */ \
+        } else {                                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                       \
+        }                                                                                                                 \
+    } while (0)

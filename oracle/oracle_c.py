@@ -55,6 +55,11 @@ def _d9(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
 
 
+def set_threads(n):
+    """Host threads for the per-pixel loops (default 1 = scalar).  Returns the value in effect."""
+    return int(lib().orc_set_threads(int(n)))
+
+
 def frame_ids(n):
     h = (C.c_int * 6)()
     v = (C.c_int * 6)()

@@ -25,6 +25,12 @@
 #define ORC_OK 0
 #define ORC_EINVAL (-1)
 
+/* Per-pixel loops are independent; orc_set_threads(n > 1) runs them on n host threads (OpenMP) for bench.py's all-cores CPU
+ * baseline.  Default 1: the tests use the scalar path.  Results do not depend on the thread count. */
+static int orc_threads = 1;
+int orc_set_threads(int n) { orc_threads = n < 1 ? 1 : n; return orc_threads; }
+#define ORC_PAR _Pragma("omp parallel for schedule(static) num_threads(orc_threads) if(orc_threads > 1)")
+
 static inline double px(const void *stack, int is_f64, size_t idx)
 {
     return is_f64 ? ((const double *)stack)[idx] : (double)((const uint8_t *)stack)[idx];
@@ -53,6 +59,7 @@ int orc_direct_indirect(const void *stack, int is_f64, int N, int H, int W, doub
     int hid[6], vid[6];
     if (orc_frame_ids(N, hid, vid)) return ORC_EINVAL;
     size_t plane = (size_t)H * W;
+    ORC_PAR
     for (size_t p = 0; p < plane; ++p) {
         double black = px(stack, is_f64, p), white = px(stack, is_f64, plane + p);
         double b_inv = white / (white + black);                                   /* :113 */
@@ -95,6 +102,7 @@ int orc_is_lit(const void *stack, int is_f64, int N, int H, int W, const double 
     for (int k = 0; k < L; ++k) {
         size_t hn = (size_t)(2 + 2 * k) * plane, hi = (size_t)(2 + 2 * L + 2 * k) * plane;         /* :154,157,159 */
         size_t vn = (size_t)(2 + 2 * k + 1) * plane, vi = (size_t)(2 + 2 * L + 2 * k + 1) * plane; /* :155,158,160 */
+        ORC_PAR
         for (size_t p = 0; p < plane; ++p) {
             hc[(size_t)k * plane + p] = classify(Ld[p], Lg[p], px(stack, is_f64, hn + p), px(stack, is_f64, hi + p), eps);
             vc[(size_t)k * plane + p] = classify(Ld[p], Lg[p], px(stack, is_f64, vn + p), px(stack, is_f64, vi + p), eps);
@@ -121,6 +129,7 @@ int orc_codes_to_pixels(const int8_t *hc, const int8_t *vc, int R, int L, int H,
 {
     if (R < 1 || L < 1 || L > 62) return ORC_EINVAL;
     size_t plane = (size_t)H * W, run = (size_t)L * plane;
+    ORC_PAR
     for (size_t p = 0; p < plane; ++p) {
         int64_t gh = 0, gv = 0;
         int bad_h = 0, bad_v = 0;
@@ -199,6 +208,7 @@ int orc_undistort(const float *pts, int64_t M, const double K[9], const double *
     double RR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (R) memcpy(RR, R, sizeof RR);
     double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
+    ORC_PAR
     for (int64_t q = 0; q < M; ++q) {
         double u = pts[2 * q], v = pts[2 * q + 1];
         double x = (u - cx) * ifx, y = (v - cy) * ify, x0 = x, y0 = y;
@@ -230,6 +240,7 @@ int orc_undistort(const float *pts, int64_t M, const double K[9], const double *
 int orc_law_of_sines(const float *cam_n, const float *proj_n, int64_t M, const double T[3], double *xyz)
 {
     double t_len = sqrt(T[0] * T[0] + T[1] * T[1] + T[2] * T[2]);                /* :89 */
+    ORC_PAR
     for (int64_t q = 0; q < M; ++q) {
         float cx = cam_n[2 * q], cy = cam_n[2 * q + 1], cz = 1.0f;
         float cn = sqrtf((cx * cx + cy * cy) + cz * cz);
@@ -292,6 +303,7 @@ int orc_scan_dense(const void *stack, int is_f64, int R, int N, int H, int W, do
     size_t plane = (size_t)H * W;
     float *cam = malloc(plane * 2 * sizeof(float)), *proj = malloc(plane * 2 * sizeof(float));
     if (!cam || !proj) { free(cam); free(proj); return ORC_EINVAL; }
+    ORC_PAR
     for (size_t p = 0; p < plane; ++p) {
         int64_t hv = hp[p], vv = vp[p];
         cam[2 * p] = (float)(p % W);
@@ -300,8 +312,11 @@ int orc_scan_dense(const void *stack, int is_f64, int R, int N, int H, int W, do
         proj[2 * p + 1] = (float)(vv < 0 ? 0 : (vv < proj_h - 1 ? vv : proj_h - 1));
     }
     rc = orc_triangulate(cam, proj, (int64_t)plane, camK, cam_dist, n_cam_dist, projK, proj_dist, n_proj_dist, Rm, T, xyz);
-    for (size_t p = 0; p < plane && !rc; ++p)
-        if (hp[p] == -1 || vp[p] == -1) xyz[p] = xyz[plane + p] = xyz[2 * plane + p] = NAN;
+    if (!rc) {
+        ORC_PAR
+        for (size_t p = 0; p < plane; ++p)
+            if (hp[p] == -1 || vp[p] == -1) xyz[p] = xyz[plane + p] = xyz[2 * plane + p] = NAN;
+    }
     free(cam); free(proj);
     return rc;
 }
