@@ -85,19 +85,23 @@ def cpu_baseline(N, crop_w, crop_h, calib, proj_size):
     oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)
     dt_c = time.perf_counter() - t1
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    oc.set_threads(cores)
-    oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)                  # thread pool start-up
-    t2 = time.perf_counter()
-    oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)
-    dt_mt = time.perf_counter() - t2
+    dt_mt, used = None, 1
+    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
+        oc.set_threads(n)
+        oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)              # thread pool start-up
+        t2 = time.perf_counter()
+        oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)
+        d = time.perf_counter() - t2
+        if dt_mt is None or d < dt_mt:
+            dt_mt, used = d, n
     oc.set_threads(1)
     return {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
             "sample": f"{crop_w}x{crop_h}x{N} crop of the same synthetic scene, decode+triangulate, {dt:.1f} s, "
                       f"{pts.shape[1]} points; NumPy/Python port of the reference path (oracle/oracle_np.py), 1 thread; "
                       f"host has {os.cpu_count()} cores",
             "c_oracle_value": round(mpix / dt_c, 3), "c_oracle_note": "plain-C scalar oracle, 1 thread, same crop",
-            "c_oracle_all_cores_value": round(mpix / dt_mt, 3), "c_oracle_all_cores": cores,
-            "c_oracle_all_cores_note": "the same C oracle with its per-pixel loops on every host core (OpenMP), same crop"}
+            "c_oracle_all_cores_value": round(mpix / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
+            "c_oracle_all_cores_note": "the same C oracle with its per-pixel loops on host threads (OpenMP), best of 8/16/32/64/128/all visible cores, same crop"}
 
 
 def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
