@@ -2,9 +2,8 @@
 //
 // The reference is single-process; this exchange exists only because the build shards a
 // scan by image rows across the GPUs of one node.  One context = one rank = one GPU.  RCCL is loaded lazily with
-// dlopen so single-GPU users never pay for it.  RCCL has no all-gatherv: it is a grouped ncclBroadcast, one per
-// contributing rank, which on xGMI's point-to-point links lets every rank push its shard to all peers at once
-// instead of walking a ring.
+// dlopen so single-GPU users never pay for it.  RCCL has no all-gatherv: equal shards laid out back to back take
+// ncclAllGather, ragged ones a grouped ncclBroadcast (one per contributing rank).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -168,6 +167,16 @@ extern "C" int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, voi
     for (int r = 0; r < ctx->nranks; ++r)
         if (counts[r] < 0 || displs[r] < 0) return slgc_fail(ctx, SLGC_EINVAL, "negative count/displacement");
     if ((rc = comm_after_compute(ctx))) return rc;
+    // Equal shards laid out back to back (the row-band plan when H % nranks == 0): RCCL's native all-gather, in place when the
+    // caller's shard already sits in its slot.
+    bool uniform = counts[0] > 0;
+    for (int r = 0; r < ctx->nranks && uniform; ++r) uniform = counts[r] == counts[0] && displs[r] == (int64_t)r * counts[0];
+    if (uniform) {
+        if (!d_send) return slgc_fail(ctx, SLGC_EINVAL, "null send buffer");
+        NCCL_TRY(ctx, rccl().AllGather(d_send, d_recv, (size_t)counts[0], ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done[slot], ctx->comm_stream));
+        return SLGC_OK;
+    }
     NCCL_TRY(ctx, rccl().GroupStart());
     for (int r = 0; r < ctx->nranks; ++r) {
         if (counts[r] == 0) continue;  // same decision on every rank (counts are global)

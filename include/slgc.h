@@ -194,7 +194,9 @@ int slgc_comm_barrier(slgc_ctx *ctx);                                          /
 int slgc_comm_allreduce_max_f64(slgc_ctx *ctx, double *value);                 /* in place, host scalar */
 int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all);        /* all: host int64[nranks] */
 /* all-gatherv of byte records: rank r contributes counts[r] bytes from d_send; every rank receives all of them at
- * d_recv + displs[r].  Grouped ncclBroadcast (RCCL has no native all-gatherv). */
+ * d_recv + displs[r].  Equal counts laid out back to back (displs[r] = r*count) run as ncclAllGather (in place when
+ * d_send = d_recv + displs[rank]); anything else as one grouped ncclBroadcast per contributing rank (RCCL has no
+ * native all-gatherv). */
 int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs);
 /* Split form for overlap: collectives run on the context's own communication stream, ordered after everything enqueued on
  * the compute stream at the time of the call.  _begin enqueues the all-gatherv and returns; kernels enqueued afterwards overlap

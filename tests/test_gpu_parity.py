@@ -417,7 +417,15 @@ def test_rccl_single_rank(ctx):
         assert ctx.comm_allgather_i64(42) == [42]
         src = ctx.alloc(1000).upload(np.arange(1000, dtype=np.uint8))
         dst = ctx.alloc(1000).zero()
-        ctx.comm_allgatherv(src.ptr, dst.ptr, [1000], [0])
+        ctx.comm_allgatherv(src.ptr, dst.ptr, [1000], [0])                     # equal shards back to back: ncclAllGather
+        ctx.synchronize()
+        assert np.array_equal(dst.download((1000,), np.uint8), np.arange(1000, dtype=np.uint8))
+        dst2 = ctx.alloc(1200).zero()
+        ctx.comm_allgatherv(src.ptr, dst2.ptr, [1000], [64])                   # any other layout: grouped ncclBroadcast
+        ctx.synchronize()
+        got = dst2.download((1200,), np.uint8)
+        assert np.array_equal(got[64:1064], np.arange(1000, dtype=np.uint8)) and not got[:64].any() and not got[1064:].any()
+        ctx.comm_allgatherv(dst.ptr, dst.ptr, [1000], [0])                     # in place
         ctx.synchronize()
         assert np.array_equal(dst.download((1000,), np.uint8), np.arange(1000, dtype=np.uint8))
     finally:
