@@ -235,6 +235,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     const float2 *proj_lut;   // 8x8-tiled projector rays
     float *xyz;               // [npix][3]
     int proj_w, proj_h, tiles_x;
+    int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     double T[3], t_len;
 };
 
@@ -424,8 +425,13 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
     }
     if constexpr (NW == 1) {
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
+        if (FUSE && (a.f.nt_store & 2)) {          // fused scan: the maps are a product, nothing re-reads them
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 2);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 0);
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < NW; q += 2) {
@@ -487,7 +493,15 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
         for (int it = 0; it < 3; ++it)
-            if ((uint32_t)(it * BLOCK + tid) < nvec && (ABL != 5 || s_buf[it * BLOCK + tid].x == 12345.678f)) dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
+            if ((uint32_t)(it * BLOCK + tid) < nvec && (ABL != 5 || s_buf[it * BLOCK + tid].x == 12345.678f)) {
+                if (a.f.nt_store & 1) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const float4 q = s_buf[it * BLOCK + tid];
+                    __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f *>(dst) + it * BLOCK + tid);
+                } else {
+                    dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
+                }
+            }
     }
 }
 
@@ -672,6 +686,8 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
     b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = (proj_w + 7) / 8;
+    static const int fuse_nt = xcd_env("SLGC_FUSE_NT", 3);
+    b.f.nt_store = fuse_nt;
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

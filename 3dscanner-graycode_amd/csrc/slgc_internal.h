@@ -139,6 +139,7 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t chunk)
 {
     return (chunk != 0u && bid < chunk * 8u) ? (bid & 7u) * chunk + (bid >> 3) : bid;
 }
+// Integer environment knob (A/B switches: SLGC_XCD, SLGC_TRI_NT, SLGC_FUSE_NT).
 inline int xcd_env(const char *name, int dflt)
 {
     const char *e = getenv(name);

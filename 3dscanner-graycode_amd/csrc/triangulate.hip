@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
                                                               const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
-                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk)
+                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store)
 {
     __shared__ uint4 s_idx[256];
     __shared__ float4 s_buf[768];
@@ -269,7 +269,15 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     float4 *dst = reinterpret_cast<float4 *>(xyz) + first * 3;
 #pragma unroll
     for (int it = 0; it < 3; ++it)
-        if ((size_t)(it * 256 + tid) < nvec) dst[it * 256 + tid] = s_buf[it * 256 + tid];
+        if ((size_t)(it * 256 + tid) < nvec) {
+            if (nt_store) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const float4 q = s_buf[it * 256 + tid];
+                __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f *>(dst) + it * 256 + tid);
+            } else {
+                dst[it * 256 + tid] = s_buf[it * 256 + tid];
+            }
+        }
     if (count) block_count_add(count, nvalid);
 }
 
@@ -356,12 +364,13 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         tc.t_len = ctx->calib.t_len;
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
+        static const int tri_nt = xcd_env("SLGC_TRI_NT", 1);     // XYZ leaves with non-temporal stores (A/B: SLGC_TRI_NT=0)
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks));
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks));
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;
