@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
     }
     if constexpr (NW == 1) {
-        if (FUSE && (a.f.nt_store & 2)) {          // fused scan: the maps are a product, nothing re-reads them
+        if (a.f.nt_store & 2) {          // fused scan only: the maps are a product there, nothing re-reads them (the two-kernel path keeps them cacheable for K3)
             __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 2);
             __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 2);
         } else {
