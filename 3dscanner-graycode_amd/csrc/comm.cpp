@@ -159,38 +159,59 @@ extern "C" int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all
     return SLGC_OK;
 }
 
-extern "C" int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot)
+// One or two buffers with the same shard layout, one RCCL group (one launch): the map exchange sends h and v together.
+static int allgatherv_enqueue(slgc_ctx *ctx, int nbuf, const void *const *d_send, void *const *d_recv, const int64_t *counts,
+                              const int64_t *displs, int slot)
 {
     int rc = need_comm(ctx);
     if (rc) return rc;
-    if (!d_recv || !counts || !displs || slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "null argument / slot outside 0..3");
+    if (!counts || !displs || slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "null argument / slot outside 0..3");
+    for (int b = 0; b < nbuf; ++b)
+        if (!d_recv[b]) return slgc_fail(ctx, SLGC_EINVAL, "null receive buffer");
     for (int r = 0; r < ctx->nranks; ++r)
         if (counts[r] < 0 || displs[r] < 0) return slgc_fail(ctx, SLGC_EINVAL, "negative count/displacement");
-    if ((rc = comm_after_compute(ctx))) return rc;
     // Equal shards laid out back to back (the row-band plan when H % nranks == 0): RCCL's native all-gather, in place when the
-    // caller's shard already sits in its slot.
+    // caller's shard already sits in its slot.  Anything else: one broadcast per contributing rank.
     bool uniform = counts[0] > 0;
     for (int r = 0; r < ctx->nranks && uniform; ++r) uniform = counts[r] == counts[0] && displs[r] == (int64_t)r * counts[0];
-    if (uniform) {
-        if (!d_send) return slgc_fail(ctx, SLGC_EINVAL, "null send buffer");
-        NCCL_TRY(ctx, rccl().AllGather(d_send, d_recv, (size_t)counts[0], ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done[slot], ctx->comm_stream));
-        return SLGC_OK;
-    }
+    if (uniform)
+        for (int b = 0; b < nbuf; ++b)
+            if (!d_send[b]) return slgc_fail(ctx, SLGC_EINVAL, "null send buffer");
+    if ((rc = comm_after_compute(ctx))) return rc;
     NCCL_TRY(ctx, rccl().GroupStart());
-    for (int r = 0; r < ctx->nranks; ++r) {
-        if (counts[r] == 0) continue;  // same decision on every rank (counts are global)
-        char *dst = (char *)d_recv + displs[r];
-        const void *src = (r == ctx->rank) ? d_send : dst;
-        ncclResult_t e = rccl().Broadcast(src, dst, (size_t)counts[r], ncclUint8, r, (ncclComm_t)ctx->comm, ctx->comm_stream);
-        if (e != ncclSuccess) {
-            rccl().GroupEnd();
-            return slgc_fail(ctx, SLGC_ECOMM, "ncclBroadcast(root %d): %s", r, rccl().GetErrorString(e));
+    ncclResult_t e = ncclSuccess;
+    for (int b = 0; b < nbuf && e == ncclSuccess; ++b) {
+        if (uniform) {
+            e = rccl().AllGather(d_send[b], d_recv[b], (size_t)counts[0], ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream);
+            continue;
         }
+        for (int r = 0; r < ctx->nranks && e == ncclSuccess; ++r) {
+            if (counts[r] == 0) continue;  // same decision on every rank (counts are global)
+            char *dst = (char *)d_recv[b] + displs[r];
+            const void *src = (r == ctx->rank) ? d_send[b] : dst;
+            e = rccl().Broadcast(src, dst, (size_t)counts[r], ncclUint8, r, (ncclComm_t)ctx->comm, ctx->comm_stream);
+        }
+    }
+    if (e != ncclSuccess) {
+        rccl().GroupEnd();
+        return slgc_fail(ctx, SLGC_ECOMM, "all-gatherv enqueue: %s", rccl().GetErrorString(e));
     }
     NCCL_TRY(ctx, rccl().GroupEnd());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_comm_done[slot], ctx->comm_stream));
     return SLGC_OK;
+}
+
+extern "C" int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot)
+{
+    return allgatherv_enqueue(ctx, 1, &d_send, &d_recv, counts, displs, slot);
+}
+
+extern "C" int slgc_comm_allgatherv_pair_begin(slgc_ctx *ctx, const void *d_send_a, void *d_recv_a, const void *d_send_b, void *d_recv_b,
+                                               const int64_t *counts, const int64_t *displs, int slot)
+{
+    const void *send[2] = {d_send_a, d_send_b};
+    void *recv[2] = {d_recv_a, d_recv_b};
+    return allgatherv_enqueue(ctx, 2, send, recv, counts, displs, slot);
 }
 
 extern "C" int slgc_comm_wait(slgc_ctx *ctx, int slot)
@@ -238,8 +259,7 @@ extern "C" int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack,
     }
     int16_t *my_h = d_h_full + (size_t)row0 * W, *my_v = d_v_full + (size_t)row0 * W;
     if (rows > 0 && (rc = slgc_decode_dev(ctx, d_band_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, m, my_h, my_v, 0))) return rc;
-    if ((rc = slgc_comm_allgatherv_begin(ctx, my_h, d_h_full, counts, displs, 2))) return rc;
-    if ((rc = slgc_comm_allgatherv_begin(ctx, my_v, d_v_full, counts, displs, 3))) return rc;
-    if ((rc = slgc_comm_wait(ctx, 2)) || (rc = slgc_comm_wait(ctx, 3))) return rc;
+    if ((rc = slgc_comm_allgatherv_pair_begin(ctx, my_h, d_h_full, my_v, d_v_full, counts, displs, 3))) return rc;
+    if ((rc = slgc_comm_wait(ctx, 3))) return rc;
     return slgc_triangulate_maps_dev(ctx, d_h_full, d_v_full, H, W, 0, proj_w, proj_h, mode & 3, d_xyz_full, nullptr);
 }

@@ -77,6 +77,7 @@ SIGNATURES = {
     "slgc_comm_allgather_i64": (_i, [_vp, _i64, C.POINTER(_i64)]),
     "slgc_comm_allgatherv": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "slgc_comm_allgatherv_begin": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
+    "slgc_comm_allgatherv_pair_begin": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_wait": (_i, [_vp, _i]),
     "slgc_shard_band": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "slgc_scan_sharded_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
@@ -471,6 +472,12 @@ class Context:
         c = (C.c_int64 * n)(*[int(x) for x in counts])
         d = (C.c_int64 * n)(*[int(x) for x in displs])
         self._ck(lib().slgc_comm_allgatherv_begin(self._h, d_send, d_recv, c, d, int(slot)))
+
+    def comm_allgatherv_pair_begin(self, d_send_a: int, d_recv_a: int, d_send_b: int, d_recv_b: int, counts, displs, slot: int):
+        n = self.nranks
+        c = (C.c_int64 * n)(*[int(x) for x in counts])
+        d = (C.c_int64 * n)(*[int(x) for x in displs])
+        self._ck(lib().slgc_comm_allgatherv_pair_begin(self._h, d_send_a, d_recv_a, d_send_b, d_recv_b, c, d, int(slot)))
 
     def comm_wait(self, slot: int):
         self._ck(lib().slgc_comm_wait(self._h, int(slot)))

@@ -141,6 +141,11 @@ class RcclExchange:
         """Enqueue on the communication stream (after the compute stream's work so far) and return; see wait()."""
         self.ctx.comm_allgatherv_begin(self._ptr(d_send), self._ptr(d_recv), byte_counts, byte_displs, slot)
 
+    def allgatherv_pair_begin(self, d_send_a, d_recv_a, d_send_b, d_recv_b, byte_counts, byte_displs, slot: int):
+        """Two buffers with one shard layout (the h and v maps) in one RCCL group."""
+        self.ctx.comm_allgatherv_pair_begin(self._ptr(d_send_a), self._ptr(d_recv_a), self._ptr(d_send_b), self._ptr(d_recv_b),
+                                            byte_counts, byte_displs, slot)
+
     def wait(self, slot: int):
         """Make the compute stream wait for the exchange started in ``slot``."""
         self.ctx.comm_wait(slot)
@@ -161,6 +166,11 @@ def exchange_map_bands(exchange, plan: ShardPlan, h_full, v_full, band_view):
     afterwards both maps are complete everywhere.  ``band_view(buf, byte_offset)`` addresses a buffer of the exchange's
     kind (device pointer arithmetic for RCCL, a NumPy view for the gloo test double)."""
     counts, displs = map_band_layout(plan)
+    if hasattr(exchange, "allgatherv_pair_begin"):                 # both maps in one RCCL group
+        exchange.allgatherv_pair_begin(band_view(h_full, displs[exchange.rank]), h_full, band_view(v_full, displs[exchange.rank]), v_full,
+                                       counts, displs, 3)
+        exchange.wait(3)
+        return
     for full in (h_full, v_full):
         exchange.allgatherv(band_view(full, displs[exchange.rank]), full, counts, displs)
 
@@ -187,6 +197,7 @@ class ShardedScanner:
             self.xyz_full = ctx.alloc(max(16, full_px * 12))
             self._submitted = 0
             self._pending = None
+            self._pair = False
         else:
             self.maps = ctx.alloc(max(16, band_px * 4))
             self.xyz = ctx.alloc(max(16, band_px * 12))
@@ -217,8 +228,13 @@ class ShardedScanner:
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      h_full.at(off), v_full.at(off), eps=eps)
         counts, displs = map_band_layout(self.plan)
-        self.exchange.allgatherv_begin(h_full.at(displs[self.rank]), h_full, counts, displs, 2 * s)
-        self.exchange.allgatherv_begin(v_full.at(displs[self.rank]), v_full, counts, displs, 2 * s + 1)
+        if hasattr(self.exchange, "allgatherv_pair_begin"):           # one RCCL group for both maps
+            self.exchange.allgatherv_pair_begin(h_full.at(displs[self.rank]), h_full, v_full.at(displs[self.rank]), v_full, counts, displs, 2 * s)
+            self._pair = True
+        else:
+            self.exchange.allgatherv_begin(h_full.at(displs[self.rank]), h_full, counts, displs, 2 * s)
+            self.exchange.allgatherv_begin(v_full.at(displs[self.rank]), v_full, counts, displs, 2 * s + 1)
+            self._pair = False
         if self._pending is not None:
             self._finish(self._pending)
         self._pending = s
@@ -227,7 +243,8 @@ class ShardedScanner:
     def _finish(self, s: int):
         h_full, v_full = self._sets[s]
         self.exchange.wait(2 * s)
-        self.exchange.wait(2 * s + 1)
+        if not self._pair:
+            self.exchange.wait(2 * s + 1)
         self.ctx.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, self.plan.W, 0, self.proj_size, self.xyz_full.ptr, None,
                                       mode=self.mode & 3)
         self.h_full, self.v_full = h_full, v_full

@@ -202,6 +202,9 @@ int slgc_comm_allgatherv(slgc_ctx *ctx, const void *d_send, void *d_recv, const 
  * the compute stream at the time of the call.  _begin enqueues the all-gatherv and returns; kernels enqueued afterwards overlap
  * with it; slgc_comm_wait(slot) makes the compute stream wait for the exchange started in that slot (0..3). */
 int slgc_comm_allgatherv_begin(slgc_ctx *ctx, const void *d_send, void *d_recv, const int64_t *counts, const int64_t *displs, int slot);
+/* The same for two buffers that share one shard layout (the h and v maps), enqueued as one RCCL group. */
+int slgc_comm_allgatherv_pair_begin(slgc_ctx *ctx, const void *d_send_a, void *d_recv_a, const void *d_send_b, void *d_recv_b,
+                                    const int64_t *counts, const int64_t *displs, int slot);
 int slgc_comm_wait(slgc_ctx *ctx, int slot);
 
 /* Row-band plan of the sharded scan: contiguous bands, the first H % nranks ranks get one extra

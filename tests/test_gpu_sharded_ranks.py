@@ -60,6 +60,10 @@ class StagedGlooExchange:
     def allgatherv_begin(self, d_send, d_recv, byte_counts, byte_displs, slot):
         self.allgatherv(d_send, d_recv, byte_counts, byte_displs)       # host-staged double: complete on return
 
+    def allgatherv_pair_begin(self, d_send_a, d_recv_a, d_send_b, d_recv_b, byte_counts, byte_displs, slot):
+        self.allgatherv(d_send_a, d_recv_a, byte_counts, byte_displs)   # RcclExchange sends both maps in one group
+        self.allgatherv(d_send_b, d_recv_b, byte_counts, byte_displs)
+
     def wait(self, slot):
         pass
 

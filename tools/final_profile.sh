@@ -12,4 +12,21 @@ grep '^{' "$out/bench_default.log" | tail -1 > "$out/bench_default.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py > "$out/bench_under_rocprof.log" 2>&1
 bash tools/pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 tail -3 "$out/pmc.log"
+# other configurations and the sharded path at nranks = 1
+for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
+  python3 bench.py --workload $w --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > "$out/bench_$w.json"
+done
+python3 bench.py --force-sharded --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
+python3 bench.py --force-sharded --exchange records --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
+python3 - <<PY
+import json, glob, os
+for f in sorted(glob.glob("$out/bench_*.json")):
+    try:
+        j = json.load(open(f))
+    except Exception as e:
+        print(os.path.basename(f), "unreadable", e); continue
+    sp = j.get("split_pipeline", {})
+    print(os.path.basename(f), "value", j["value"], "ms/step", j["ms_per_step"], "frac", j["roofline"]["frac"], "| split", sp.get("value"), sp.get("roofline", {}).get("frac"),
+          "| alone", j.get("decode_kernel_alone", {}).get("roofline", {}).get("frac"), "| thr", j.get("throughput_mode", {}).get("value"))
+PY
 ls "$out" "$out/kt"/* | head -20
