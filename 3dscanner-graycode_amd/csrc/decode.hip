@@ -270,7 +270,7 @@ template <int NW, int NT>
 __device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
 {
     Frame<NW, NT> f;
-    constexpr int aux = NT ? 2 : 0;
+    constexpr int aux = NT ? 2 : 0;      // nt (scope bits on top of it measured within noise)
     if constexpr (NW == 1) {
         f.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux);
     } else if constexpr (NW == 2) {
