@@ -191,7 +191,7 @@ def test_decode_fuzz_vs_oracle(ctx):
     """400 seeded random cases over N (14..62), image shape (ragged widths, single rows), run count, eps and five value
     distributions built to sit on the rule table's boundaries: device-resident kernels and the host API, bit-exact vs the oracle."""
     rng = np.random.default_rng(2024)
-    for case in range(400):
+    for case in range(400 * int(os.environ.get("SLGC_FUZZ_SCALE", "1"))):      # soak: SLGC_FUZZ_SCALE=50 -> 20 000 cases
         N = int(rng.integers(14, 63))
         H, W = int(rng.integers(1, 24)), int(rng.integers(1, 140))
         R = int(rng.integers(1, 4))
@@ -597,7 +597,8 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
     random; maps bit-exact, validity identical, XYZ within 1e-4 (exact mode everywhere; the cancelled form away from
     near-parallel rays), for the fused kernel and for the two-kernel path."""
     rng = np.random.default_rng(77)
-    for case in range(40):
+    worst = [0.0]
+    for case in range(40 * int(os.environ.get("SLGC_FUZZ_SCALE", "1"))):
         N = int(rng.choice([14, 18, 26, 30, 42, 44, 46]))
         L = (N - 2) // 4
         H, W = int(rng.integers(2, 40)), int(rng.integers(8, 200))
@@ -629,10 +630,18 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
             assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, voff), vp), tag
             got = xyz.download((H, W, 3), np.float32)
             assert np.array_equal(np.isfinite(got[..., 0]), ok), tag
-            sel = ok if mode == 0 else ok & (np.abs(want).max(axis=-1) < 100.0)
-            np.testing.assert_allclose(got[sel], want[sel], rtol=XYZ_RTOL, atol=0, err_msg=tag)
+            if mode == 0:                                        # exact mode mirrors the reference's rounding: elementwise
+                np.testing.assert_allclose(got[ok], want[ok], rtol=XYZ_RTOL, atol=0, err_msg=tag)
+            else:                                                # cancelled form: relative to the point (a component near 0 has no relative scale)
+                rng_ = np.linalg.norm(np.where(ok[..., None], want, 1.0), axis=-1) / float(np.linalg.norm(T))
+                sel = ok & (rng_ > 0.1) & (rng_ < 100.0)         # 0.1 .. 100 baselines: outside, the reference's own acos chain is noise
+                if sel.any():
+                    err = np.linalg.norm(got[sel].astype(np.float64) - want[sel], axis=-1) / np.linalg.norm(want[sel], axis=-1)
+                    assert err.max() <= XYZ_RTOL, f"{tag}: {err.max():.3e}"
+                    worst[0] = max(worst[0], float(err.max()))
         for b in (stack, xyz, maps):
             b.free()
+    print(f"cancelled form, worst |dP|/|P| over the fuzz scans: {worst[0]:.3e}")
 
 
 def test_scan_dev_ragged_sizes(ctx, calib):
