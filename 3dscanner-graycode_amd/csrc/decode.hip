@@ -305,8 +305,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
-    const uint32_t bid = blockIdx.x;
-    const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
+    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
     const uint32_t ps = a.plane_stride;
     const int L = a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
@@ -475,20 +474,14 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         __syncthreads();
         const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
         float out[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float X = __builtin_nanf(""), Y = X, Z = X;
-            if (idx[j] != 0xffffffffu) {
-                const Xyzf r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, a.f.T, a.f.t_len);
-                X = r.x; Y = r.y; Z = r.z;
-            }
-            out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
-        }
+        const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
+                               (idx[3] != 0xffffffffu ? 8u : 0u);
+        triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
         s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
         __syncthreads();
-        const uint32_t first = bid * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
+        const uint32_t first = blockIdx.x * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
         const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)BLOCK ? ngroups - first : (uint32_t)BLOCK) * 3u) : 0u;
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
@@ -698,6 +691,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), b);
     else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), b);
     else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), b);
+    else if (fabl == 8) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 8, true>), dim3(blocks), dim3(128), b);
     else if (g.n_runs > 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), b);
     else

@@ -34,22 +34,86 @@ __device__ __forceinline__ double fast_sqrt(double x)
 //   A = -T.c, B = T.p, Sa = sqrt(|T|^2 |c|^2 - A^2) = |T||c| sin(alpha), Sb likewise for beta,
 //   sin(gamma) = sin(alpha + beta)   =>   Pts = c * |T|^2 * Sb / (Sa*B + A*Sb).
 // The dot products, the two differences under the roots and the denominator (where cancellation can occur) are fp64; the
-// final scale is rounded to float32 once and applied in float32.  Agrees with the acos/sin form to ~2e-7 relative (float32
-// output resolution) away from degenerate geometry, far inside the 1e-4 tolerance of the build's north star.
+// final scale is rounded to float32 once and applied in float32 (triangulate4 below).  Agrees with the acos/sin form to ~2e-7
+// relative (float32 output resolution) away from degenerate geometry; near it, see law_of_sines_mirror.
 struct Xyzf {
     float x, y, z;
 };
 
-__device__ __forceinline__ Xyzf law_of_sines_fast(Ray2 cam, Ray2 prj, const double (&T)[3], double t_len)
+// Same cancelled form, but on the reference's own float32 intermediates (triangulate.py:90 NormedL and the float32 norm inside
+// :92 are float32 in NumPy): cos(alpha) and cos(beta) are then the reference's values bit for bit, and only arccos/sin are
+// replaced by sin = sqrt(1 - cos^2), sin(gamma) = sin(alpha + beta).  Tracks the reference to ~1e-9 even where its float32
+// rounding dominates the answer (rays nearly parallel to each other or to the baseline).
+__device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const double (&T)[3], double t_len)
 {
-    const double cx = cam.x, cy = cam.y, px = prj.x, py = prj.y;
+    // plain operators: correctly rounded under -fno-fast-math -ffp-contract=off (the __f*_rn intrinsics map to native approximations)
+    const float cn = sqrtf((cam.x * cam.x + cam.y * cam.y) + 1.0f);       // np.linalg.norm of float32 (:90)
+    const float rx = cam.x / cn, ry = cam.y / cn, rz = 1.0f / cn;         // NormedL (float32)
+    const float qn = sqrtf((prj.x * prj.x + prj.y * prj.y) + 1.0f);       // norm inside :92 (float32)
+    const double it = fast_rcp(t_len);
+    const double cos_a = (((-T[0]) * (double)rx + (-T[1]) * (double)ry) + (-T[2]) * (double)rz) * it;
+    const double cos_b = ((T[0] * (double)prj.x + T[1] * (double)prj.y) + T[2]) * fast_rcp(t_len * (double)qn);
+    const double sin_a = fast_sqrt(fma(-cos_a, cos_a, 1.0)), sin_b = fast_sqrt(fma(-cos_b, cos_b, 1.0));
+    const double len = t_len * sin_b * fast_rcp(fma(sin_a, cos_b, cos_a * sin_b));
+    return Xyzf{(float)((double)rx * len), (float)((double)ry * len), (float)((double)rz * len)};
+}
+
+// Shipped evaluation for a lane's four pixels: the fast form, except where the triangle is so flat (rays nearly parallel to
+// each other or to the baseline) that the reference's float32 NormedL / norm roundings, amplified by the cotangents of its
+// angles, move ITS answer by an amount that matters against the 1e-4 tolerance (criterion below).  Those pixels are
+// redone with the mirrored form -- in ONE not-unrolled loop behind a lane-level "any of my four" test, so the common path pays
+// for the two comparisons only and the instruction stream holds a single copy of the float32 divide / sqrt expansions.
+// valid: bit j set = pixel j decodable; out = x0 y0 z0 x1 ... (NaN where not decodable).  GUARD = false: fast form everywhere.
+// cam4 / proj_lut + idx: where the lane's rays came from -- the rare path reads them again instead of keeping 16 registers alive.
+template <bool GUARD>
+__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+                                             uint32_t valid, const double (&T)[3], double t_len, float (&out)[12],
+                                             const float2 *__restrict__ cam4, const float2 *__restrict__ proj_lut, const uint32_t (&idx)[4])
+{
     const double tl2 = t_len * t_len;
-    const double A = -fma(T[0], cx, fma(T[1], cy, T[2]));
-    const double B = fma(T[0], px, fma(T[1], py, T[2]));
-    const double cn2 = fma(cx, cx, fma(cy, cy, 1.0)), pn2 = fma(px, px, fma(py, py, 1.0));
-    const double Sa = fast_sqrt(fma(tl2, cn2, -A * A)), Sb = fast_sqrt(fma(tl2, pn2, -B * B));
-    const float s = (float)(tl2 * Sb * fast_rcp(fma(Sa, B, A * Sb)));
-    return Xyzf{cam.x * s, cam.y * s, s};
+    uint32_t ill = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double dcx = cx[j], dcy = cy[j], dpx = px[j], dpy = py[j];
+        const double A = -fma(T[0], dcx, fma(T[1], dcy, T[2]));
+        const double B = fma(T[0], dpx, fma(T[1], dpy, T[2]));
+        const double ta = tl2 * fma(dcx, dcx, fma(dcy, dcy, 1.0)), tb = tl2 * fma(dpx, dpx, fma(dpy, dpy, 1.0));
+        const double ra = fma(-A, A, ta), rb = fma(-B, B, tb);
+        const double Sa = fast_sqrt(ra), Sb = fast_sqrt(rb);
+        const double D = fma(Sa, B, A * Sb);
+        const float s = (float)(tl2 * Sb * fast_rcp(D));
+        if (GUARD) {
+            // |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], eps = 2^-24 (the float32 steps):
+            // redo the pixel when either term can pass 400 (bound 2.4e-5 per term, tolerance 1e-4).
+            //   sin^2(beta) < 2.5e-3          <=>  rb < k1 * tb
+            //   min(sin a, sin b)^2 * sin^2(gamma) < 2.5e-5   <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
+            constexpr double k1 = 2.5e-3, k2 = 2.5e-5;
+            const double tatb = ta * tb;
+            const bool bad = (rb < k1 * tb) | ((D * D) * fmin(ra * tb, rb * ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
+            ill |= bad ? (1u << j) : 0u;
+        }
+        const bool ok = (valid >> j) & 1u;
+        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
+        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
+        out[3 * j + 2] = ok ? s : __builtin_nanf("");
+    }
+    if (GUARD) {
+        ill &= valid;
+        if (ill) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                if (!((ill >> j) & 1u)) continue;
+                const float2 cr = cam4[j], pr = proj_lut[j == 0 ? idx[0] : j == 1 ? idx[1] : j == 2 ? idx[2] : idx[3]];
+                const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, T, t_len);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    out[3 * k] = (k == j) ? r.x : out[3 * k];
+                    out[3 * k + 1] = (k == j) ? r.y : out[3 * k + 1];
+                    out[3 * k + 2] = (k == j) ? r.z : out[3 * k + 2];
+                }
+            }
+        }
+    }
 }
 
 // The projector table is stored in 8x8-pixel tiles (512 B) so that a wave's gather stays within a few cache lines

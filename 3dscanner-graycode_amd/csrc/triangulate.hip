@@ -244,21 +244,21 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     __syncthreads();
     const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
     float out[12];
-    unsigned nvalid = 0;
+    const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
+                           (idx[3] != 0xffffffffu ? 8u : 0u);
+    const unsigned nvalid = __builtin_popcount(valid);
+    if constexpr (MODE == SLGC_TRI_EXACT) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float X = __builtin_nanf(""), Y = X, Z = X;
-        if (idx[j] != 0xffffffffu) {
-            if constexpr (MODE == SLGC_TRI_EXACT) {
+        for (int j = 0; j < 4; ++j) {
+            float X = __builtin_nanf(""), Y = X, Z = X;
+            if ((valid >> j) & 1u) {
                 const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
                 X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
-            } else {
-                const Xyzf r = law_of_sines_fast(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
-                X = r.x; Y = r.y; Z = r.z;
             }
-            ++nvalid;
+            out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
-        out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
+    } else {
+        triangulate4<MODE != 2>(cx, cy, px, py, valid, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);      // MODE 2: unguarded fast form (A/B)
     }
     s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
     s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
 #pragma unroll
     for (int it = 0; it < 3; ++it)
         if ((size_t)(it * 256 + tid) < nvec) {
-            if (nt_store) {
+            if (nt_store & 1) {
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const float4 q = s_buf[it * 256 + tid];
                 __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f *>(dst) + it * 256 + tid);
@@ -367,6 +367,9 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         static const int tri_nt = xcd_env("SLGC_TRI_NT", 1);     // XYZ leaves with non-temporal stores (A/B: SLGC_TRI_NT=0)
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+        else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
+            hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,

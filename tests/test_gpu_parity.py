@@ -583,11 +583,8 @@ def test_triangulate_maps_xcd_remap_sizes(ctx, calib, H, W):
         got = xyz.download((H, W, 3), np.float32)
         assert int(cnt.download((1,), np.uint64)[0]) == ok.sum()
         assert np.array_equal(np.isfinite(got[..., 0]), ok) and np.isnan(got[~ok]).all()
-        want = np.moveaxis(ref, 0, -1)
-        # this geometry has a few near-parallel ray pairs (ranges of 1e3..1e4 baselines); the cancelled form is compared on the rest
-        sel = ok if mode == 0 else ok & (np.abs(want).max(axis=-1) < 100.0)
-        assert sel.sum() > 0.99 * ok.sum()
-        np.testing.assert_allclose(got[sel], want[sel], rtol=XYZ_RTOL, atol=0)
+        want = np.moveaxis(ref, 0, -1)       # this geometry has a few near-parallel ray pairs (ranges of 1e3..1e4 baselines): guarded form
+        np.testing.assert_allclose(got[ok], want[ok], rtol=XYZ_RTOL, atol=0)
     for b in (dh, dv, xyz, cnt):
         b.free()
 
@@ -630,18 +627,15 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
             assert np.array_equal(maps.download((H, W), np.int16), hp) and np.array_equal(maps.download((H, W), np.int16, voff), vp), tag
             got = xyz.download((H, W, 3), np.float32)
             assert np.array_equal(np.isfinite(got[..., 0]), ok), tag
-            if mode == 0:                                        # exact mode mirrors the reference's rounding: elementwise
-                np.testing.assert_allclose(got[ok], want[ok], rtol=XYZ_RTOL, atol=0, err_msg=tag)
-            else:                                                # cancelled form: relative to the point (a component near 0 has no relative scale)
-                rng_ = np.linalg.norm(np.where(ok[..., None], want, 1.0), axis=-1) / float(np.linalg.norm(T))
-                sel = ok & (rng_ > 0.1) & (rng_ < 100.0)         # 0.1 .. 100 baselines: outside, the reference's own acos chain is noise
-                if sel.any():
-                    err = np.linalg.norm(got[sel].astype(np.float64) - want[sel], axis=-1) / np.linalg.norm(want[sel], axis=-1)
-                    assert err.max() <= XYZ_RTOL, f"{tag}: {err.max():.3e}"
-                    worst[0] = max(worst[0], float(err.max()))
+            # every decodable pixel, elementwise, in every mode: the cancelled form switches to the reference's own float32
+            # intermediates where an angle of the triangle is below ~3.6 degrees (tri_math.h: law_of_sines_guarded)
+            np.testing.assert_allclose(got[ok], want[ok], rtol=XYZ_RTOL, atol=0, err_msg=tag)
+            if mode != 0 and ok.any():
+                err = np.abs(got[ok].astype(np.float64) - want[ok]) / np.abs(want[ok])
+                worst[0] = max(worst[0], float(err.max()))
         for b in (stack, xyz, maps):
             b.free()
-    print(f"cancelled form, worst |dP|/|P| over the fuzz scans: {worst[0]:.3e}")
+    print(f"cancelled form, worst elementwise relative error over the fuzz scans: {worst[0]:.3e}")
 
 
 def test_scan_dev_ragged_sizes(ctx, calib):
