@@ -638,6 +638,65 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
     print(f"cancelled form, worst elementwise relative error over the fuzz scans: {worst[0]:.3e}")
 
 
+def test_host_api_fuzz_vs_oracle(ctx, calib):
+    """Seeded random cases through the reference-shaped host API: get_codes, codes_to_pixels (1-3 runs), get_cam_proj_pts
+    (both orders, with / without colours, maps with -1 holes and codes beyond the projector size), triangulate (both modes, flat
+    triangles included), filter_3d_pts (NaN / inf / boundary values).  Integer and index outputs bit-exact, XYZ within 1e-4."""
+    rng = np.random.default_rng(4242)
+    for case in range(60 * int(os.environ.get("SLGC_FUZZ_SCALE", "1"))):
+        N = int(rng.integers(14, 63))
+        L = (N - 2) // 4
+        H, W = int(rng.integers(1, 20)), int(rng.integers(1, 70))
+        tag = f"case {case}: N={N} H={H} W={W}"
+        # ---- codes and maps
+        st = _fuzz_stack(rng, 1, N, H, W)[0]
+        hc, vc = ctx.codes(st if case % 2 else st.astype(np.float64))
+        rhc, rvc = oc.get_codes(st)
+        assert np.array_equal(hc, rhc) and np.array_equal(vc, rvc), tag
+        R_ = int(rng.integers(1, 4))
+        hcs = rng.integers(-1, 2, (R_, L, H, W)).astype(np.int8)
+        vcs = rng.integers(-1, 2, (R_, L, H, W)).astype(np.int8)
+        gp = ctx.codes_to_pixels(hcs if R_ > 1 else hcs[0], vcs if R_ > 1 else vcs[0])
+        rp = oc.codes_to_pixels(hcs, vcs)
+        assert np.array_equal(gp[0], rp[0]) and np.array_equal(gp[1], rp[1]), tag
+        # ---- correspondences
+        psize = (int(rng.integers(2, (2 << L) + 8)), int(rng.integers(2, (2 << L) + 8)))
+        hp = rng.integers(-1, 1 << L, (H, W)).astype(np.int64)
+        vp = rng.integers(-1, 1 << L, (H, W)).astype(np.int64)
+        hp[rng.random((H, W)) < 0.3] = -1
+        white = rng.integers(0, 256, (H, W, 3), dtype=np.uint8) if case % 3 else None
+        for order in ("x", "row"):
+            g = ctx.cam_proj_pts(hp, vp, (W, H), psize, white, order={"x": 0, "row": 1}[order])
+            r = oc.cam_proj_pts(hp, vp, (W, H), psize, white, order=order)
+            assert np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1]), tag
+            assert (g[2] is None and r[2] is None) or np.array_equal(g[2], r[2]), tag
+        # ---- triangulation of the list (random calibration; some pairs nearly parallel)
+        K = calib["cam_mtx"].copy()
+        f = float(rng.uniform(0.8, 2.0)) * max(W, H, 8)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = f, f, W / 2, H / 2
+        pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+        cd, pd = calib["cam_dist"] * float(rng.uniform(0, 1.5)), calib["proj_dist"] * float(rng.uniform(0, 1.5))
+        Rm, T = rot_y(float(rng.uniform(-30, 30))), np.array([[float(rng.uniform(0.1, 0.4))], [float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.1, 0.1))]])
+        ctx.set_calibration(K, cd, pk, pd, Rm, T)
+        cam, proj, _ = oc.cam_proj_pts(hp, vp, (W, H), psize, None, order="x")
+        want = oc.triangulate(cam, proj, K, cd, pk, pd, Rm, T)
+        for mode in (0, 1):
+            got = ctx.triangulate(cam, proj, mode=mode)
+            fin = np.isfinite(want)
+            if mode == 0:
+                assert np.array_equal(np.isfinite(got), fin), tag           # the exact chain reproduces the reference's NaN / inf too
+            np.testing.assert_allclose(got[fin], want[fin], rtol=XYZ_RTOL, atol=0, err_msg=f"{tag} mode {mode}")
+        # ---- box filter
+        M = int(rng.integers(0, 200))
+        pts = rng.uniform(-0.8, 0.8, (3, M))
+        if M:
+            pts[:, rng.integers(0, M, 3)] = np.array([[np.nan], [0.5], [-0.5]])       # NaN, exactly on the threshold (strict <)
+            pts[0, rng.integers(0, M)] = np.inf
+        col = rng.uniform(0, 1, (M, 3)) if case % 2 else None
+        gf, rf = ctx.filter_3d_pts(pts, col, 0.5), oc.filter_3d_pts(pts, col, 0.5)
+        assert np.array_equal(gf[0], rf[0]) and ((gf[1] is None and rf[1] is None) or np.array_equal(gf[1], rf[1])), tag
+
+
 def test_scan_dev_ragged_sizes(ctx, calib):
     """Bands whose pixel count is not a multiple of 4 (or whose width is odd) take the two-kernel path with byte-wide tails."""
     N = 26
