@@ -779,6 +779,23 @@ extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs
     return decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant);
 }
 
+extern "C" int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, int black_hi, unsigned long long *mismatches)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    const int skew = (eps & 0x100) ? 1 : 0;      // bit 8: negative control, the literal side is evaluated with eps + 1
+    eps &= ~0x100;
+    if (!mismatches || eps < 0 || eps > 255 || black_lo < 0 || black_hi > 256 || black_lo >= black_hi)
+        return slgc_fail(ctx, SLGC_EINVAL, "eps in 0..255, 0 <= black_lo < black_hi <= 256");
+    void *d_bad;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_bad))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    if ((rc = launch_selftest_thresholds(ctx, eps, black_lo, black_hi - black_lo, (unsigned long long *)d_bad, skew))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
 extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                                          int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
 {

@@ -638,6 +638,38 @@ int launch_fast_t(slgc_ctx *ctx, FastArgs &a, size_t npix_main)
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------
+// Diagnostic: exhaustive equivalence of the integer-threshold folding (pixel_thresholds) with the literal fp64 predicates
+// of decode_codes.py:172-182 over the whole uint8 domain.  One thread per (black, white, L_max, L_min) tuple; each checks
+//   n + eps < L_d  <=>  n < tnd,    n > L_g + eps  <=>  n >= tg   for n = 0..255,   and   L_d > L_g + eps  <=>  cA reachable.
+// (The remaining predicates n > i + eps, n + eps < i do not depend on the tuple: n - i >= e + 1, i - n >= e + 1 on integers.)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_selftest_thresholds(int e, int black0, unsigned long long *bad, int skew)
+{
+    const int lmin = threadIdx.x, lmax = blockIdx.x, white = blockIdx.y, black = black0 + (int)blockIdx.z;
+    int tt, cA;
+    pixel_thresholds(black, white, lmax, lmin, e, tt, cA);
+    const int tnd = tt & 0xffff, tg = (int)((uint32_t)tt >> 16);
+    const double w = (double)white, b = (double)black, eps = (double)(e + skew);      // skew != 0: negative control
+    const double b_inv = w / (w + b);
+    const double ld = ((double)lmax - (double)lmin) * b_inv;
+    const double lg = (2.0 * ((double)lmax - ld)) * b_inv;
+    unsigned n_bad = ((ld > (lg + eps)) != (cA != kUnreachable)) ? 1u : 0u;
+    for (int n = 0; n < 256; ++n) {
+        const double x = (double)n;
+        n_bad += (((x + eps) < ld) != (n < tnd)) ? 1u : 0u;
+        n_bad += ((x > (lg + eps)) != (n >= tg)) ? 1u : 0u;
+    }
+    if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
+}
+
+int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, unsigned long long *d_bad, int skew)
+{
+    hipLaunchKernelGGL(k_selftest_thresholds, dim3(256, 256, (unsigned)n_black), dim3(256), 0, ctx->stream, e, black0, d_bad, skew);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
 bool decode_fast_eligible(double eps, int *e_out)
 {
     if (!(eps >= 0.0 && eps <= 255.0)) return false;

@@ -61,6 +61,7 @@ SIGNATURES = {
     "slgc_dev_memset": (_i, [_vp, _vp, _i, _sz]),
     "slgc_decode_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _d, _d, _vp, _vp, _i]),
     "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
+    "slgc_selftest_thresholds": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -407,6 +408,12 @@ class Context:
                  d_h=None, d_v=None, eps=1, m=10, mode=TRI_ALGEBRAIC):
         self._ck(lib().slgc_scan_dev(self._h, d_stack, n_runs, run_stride, plane_stride, N, rows, W, row0, int(proj_size[0]),
                                      int(proj_size[1]), float(eps), float(m), int(mode), d_h, d_v, d_xyz, d_count))
+
+    def selftest_thresholds(self, eps: int = 1, black_lo: int = 0, black_hi: int = 256) -> int:
+        """Exhaustive check of the decode kernels' integer-threshold folding over the uint8 domain; returns the mismatch count."""
+        bad = C.c_uint64()
+        self._ck(lib().slgc_selftest_thresholds(self._h, int(eps), int(black_lo), int(black_hi), C.byref(bad)))
+        return int(bad.value)
 
     def triangulate_maps_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_xyz: int, d_count=None, mode=TRI_ALGEBRAIC):
         self._ck(lib().slgc_triangulate_maps_dev(self._h, d_h, d_v, rows, W, row0, int(proj_size[0]), int(proj_size[1]),

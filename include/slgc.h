@@ -158,6 +158,13 @@ int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_
                   int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
                   int16_t *d_v, float *d_xyz, unsigned long long *d_count);
 
+/* Diagnostic.  The device-resident decode kernels fold the per-pixel fp64 quantities of decode_codes.py:113-120 into integer
+ * thresholds; this checks, for every (black, white, L_max, L_min) with black in [black_lo, black_hi) and the other three over
+ * 0..255, that the folded tests agree with the literal fp64 comparisons of :172-182 for every grey level 0..255.
+ * *mismatches receives the number of disagreements (0 expected).  black_lo = 0, black_hi = 256 is the whole uint8 domain.
+ * Negative control: eps | 0x100 evaluates the literal side with eps + 1 (the count must then be non-zero). */
+int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, int black_hi, unsigned long long *mismatches);
+
 /* Triangulate dense int16 maps (as written by slgc_decode_dev) into dense XYZ; same outputs as slgc_scan_dev. */
 int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                               int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);

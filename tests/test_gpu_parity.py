@@ -207,6 +207,16 @@ def test_decode_fuzz_vs_oracle(ctx):
             assert np.array_equal(h, ref[0]) and np.array_equal(v, ref[1]), tag
 
 
+@pytest.mark.parametrize("eps", [0, 1, 2, 5, 40, 255])
+def test_threshold_folding_exhaustive(ctx, eps):
+    """All 2^32 (black, white, L_max, L_min) tuples x all 256 grey levels: the integer thresholds the device-resident kernels
+    compare against give exactly the literal fp64 predicates of decode_codes.py:172-182 (device evaluation of the same
+    expressions k_decode_generic uses, which the golden vectors pin).  2.2e12 comparisons per eps."""
+    assert ctx.selftest_thresholds(eps) == 0
+    if eps == 1:
+        assert ctx.selftest_thresholds(eps | 0x100, 0, 8) > 1_000_000          # negative control: literal side with eps + 1
+
+
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
