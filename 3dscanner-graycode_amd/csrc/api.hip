@@ -796,6 +796,20 @@ extern "C" int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, in
     return SLGC_OK;
 }
 
+extern "C" int slgc_selftest_classify(slgc_ctx *ctx, int negative_control, unsigned long long *mismatches)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!mismatches) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    void *d_bad;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_bad))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
+    if ((rc = launch_selftest_classify(ctx, (unsigned long long *)d_bad, negative_control ? 1 : 0))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
 extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                                          int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
 {

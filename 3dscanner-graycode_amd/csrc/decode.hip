@@ -283,6 +283,18 @@ __device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, u
     return f;
 }
 
+// Thresholds of the two pixels of a pair register -> the four packed constants classify_pk compares against
+// (tt = tnd | tg << 16 and cc = cA from pixel_thresholds; lo / hi = the register's low / high half).
+__device__ __forceinline__ void pack_pair_consts(int tt_lo, int cc_lo, int tt_hi, int cc_hi, uint32_t &KA, uint32_t &KB, uint32_t &C1, uint32_t &C2)
+{
+    const uint32_t a_lo = (uint32_t)tt_lo & 0xffffu, a_hi = (uint32_t)tt_hi & 0xffffu;
+    const uint32_t b_lo = (uint32_t)tt_lo >> 16, b_hi = (uint32_t)tt_hi >> 16;
+    KA = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
+    KB = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
+    C1 = (uint32_t)cc_lo | ((uint32_t)cc_hi << 16);
+    C2 = (uint32_t)(cc_lo - 1) | ((uint32_t)(cc_hi - 1) << 16);
+}
+
 // One (normal, inverse) pair register through the rule table; updates the code-bit and validity accumulators.
 template <bool MULTI>
 __device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t C1, uint32_t C2,
@@ -352,12 +364,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 #pragma unroll
                 for (int par = 0; par < 2; ++par) {
                     const int lo = par, hi = par + 2, p = 2 * q + par;
-                    const uint32_t a_lo = (uint32_t)tt[lo] & 0xffffu, a_hi = (uint32_t)tt[hi] & 0xffffu;
-                    const uint32_t b_lo = (uint32_t)tt[lo] >> 16, b_hi = (uint32_t)tt[hi] >> 16;
-                    KA[p] = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
-                    KB[p] = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
-                    C1[p] = (uint32_t)cc[lo] | ((uint32_t)cc[hi] << 16);
-                    C2[p] = (uint32_t)(cc[lo] - 1) | ((uint32_t)(cc[hi] - 1) << 16);
+                    pack_pair_consts(tt[lo], cc[lo], tt[hi], cc[hi], KA[p], KB[p], C1[p], C2[p]);
                 }
             }
         }
@@ -661,6 +668,45 @@ __global__ void __launch_bounds__(256) k_selftest_thresholds(int e, int black0, 
         n_bad += ((x > (lg + eps)) != (n >= tg)) ? 1u : 0u;
     }
     if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
+}
+
+// Diagnostic: the packed-16 rule evaluation (classify_pk) against the scalar rule table for EVERY threshold triple
+// (tnd, tg in 0..256; cA = 1..256 or unreachable) and EVERY (n, i) in 0..255^2 -- 1.1e12 classifications.  The register's other half
+// carries a different triple and different pixel values, so leaks between the halves would show.
+__global__ void __launch_bounds__(256) k_selftest_classify(unsigned long long *bad, int skew)
+{
+    const int tnd = blockIdx.x, tg = blockIdx.y, ci = blockIdx.z;                  // 257 x 257 x 257
+    const int cA = ci < 256 ? ci + 1 : kUnreachable;
+    const int tnd2 = 256 - tnd, tg2 = (tg * 7 + 3) % 257, cA2 = ci % 3 == 0 ? kUnreachable : (ci * 5) % 256 + 1;
+    uint32_t KA, KB, C1, C2;
+    pack_pair_consts(tnd | (tg << 16), cA, tnd2 | (tg2 << 16), cA2, KA, KB, C1, C2);
+    const int n = threadIdx.x;
+    unsigned n_bad = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int n2 = 255 - n, i2 = (i * 37 + 11) & 255;
+        uint32_t accB = 0u, accV = 0xffffffffu;
+        classify_pk<false>((uint32_t)n | ((uint32_t)n2 << 16), (uint32_t)i | ((uint32_t)i2 << 16), KA, KB, C1, C2, accB, accV);
+        auto expect = [](int n_, int i_, int tnd_, int tg_, int cA_, bool &bit, bool &valid) {
+            const bool r1 = (n_ - i_) >= cA_, r2 = (i_ - n_) >= cA_;
+            const bool r3 = (n_ < tnd_) & (i_ >= tg_), r4 = (n_ >= tg_) & (i_ < tnd_);
+            bit = r4 | (r1 & !r3);
+            valid = r1 | r2 | r3 | r4;
+        };
+        bool b_lo, v_lo, b_hi, v_hi;
+        expect(n, i, tnd, tg + skew, cA, b_lo, v_lo);          // skew != 0: negative control
+        expect(n2, i2, tnd2, tg2, cA2, b_hi, v_hi);
+        // an unclassified pair leaves the code bit unspecified (the pixel becomes -1): compare it only where valid
+        n_bad += (((accV >> 15) & 1u) != (unsigned)v_lo) + (((accV >> 31) & 1u) != (unsigned)v_hi);
+        n_bad += (v_lo && (((accB >> 15) & 1u) != (unsigned)b_lo)) + (v_hi && (((accB >> 31) & 1u) != (unsigned)b_hi));
+    }
+    if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
+}
+
+int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew)
+{
+    hipLaunchKernelGGL(k_selftest_classify, dim3(257, 257, 257), dim3(256), 0, ctx->stream, d_bad, skew);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
 }
 
 int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, unsigned long long *d_bad, int skew)

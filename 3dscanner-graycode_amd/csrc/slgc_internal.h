@@ -105,6 +105,7 @@ int launch_codes_to_pixels(slgc_ctx *ctx, const int8_t *d_hc, const int8_t *d_vc
                            int64_t *d_h, int64_t *d_v);
 bool decode_fast_eligible(double eps, int *e_out);
 int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, unsigned long long *d_bad, int skew);
+int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew);
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
                       int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h);
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "slgc_decode_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _d, _d, _vp, _vp, _i]),
     "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "slgc_selftest_thresholds": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
+    "slgc_selftest_classify": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -413,6 +414,12 @@ class Context:
         """Exhaustive check of the decode kernels' integer-threshold folding over the uint8 domain; returns the mismatch count."""
         bad = C.c_uint64()
         self._ck(lib().slgc_selftest_thresholds(self._h, int(eps), int(black_lo), int(black_hi), C.byref(bad)))
+        return int(bad.value)
+
+    def selftest_classify(self, negative_control: bool = False) -> int:
+        """Exhaustive check of the packed-16 rule evaluation against the scalar rule table; returns the mismatch count."""
+        bad = C.c_uint64()
+        self._ck(lib().slgc_selftest_classify(self._h, int(bool(negative_control)), C.byref(bad)))
         return int(bad.value)
 
     def triangulate_maps_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_xyz: int, d_count=None, mode=TRI_ALGEBRAIC):

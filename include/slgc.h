@@ -165,6 +165,12 @@ int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_
  * Negative control: eps | 0x100 evaluates the literal side with eps + 1 (the count must then be non-zero). */
 int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, int black_hi, unsigned long long *mismatches);
 
+/* Diagnostic.  The packed 16-bit evaluation of the rule table (two pixels per register, decode_codes.py:162-182 "last match
+ * wins") against the scalar rules for every threshold triple (tnd, tg in 0..256, cA in 1..256 or "not direct") and every
+ * (normal, inverse) grey-level pair: 1.1e12 classifications; *mismatches = 0 expected.  negative_control != 0 shifts one
+ * threshold of the scalar side by one (the count must then be non-zero). */
+int slgc_selftest_classify(slgc_ctx *ctx, int negative_control, unsigned long long *mismatches);
+
 /* Triangulate dense int16 maps (as written by slgc_decode_dev) into dense XYZ; same outputs as slgc_scan_dev. */
 int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                               int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);

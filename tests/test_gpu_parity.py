@@ -217,6 +217,13 @@ def test_threshold_folding_exhaustive(ctx, eps):
         assert ctx.selftest_thresholds(eps | 0x100, 0, 8) > 1_000_000          # negative control: literal side with eps + 1
 
 
+def test_packed_classification_exhaustive(ctx):
+    """Every threshold triple x every (normal, inverse) grey-level pair through the packed-16 rule evaluation of the shipped
+    kernel (classify_pk) == the scalar rule table; the other half of each register carries different data."""
+    assert ctx.selftest_classify() == 0
+    assert ctx.selftest_classify(negative_control=True) > 1_000_000
+
+
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
