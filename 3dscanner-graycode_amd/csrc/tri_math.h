@@ -83,11 +83,13 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
         const double D = fma(Sa, B, A * Sb);
         const float s = (float)(tl2 * Sb * fast_rcp(D));
         if (GUARD) {
-            // |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], eps = 2^-24 (the float32 steps):
-            // redo the pixel when either term can pass 400 (bound 2.4e-5 per term, tolerance 1e-4).
-            //   sin^2(beta) < 2.5e-3          <=>  rb < k1 * tb
-            //   min(sin a, sin b)^2 * sin^2(gamma) < 2.5e-5   <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
-            constexpr double k1 = 2.5e-3, k2 = 2.5e-5;
+            // |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], where eps bounds the error of
+            // cos(alpha), cos(beta) caused by the float32 steps of the reference (sqrt and three divisions for NormedL, one sqrt for
+            // the projector norm: <= 3 * 2^-24 = 1.8e-7).  Redo the pixel when either term can pass 200: the fast form is then
+            // never further than 2 * 200 * 1.8e-7 = 7.2e-5 from the reference, inside the 1e-4 tolerance even if every rounding aligns.
+            //   sin^2(beta) < 5e-3                             <=>  rb < k1 * tb
+            //   min(sin a, sin b)^2 * sin^2(gamma) < 1e-4      <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
+            constexpr double k1 = 5e-3, k2 = 1e-4;
             const double tatb = ta * tb;
             const bool bad = (rb < k1 * tb) | ((D * D) * fmin(ra * tb, rb * ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
             ill |= bad ? (1u << j) : 0u;
