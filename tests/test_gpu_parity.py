@@ -693,6 +693,9 @@ def test_host_api_fuzz_vs_oracle(ctx, calib):
         K[0, 0], K[1, 1], K[0, 2], K[1, 2] = f, f, W / 2, H / 2
         pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
         cd, pd = calib["cam_dist"] * float(rng.uniform(0, 1.5)), calib["proj_dist"] * float(rng.uniform(0, 1.5))
+        if case % 5 == 0:                                      # violent distortion: the icdist < 0 bail-out of undistortPoints fires for some pixels
+            cd = calib["cam_dist"] * float(rng.uniform(-60, 60))
+            pd = calib["proj_dist"] * float(rng.uniform(-60, 60))
         Rm, T = rot_y(float(rng.uniform(-30, 30))), np.array([[float(rng.uniform(0.1, 0.4))], [float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.1, 0.1))]])
         ctx.set_calibration(K, cd, pk, pd, Rm, T)
         cam, proj, _ = oc.cam_proj_pts(hp, vp, (W, H), psize, None, order="x")
