@@ -111,6 +111,22 @@ def test_product_never_touches_oracle_or_torch():
         assert "slgc_oracle" not in text and "orc_" not in text, f
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/slgc.h is the boundary a non-Python host binds: it must compile as C99 and a C program must link against
+    libslgc.so and call the entry points that need no GPU."""
+    from scanner import _native
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include "slgc.h"\nint main(void){ int r0, rn;\n'
+                   ' if (slgc_shard_band(3000, 8, 7, &r0, &rn)) return 2;\n'
+                   ' printf("%d %s %d %d\\n", slgc_version(), slgc_backend(), r0, rn); return 0; }\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lslgc", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["100", "hip:gfx950", "2625", "375"]
+
+
 def test_host_only_helpers(tmp_path):
     """Helpers that need no GPU: PLY layout, read_images file order, shard plan."""
     from scanner.grayCode.decode_codes import read_images_order
