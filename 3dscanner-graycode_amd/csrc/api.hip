@@ -856,6 +856,24 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 
+extern "C" int slgc_pack_hv24_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int code_bits, uint8_t *d_wire)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_h || !d_v || !d_wire) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (code_bits < 1 || code_bits > SLGC_WIRE_MAX_CODE_BITS)
+        return slgc_fail(ctx, SLGC_EINVAL, "the 3-byte wire format holds codes of at most %d bits (got %d)", SLGC_WIRE_MAX_CODE_BITS, code_bits);
+    return launch_pack_hv24(ctx, d_h, d_v, npix, d_wire);
+}
+
+extern "C" int slgc_unpack_hv24_dev(slgc_ctx *ctx, const uint8_t *d_wire, size_t npix, int16_t *d_h, int16_t *d_v)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_h || !d_v || !d_wire) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    return launch_unpack_hv24(ctx, d_wire, npix, d_h, d_v);
+}
+
 extern "C" int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
                                 unsigned long long *d_count)
 {

@@ -133,6 +133,10 @@ int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, siz
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
                              unsigned long long *d_counts);
 
+// wire.hip
+int launch_pack_hv24(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, uint8_t *d_out);
+int launch_unpack_hv24(slgc_ctx *ctx, const uint8_t *d_in, size_t npix, int16_t *d_h, int16_t *d_v);
+
 // XCD-aware workgroup -> tile map.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round-robin, and each XCD has
 // its own L2.  With the identity map every XCD sees every 8th tile of the image; with this map XCD x owns the contiguous
 // tile range [x*chunk, (x+1)*chunk) (a band of whole rows), so the projector-ray lines it gathers are shared by neighbouring

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SLGC_LIB", os.path.join(_PKG_ROOT, "lib", "libslgc.so
 
 U8, F64 = 0, 1
 ORDER_X, ORDER_ROW = 0, 1
+WIRE_MAX_CODE_BITS = 11           # slgc.h SLGC_WIRE_MAX_CODE_BITS
 TRI_EXACT, TRI_ALGEBRAIC, TRI_DIRECT, TRI_SPLIT = 0, 1, 2, 4
 UNIQUE_ID_BYTES = 128
 
@@ -66,6 +67,8 @@ SIGNATURES = {
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "slgc_pack_hv24_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "slgc_unpack_hv24_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
@@ -431,6 +434,13 @@ class Context:
 
     def compact_records_dev(self, d_xyz: int, rows, W, row0, d_records: int, d_count: int):
         self._ck(lib().slgc_compact_records_dev(self._h, d_xyz, rows, W, row0, d_records, d_count))
+
+    def pack_hv24_dev(self, d_h: int, d_v: int, npix: int, code_bits: int, d_wire: int):
+        """int16 maps -> 3 bytes per pixel (12 + 12 bits, 0xFFF = -1) for the multi-GPU exchange; code_bits <= WIRE_MAX_CODE_BITS."""
+        self._ck(lib().slgc_pack_hv24_dev(self._h, d_h, d_v, int(npix), int(code_bits), d_wire))
+
+    def unpack_hv24_dev(self, d_wire: int, npix: int, d_h: int, d_v: int):
+        self._ck(lib().slgc_unpack_hv24_dev(self._h, d_wire, int(npix), d_h, d_v))
 
     def synth_scene_dev(self, d_stack: int, plane_stride, N, H, W, row0=0, rows=None, seed=1, noise=3, shadow=True):
         rows = H if rows is None else rows

@@ -181,9 +181,22 @@ class ShardedScanner:
     With the "maps" strategy consecutive scans can be pipelined (:meth:`submit` / :meth:`flush`): the all-gatherv of scan i runs
     on the communication stream while the compute stream triangulates scan i-1 and decodes scan i+1 (two sets of map buffers)."""
 
-    def __init__(self, ctx, exchange, plan: ShardPlan, proj_size, n_frames: int, mode: int = 1, exchange_kind: str = "maps"):
+    def __init__(self, ctx, exchange, plan: ShardPlan, proj_size, n_frames: int, mode: int = 1, exchange_kind: str = "maps",
+                 wire: str = "auto"):
+        """wire ("maps" strategy): "int16" sends the two int16 maps as they are (4 B/pixel); "hv24" packs them into 3 B/pixel
+        for the exchange (codes of <= 11 bits) and unpacks on arrival -- the exchange bounds a sharded scan, so fewer bytes on
+        the links is worth two small streaming kernels; "auto" = hv24 when there is more than one rank and the codes fit."""
         if exchange_kind not in ("maps", "records"):
             raise ValueError("exchange_kind must be 'maps' or 'records'")
+        if wire not in ("auto", "int16", "hv24"):
+            raise ValueError("wire must be 'auto', 'int16' or 'hv24'")
+        from ._native import WIRE_MAX_CODE_BITS
+        self.code_bits = int((n_frames - 2) / 4)
+        if wire == "auto":
+            wire = "hv24" if (plan.G > 1 and self.code_bits <= WIRE_MAX_CODE_BITS) else "int16"
+        if wire == "hv24" and self.code_bits > WIRE_MAX_CODE_BITS:
+            raise ValueError(f"the 3-byte wire format holds codes of at most {WIRE_MAX_CODE_BITS} bits (N={n_frames} has {self.code_bits})")
+        self.wire = wire
         self.ctx, self.exchange, self.plan = ctx, exchange, plan
         self.proj_size, self.N, self.mode, self.kind = proj_size, n_frames, mode, exchange_kind
         self.rank = exchange.rank
@@ -193,6 +206,7 @@ class ShardedScanner:
         self.last_counts = None
         if exchange_kind == "maps":
             self._sets = [(ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 2))) for _ in range(2)]
+            self._wire = [ctx.alloc(max(16, full_px * 3)) for _ in range(2)] if wire == "hv24" else None
             self.h_full, self.v_full = self._sets[0]                 # where scan_maps() / the last finished submit() left the maps
             self.xyz_full = ctx.alloc(max(16, full_px * 12))
             self._submitted = 0
@@ -213,8 +227,24 @@ class ShardedScanner:
         off = self.row0 * W * 2
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      self.h_full.at(off), self.v_full.at(off), eps=eps)
-        exchange_map_bands(self.exchange, self.plan, self.h_full, self.v_full, lambda buf, o: buf.at(o))
+        if self.wire == "hv24":
+            self._wire_begin(0, self.h_full, self.v_full, 3)
+            self.exchange.wait(3)
+            c.unpack_hv24_dev(self._wire[0].ptr, H * W, self.h_full.ptr, self.v_full.ptr)
+        else:
+            exchange_map_bands(self.exchange, self.plan, self.h_full, self.v_full, lambda buf, o: buf.at(o))
         c.triangulate_maps_dev(self.h_full.ptr, self.v_full.ptr, H, W, 0, self.proj_size, self.xyz_full.ptr, None, mode=self.mode & 3)
+
+    def _wire_begin(self, s: int, h_full, v_full, slot: int):
+        """Pack this rank's band into its slot of wire buffer ``s`` and start the in-place all-gatherv of the packed bands."""
+        W = self.plan.W
+        band_px = self.rows * W
+        wire = self._wire[s]
+        if band_px:
+            self.ctx.pack_hv24_dev(h_full.at(self.row0 * W * 2), v_full.at(self.row0 * W * 2), band_px, self.code_bits, wire.at(self.row0 * W * 3))
+        counts = [rows * W * 3 for _, rows in self.plan.bands()]
+        displs = [row0 * W * 3 for row0, _ in self.plan.bands()]
+        self.exchange.allgatherv_begin(wire.at(displs[self.rank]), wire, counts, displs, slot)
 
     def submit(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
         """Pipelined "maps" scan: decode this scan's band, start its exchange on the communication stream, then finish the
@@ -228,7 +258,10 @@ class ShardedScanner:
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      h_full.at(off), v_full.at(off), eps=eps)
         counts, displs = map_band_layout(self.plan)
-        if hasattr(self.exchange, "allgatherv_pair_begin"):           # one RCCL group for both maps
+        if self.wire == "hv24":
+            self._wire_begin(s, h_full, v_full, 2 * s)
+            self._pair = True
+        elif hasattr(self.exchange, "allgatherv_pair_begin"):         # one RCCL group for both maps
             self.exchange.allgatherv_pair_begin(h_full.at(displs[self.rank]), h_full, v_full.at(displs[self.rank]), v_full, counts, displs, 2 * s)
             self._pair = True
         else:
@@ -245,6 +278,8 @@ class ShardedScanner:
         self.exchange.wait(2 * s)
         if not self._pair:
             self.exchange.wait(2 * s + 1)
+        if self.wire == "hv24":
+            self.ctx.unpack_hv24_dev(self._wire[s].ptr, self.plan.H * self.plan.W, h_full.ptr, v_full.ptr)
         self.ctx.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, self.plan.W, 0, self.proj_size, self.xyz_full.ptr, None,
                                       mode=self.mode & 3)
         self.h_full, self.v_full = h_full, v_full

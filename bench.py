@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default), or all-gatherv "
                          "compacted 16-byte XYZ+key records")
+    ap.add_argument("--wire", default="auto", choices=["auto", "int16", "hv24"],
+                    help="sharded 'maps' exchange: send the int16 maps (4 B/pixel) or the packed 3 B/pixel wire format (auto: hv24 for G > 1)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded 'maps' mode: do not pipeline the exchange with the neighbouring scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
     ap.add_argument("--plane-pad", type=int, default=0,
@@ -236,7 +238,7 @@ def main():
     if use_comm:
         from scanner import sharded
         sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(cam_h, cam_w, G),
-                                                 (proj_w, proj_h), N, mode=mode, exchange_kind=args.exchange)
+                                                 (proj_w, proj_h), N, mode=mode, exchange_kind=args.exchange, wire=args.wire)
     ctx.synchronize()
 
     def step(i, counted=False, mode=mode):
@@ -326,7 +328,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
                                    + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
-                       **({} if not use_comm else {"exchange": ("int16 map bands all-gathered, every rank triangulates the full maps"
+                       **({} if not use_comm else {"exchange": ((("map bands packed to 3 B/pixel, all-gathered, unpacked" if sharded_scanner.wire == "hv24"
+                                                                  else "int16 map bands all-gathered") + ", every rank triangulates the full maps")
                                                                 + ("" if args.no_overlap else "; exchange of scan i overlaps triangulation of i-1 and decode of i+1")
                                                                 if args.exchange == "maps" else
                                                                 "compacted 16-byte XYZ+key records all-gathered")}),

@@ -184,6 +184,13 @@ int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row
 int slgc_compact_records_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, void *d_records,
                              unsigned long long *d_count);
 
+/* 3-byte wire format of the maps for the multi-GPU exchange (the exchange, not the kernels, bounds a sharded scan): per pixel
+ * bits 0..11 = h, bits 12..23 = v, 0xFFF = -1.  Holds codes of at most SLGC_WIRE_MAX_CODE_BITS bits (N <= 49 frames; the
+ * reference's captures use 10); _pack rejects more.  d_wire: 3 * npix bytes. */
+#define SLGC_WIRE_MAX_CODE_BITS 11
+int slgc_pack_hv24_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int code_bits, uint8_t *d_wire);
+int slgc_unpack_hv24_dev(slgc_ctx *ctx, const uint8_t *d_wire, size_t npix, int16_t *d_h, int16_t *d_v);
+
 /* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
 int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                          uint32_t seed, int noise, int shadow);

@@ -224,6 +224,39 @@ def test_packed_classification_exhaustive(ctx):
     assert ctx.selftest_classify(negative_control=True) > 1_000_000
 
 
+def _pack_hv24_np(h, v):
+    p = (h.astype(np.int64) & 0xfff) | ((v.astype(np.int64) & 0xfff) << 12)
+    return np.stack([p & 0xff, (p >> 8) & 0xff, (p >> 16) & 0xff], axis=-1).astype(np.uint8).reshape(-1)
+
+
+def test_wire_format_hv24_round_trip(ctx):
+    """3-byte wire format of the maps (multi-GPU exchange): pack == the bit layout slgc.h states, unpack(pack(x)) == x, for
+    aligned, misaligned and ragged sizes, -1 included, 11-bit codes at their maximum."""
+    rng = np.random.default_rng(99)
+    for npix, misalign in ((4096, 0), (4099, 0), (1, 0), (3, 0), (5, 0), (1000, 2), (1001, 6), (64, 4)):
+        h = rng.integers(-1, 2048, npix).astype(np.int16)
+        v = rng.integers(-1, 2048, npix).astype(np.int16)
+        h[rng.random(npix) < 0.2] = -1
+        v[-1] = 2047
+        dh, dv = ctx.alloc(npix * 2 + 16), ctx.alloc(npix * 2 + 16)
+        dh.upload(h, misalign)
+        dv.upload(v, misalign)
+        wire = ctx.alloc(npix * 3 + 16).zero()
+        woff = misalign // 2 if misalign else 0
+        ctx.pack_hv24_dev(dh.at(misalign), dv.at(misalign), npix, 11, wire.at(woff))
+        ctx.synchronize()
+        assert np.array_equal(wire.download((npix * 3,), np.uint8, woff), _pack_hv24_np(h, v)), (npix, misalign)
+        oh, ov = ctx.alloc(npix * 2 + 16).zero(), ctx.alloc(npix * 2 + 16).zero()
+        ctx.unpack_hv24_dev(wire.at(woff), npix, oh.at(misalign), ov.at(misalign))
+        ctx.synchronize()
+        assert np.array_equal(oh.download((npix,), np.int16, misalign), h) and np.array_equal(ov.download((npix,), np.int16, misalign), v)
+        for b in (dh, dv, wire, oh, ov):
+            b.free()
+    buf = ctx.alloc(64)
+    with pytest.raises(ValueError):
+        ctx.pack_hv24_dev(buf.ptr, buf.ptr, 4, 12, buf.ptr)            # 12-bit codes do not fit
+
+
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
@@ -486,6 +519,20 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
             ok2 = (rh2 != -1) & (rv2 != -1)
             assert np.array_equal(gh2, rh2) and np.array_equal(gv2, rv2) and np.array_equal(np.isfinite(gx2[..., 0]), ok2)
             np.testing.assert_allclose(gx2[ok2], np.moveaxis(rx2, 0, -1)[ok2], rtol=XYZ_RTOL, atol=0)
+        # the 3-byte wire format forced on (auto keeps int16 for a single rank): same products
+        scw = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT, wire="hv24")
+        assert scm.wire == "int16" and scw.wire == "hv24"
+        scw.scan(stack.ptr, H * W)
+        wh, wv, wx = scw.fetch_dense()
+        assert np.array_equal(wh, hp) and np.array_equal(wv, vp) and np.array_equal(wx, gx, equal_nan=True)
+        scw.submit(stack.ptr, H * W)
+        scw.submit(bufs[0].ptr, H * W)
+        scw.flush()
+        wh, wv, wx = scw.fetch_dense()
+        rh0, rv0, _ = oc.scan_dense(caps[0], psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+        assert np.array_equal(wh, rh0) and np.array_equal(wv, rv0)
+        with pytest.raises(ValueError):
+            sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, 62, wire="hv24")      # L = 15 does not fit
         # the same scan through the one-call C entry point (slgc_scan_sharded_dev)
         dh, dv, dx = ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 12).zero()
         ctx.scan_sharded_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, psize, dh.ptr, dv.ptr, dx.ptr, mode=_native.TRI_EXACT)

@@ -113,20 +113,22 @@ def _worker(rank, world, port, H, W, N, q):
         caps = [onp.synth_scene_int(N, H, W, seed=40 + j, noise=3 + j)[0] for j in range(3)]
         bufs = [upload_band(cp) for cp in caps]
         plane = max(1, rows * W)
-        # ---- "maps" strategy, one scan at a time
-        scm = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT)
-        assert scm.scan(bufs[0].ptr, plane) is None
-        check_dense(scm.fetch_dense(), caps[0])
-        # ---- pipelined: three captures in flight, results in order
-        outs = []
-        for j, b in enumerate(bufs):
-            scm.submit(b.ptr, plane)
-            if j:
-                outs.append(scm.fetch_dense())
-        scm.flush()
-        outs.append(scm.fetch_dense())
-        for cp, got in zip(caps, outs):
-            check_dense(got, cp)
+        for wire in ("auto", "int16"):                           # auto = the 3-byte wire format (world > 1, L = 6 bits)
+            # ---- "maps" strategy, one scan at a time
+            scm = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT, wire=wire)
+            assert scm.wire == ("hv24" if wire == "auto" else "int16")
+            assert scm.scan(bufs[0].ptr, plane) is None
+            check_dense(scm.fetch_dense(), caps[0])
+            # ---- pipelined: three captures in flight, results in order
+            outs = []
+            for j, b in enumerate(bufs):
+                scm.submit(b.ptr, plane)
+                if j:
+                    outs.append(scm.fetch_dense())
+            scm.flush()
+            outs.append(scm.fetch_dense())
+            for cp, got in zip(caps, outs):
+                check_dense(got, cp)
         # ---- "records" strategy: counts all-gather + all-gatherv of {xyz, key} records
         sc = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT, exchange_kind="records")
         total = sc.scan(bufs[1].ptr, plane)
