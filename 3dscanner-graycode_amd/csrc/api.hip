@@ -821,6 +821,17 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 
+extern "C" int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, int W, int row0, int proj_w, int proj_h, int mode,
+                                         int16_t *d_h, int16_t *d_v, float *d_xyz, unsigned long long *d_count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_wire || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (mode < 0 || mode > 1) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count, d_wire);
+}
+
 extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
                              int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
                              int16_t *d_v, float *d_xyz, unsigned long long *d_count)

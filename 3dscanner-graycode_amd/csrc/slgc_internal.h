@@ -124,7 +124,7 @@ int launch_compact_records(slgc_ctx *ctx, const float *d_xyz, int rows, int W, i
 // triangulate.hip
 int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz);
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
-                            int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
+                            int proj_h, int mode, float *d_xyz, unsigned long long *d_count, const uint8_t *d_wire = nullptr);
 // synth.hip
 int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
                  int noise, int shadow);
@@ -132,6 +132,21 @@ int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, in
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
                              unsigned long long *d_counts);
+
+// 3-byte wire format (wire.hip): three dwords = four pixels of (h: bits 0..11, v: bits 12..23, 0xFFF = -1) -> int16 pairs.
+__device__ __forceinline__ void unpack_hv24_x4(uint32_t w0, uint32_t w1, uint32_t w2, uint2 &hw, uint2 &vw)
+{
+    const uint32_t p[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
+    uint32_t hh[4], vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t a = p[j] & 0xfffu, b = p[j] >> 12;
+        hh[j] = a == 0xfffu ? 0xffffu : a;
+        vv[j] = b == 0xfffu ? 0xffffu : b;
+    }
+    hw = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
+    vw = make_uint2(vv[0] | (vv[1] << 16), vv[2] | (vv[3] << 16));
+}
 
 // wire.hip
 int launch_pack_hv24(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, uint8_t *d_out);

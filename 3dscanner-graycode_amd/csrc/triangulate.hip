@@ -21,7 +21,8 @@
 int launch_triangulate_maps_direct(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, size_t first, int W, int row0,
                                    int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
 static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int W, int row0, int rows,
-                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count);
+                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count,
+                                        const uint8_t *d_wire);
 
 namespace {
 
@@ -203,9 +204,11 @@ struct TriConst {
 //   2. gathers run pixel-per-lane (64 neighbouring pixels per instruction) -> s_ray  (8 KB)
 //   3. every lane triangulates its own 4 pixels                            -> s_xyz  (12 KB, aliases s_ray)
 //   4. the 12 KB of XYZ leave as wave-contiguous 1 KB stores.
+// wire != nullptr: the maps arrive in the 3-byte wire format of the multi-GPU exchange (wire.hip); the kernel unpacks them and
+// also writes the int16 maps (h, v are outputs then), so the exchange needs no separate unpack pass.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc, const int16_t *__restrict__ h,
-                                                              const int16_t *__restrict__ v, const float2 *__restrict__ cam_lut,
+__global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc, int16_t *__restrict__ h, int16_t *__restrict__ v,
+                                                              const uint32_t *__restrict__ wire, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
                                                               unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store)
@@ -219,7 +222,15 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const uint2 hw = reinterpret_cast<const uint2 *>(h)[g], vw = reinterpret_cast<const uint2 *>(v)[g];
+        uint2 hw, vw;
+        if (wire) {
+            unpack_hv24_x4(wire[3 * g], wire[3 * g + 1], wire[3 * g + 2], hw, vw);
+            reinterpret_cast<uint2 *>(h)[g] = hw;
+            reinterpret_cast<uint2 *>(v)[g] = vw;
+        } else {
+            hw = reinterpret_cast<const uint2 *>(h)[g];
+            vw = reinterpret_cast<const uint2 *>(v)[g];
+        }
         const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
         cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
         const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
@@ -328,7 +339,7 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
 }
 
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
-                            int proj_h, int mode, float *d_xyz, unsigned long long *d_count)
+                            int proj_h, int mode, float *d_xyz, unsigned long long *d_count, const uint8_t *d_wire)
 {
     const size_t npix = (size_t)rows * W;
     if (npix == 0) return SLGC_OK;
@@ -343,7 +354,7 @@ int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_
     }
     const bool direct = (mode & SLGC_TRI_DIRECT) != 0;
     mode &= 1;
-    int rc = launch_triangulate_maps_body(ctx, d_h, d_v, npix, W, row0, rows, proj_w, proj_h, mode, direct, d_xyz, slots);
+    int rc = launch_triangulate_maps_body(ctx, d_h, d_v, npix, W, row0, rows, proj_w, proj_h, mode, direct, d_xyz, slots, d_wire);
     if (rc) return rc;
     if (d_count) {
         hipLaunchKernelGGL(k_count_finish, dim3(1), dim3(256), 0, ctx->stream, slots, d_count);
@@ -352,10 +363,19 @@ int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_
     return SLGC_OK;
 }
 
-static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int W, int row0, int rows,
-                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count)
+static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, const int16_t *d_v_in, size_t npix, int W, int row0, int rows,
+                                        int proj_w, int proj_h, int mode, bool direct, float *d_xyz, unsigned long long *d_count,
+                                        const uint8_t *d_wire)
 {
-    const bool vec_ok = !direct && (((uintptr_t)d_h | (uintptr_t)d_v) % 8 == 0) && ((uintptr_t)d_xyz % 16 == 0) && (size_t)proj_w * proj_h < (1u << 28);
+    int16_t *d_h = const_cast<int16_t *>(d_h_in), *d_v = const_cast<int16_t *>(d_v_in);      // written only when d_wire is given
+    const bool vec_ok = !direct && (((uintptr_t)d_h | (uintptr_t)d_v) % 8 == 0) && ((uintptr_t)d_xyz % 16 == 0) && (size_t)proj_w * proj_h < (1u << 28) &&
+                        (uintptr_t)d_wire % 4 == 0;
+    if (d_wire && !(vec_ok && npix >= 4 && npix % 4 == 0)) {       // odd shapes: unpack first, then the ordinary path
+        int rc = launch_unpack_hv24(ctx, d_wire, npix, d_h, d_v);
+        if (rc) return rc;
+        d_wire = nullptr;
+    }
+    const uint32_t *d_wire32 = reinterpret_cast<const uint32_t *>(d_wire);
     if (vec_ok && npix >= 4) {
         int rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
         if (rc) return rc;
@@ -366,13 +386,13 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         static const int tri_nt = xcd_env("SLGC_TRI_NT", 1);     // XYZ leaves with non-temporal stores (A/B: SLGC_TRI_NT=0)
         if (mode == SLGC_TRI_EXACT)
-            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
-            hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+            hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         else
-            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v,
+            hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;

@@ -47,16 +47,10 @@ __global__ void __launch_bounds__(256) k_unpack_hv24(const uint8_t *__restrict__
     if (q * 4 >= npix) return;
     if (vec_ok && q * 4 + 4 <= npix) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(in) + q * 3;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
-        const uint32_t p[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
-        uint32_t hh[4], vv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            hh[j] = (uint32_t)(uint16_t)dec12(p[j] & 0xfffu);
-            vv[j] = (uint32_t)(uint16_t)dec12(p[j] >> 12);
-        }
-        reinterpret_cast<uint2 *>(h)[q] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
-        reinterpret_cast<uint2 *>(v)[q] = make_uint2(vv[0] | (vv[1] << 16), vv[2] | (vv[3] << 16));
+        uint2 hw, vw;
+        unpack_hv24_x4(src[0], src[1], src[2], hw, vw);
+        reinterpret_cast<uint2 *>(h)[q] = hw;
+        reinterpret_cast<uint2 *>(v)[q] = vw;
     } else {
         for (size_t i = q * 4; i < npix && i < q * 4 + 4; ++i) {
             const uint32_t p = (uint32_t)in[3 * i] | ((uint32_t)in[3 * i + 1] << 8) | ((uint32_t)in[3 * i + 2] << 16);

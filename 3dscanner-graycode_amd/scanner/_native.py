@@ -69,6 +69,7 @@ SIGNATURES = {
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slgc_pack_hv24_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "slgc_unpack_hv24_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "slgc_triangulate_wire_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
@@ -441,6 +442,11 @@ class Context:
 
     def unpack_hv24_dev(self, d_wire: int, npix: int, d_h: int, d_v: int):
         self._ck(lib().slgc_unpack_hv24_dev(self._h, d_wire, int(npix), d_h, d_v))
+
+    def triangulate_wire_dev(self, d_wire: int, rows, W, row0, proj_size, d_h: int, d_v: int, d_xyz: int, d_count=None, mode=TRI_ALGEBRAIC):
+        """triangulate_maps_dev on wire-format maps; also writes the int16 maps d_h / d_v."""
+        self._ck(lib().slgc_triangulate_wire_dev(self._h, d_wire, rows, W, row0, int(proj_size[0]), int(proj_size[1]), int(mode) & 1,
+                                                 d_h, d_v, d_xyz, d_count))
 
     def synth_scene_dev(self, d_stack: int, plane_stride, N, H, W, row0=0, rows=None, seed=1, noise=3, shadow=True):
         rows = H if rows is None else rows

@@ -230,9 +230,10 @@ class ShardedScanner:
         if self.wire == "hv24":
             self._wire_begin(0, self.h_full, self.v_full, 3)
             self.exchange.wait(3)
-            c.unpack_hv24_dev(self._wire[0].ptr, H * W, self.h_full.ptr, self.v_full.ptr)
-        else:
-            exchange_map_bands(self.exchange, self.plan, self.h_full, self.v_full, lambda buf, o: buf.at(o))
+            c.triangulate_wire_dev(self._wire[0].ptr, H, W, 0, self.proj_size, self.h_full.ptr, self.v_full.ptr, self.xyz_full.ptr, None,
+                                   mode=self.mode & 1)           # unpacks while it loads: int16 maps + XYZ in one pass
+            return
+        exchange_map_bands(self.exchange, self.plan, self.h_full, self.v_full, lambda buf, o: buf.at(o))
         c.triangulate_maps_dev(self.h_full.ptr, self.v_full.ptr, H, W, 0, self.proj_size, self.xyz_full.ptr, None, mode=self.mode & 3)
 
     def _wire_begin(self, s: int, h_full, v_full, slot: int):
@@ -279,9 +280,11 @@ class ShardedScanner:
         if not self._pair:
             self.exchange.wait(2 * s + 1)
         if self.wire == "hv24":
-            self.ctx.unpack_hv24_dev(self._wire[s].ptr, self.plan.H * self.plan.W, h_full.ptr, v_full.ptr)
-        self.ctx.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, self.plan.W, 0, self.proj_size, self.xyz_full.ptr, None,
-                                      mode=self.mode & 3)
+            self.ctx.triangulate_wire_dev(self._wire[s].ptr, self.plan.H, self.plan.W, 0, self.proj_size, h_full.ptr, v_full.ptr,
+                                          self.xyz_full.ptr, None, mode=self.mode & 1)
+        else:
+            self.ctx.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, self.plan.W, 0, self.proj_size, self.xyz_full.ptr, None,
+                                          mode=self.mode & 3)
         self.h_full, self.v_full = h_full, v_full
 
     def flush(self):

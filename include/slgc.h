@@ -190,6 +190,10 @@ int slgc_compact_records_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W,
 #define SLGC_WIRE_MAX_CODE_BITS 11
 int slgc_pack_hv24_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int code_bits, uint8_t *d_wire);
 int slgc_unpack_hv24_dev(slgc_ctx *ctx, const uint8_t *d_wire, size_t npix, int16_t *d_h, int16_t *d_v);
+/* slgc_triangulate_maps_dev on maps that arrive in the wire format: unpacks inside the triangulation kernel's map load and
+ * writes the int16 maps d_h / d_v as well (the separate unpack pass disappears).  mode: SLGC_TRI_EXACT or SLGC_TRI_ALGEBRAIC. */
+int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, int W, int row0, int proj_w, int proj_h, int mode,
+                              int16_t *d_h, int16_t *d_v, float *d_xyz, unsigned long long *d_count);
 
 /* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
 int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,

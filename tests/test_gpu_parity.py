@@ -257,6 +257,36 @@ def test_wire_format_hv24_round_trip(ctx):
         ctx.pack_hv24_dev(buf.ptr, buf.ptr, 4, 12, buf.ptr)            # 12-bit codes do not fit
 
 
+@pytest.mark.parametrize("H,W", [(64, 256), (270, 256), (7, 33)])
+def test_triangulate_wire_equals_unpack_then_triangulate(ctx, calib, H, W):
+    """The triangulation kernel fed with wire-format maps (unpacks in its map load, also writes the int16 maps) == the separate
+    unpack kernel followed by the ordinary triangulation, bit for bit; (7, 33) takes the unpack-first fallback (ragged size)."""
+    N = 26
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=H + W)
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 300.0, 300.0
+    psize = (60, 50)
+    pk = onp.scale_proj_mtx(calib["proj_mtx"], psize, (1920, 1080))
+    ctx.set_calibration(K, calib["cam_dist"], pk, calib["proj_dist"], rot_y(-20.0), np.array([[0.25], [0.02], [0.04]]))
+    hp, vp = oc.decode(st)
+    npix = H * W
+    dh, dv = ctx.alloc(npix * 2).upload(hp.astype(np.int16)), ctx.alloc(npix * 2).upload(vp.astype(np.int16))
+    wire = ctx.alloc(npix * 3 + 16)
+    ctx.pack_hv24_dev(dh.ptr, dv.ptr, npix, 6, wire.ptr)
+    x_ref, x_wire, cnt = ctx.alloc(npix * 12), ctx.alloc(npix * 12), ctx.alloc(8)
+    oh, ov = ctx.alloc(npix * 2).zero(), ctx.alloc(npix * 2).zero()
+    for mode in (0, 1):
+        ctx.triangulate_maps_dev(dh.ptr, dv.ptr, H, W, 0, psize, x_ref.ptr, None, mode=mode)
+        cnt.zero(); oh.zero(); ov.zero()
+        ctx.triangulate_wire_dev(wire.ptr, H, W, 0, psize, oh.ptr, ov.ptr, x_wire.ptr, cnt.ptr, mode=mode)
+        ctx.synchronize()
+        assert np.array_equal(oh.download((H, W), np.int16), hp) and np.array_equal(ov.download((H, W), np.int16), vp)
+        assert np.array_equal(x_wire.download((npix, 3), np.float32), x_ref.download((npix, 3), np.float32), equal_nan=True)
+        assert int(cnt.download((1,), np.uint64)[0]) == int(((hp != -1) & (vp != -1)).sum())
+    for b in (dh, dv, wire, x_ref, x_wire, cnt, oh, ov):
+        b.free()
+
+
 def test_decode_dev_misaligned_band_falls_back_to_narrow_loads(ctx):
     rng = np.random.default_rng(10)
     st = rng.integers(0, 256, (1, 42, 37, 101), dtype=np.uint8)       # W odd: bands start at odd byte offsets
