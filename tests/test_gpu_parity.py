@@ -561,6 +561,17 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
         wh, wv, wx = scw.fetch_dense()
         rh0, rv0, _ = oc.scan_dense(caps[0], psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
         assert np.array_equal(wh, rh0) and np.array_equal(wv, rv0)
+        # 41 scans back to back without touching the host in between (double-buffered maps / wire buffers, two streams, events):
+        # the last result must be the last input's
+        for sc_ in (scm, scw):
+            for j in range(41):
+                sc_.submit(bufs[j % 3].ptr, H * W)
+            sc_.flush()
+            lh, lv, lx = sc_.fetch_dense()
+            rhl, rvl, rxl = oc.scan_dense(caps[40 % 3], psize, K, calib["cam_dist"], pk, calib["proj_dist"], R, T)
+            okl = (rhl != -1) & (rvl != -1)
+            assert np.array_equal(lh, rhl) and np.array_equal(lv, rvl) and np.array_equal(np.isfinite(lx[..., 0]), okl)
+            np.testing.assert_allclose(lx[okl], np.moveaxis(rxl, 0, -1)[okl], rtol=XYZ_RTOL, atol=0)
         with pytest.raises(ValueError):
             sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, 62, wire="hv24")      # L = 15 does not fit
         # the same scan through the one-call C entry point (slgc_scan_sharded_dev)
