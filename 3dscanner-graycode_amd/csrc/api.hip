@@ -177,7 +177,7 @@ extern "C" int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen)
     if (!buf || buflen < 2) return slgc_fail(ctx, SLGC_EINVAL, "bad buffer");
     hipDeviceProp_t p;
     HIP_TRY(ctx, hipGetDeviceProperties(&p, ctx->device));
-    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName, p.multiProcessorCount);   // some boxes report an empty marketing name
     return SLGC_OK;
 }
 
