@@ -22,6 +22,7 @@ int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...)
 int slgc_ws(slgc_ctx *ctx, int slot, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 16;
+    ++ctx->ws_gen[slot];
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -384,6 +385,7 @@ extern "C" int slgc_cam_proj_pts_count(slgc_ctx *ctx, const int64_t *h_pixels, c
     ctx->pend_M = (int64_t)total;
     ctx->pend_npix = npix;
     ctx->pend_colors = white_rgb != nullptr;
+    ctx->pend_gen = ctx->ws_gen[6];
     *M = (int64_t)total;
     return SLGC_OK;
 }
@@ -393,6 +395,10 @@ extern "C" int slgc_cam_proj_pts_fetch(slgc_ctx *ctx, float *cam_pts, float *pro
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (ctx->pend_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending correspondence list (call slgc_cam_proj_pts_count first)");
+    if (ctx->pend_gen != ctx->ws_gen[6]) {
+        ctx->pend_M = -1;
+        return slgc_fail(ctx, SLGC_ESTATE, "the correspondence lists were overwritten by a later call on this context (count again)");
+    }
     const size_t npix = ctx->pend_npix, M = (size_t)ctx->pend_M;
     char *d_out = (char *)ctx->ws[6];
     const double *d_colors = (const double *)d_out;
@@ -452,6 +458,7 @@ extern "C" int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->filt_M = (int64_t)total;
     ctx->filt_colors = colors != nullptr;
+    ctx->filt_gen = ctx->ws_gen[6];
     ctx->pend_M = -1;
     *kept = (int64_t)total;
     return SLGC_OK;
@@ -462,6 +469,10 @@ extern "C" int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (ctx->filt_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending filter result (call slgc_filter_count first)");
+    if (ctx->filt_gen != ctx->ws_gen[6]) {
+        ctx->filt_M = -1;
+        return slgc_fail(ctx, SLGC_ESTATE, "the filter result was overwritten by a later call on this context (count again)");
+    }
     const size_t K = (size_t)ctx->filt_M;
     const double *d_xo = (const double *)ctx->ws[6], *d_co = d_xo + 3 * K;
     if (K) {
@@ -601,6 +612,7 @@ extern "C" int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pend_M = -1;
     ctx->filt_M = -1;
+    ctx->pipe_gen[0] = ctx->ws_gen[3]; ctx->pipe_gen[1] = ctx->ws_gen[8]; ctx->pipe_gen[2] = ctx->ws_gen[9]; ctx->pipe_gen[3] = ctx->ws_gen[10];
     *M = ctx->pipe_M;
     return SLGC_OK;
 }
@@ -611,6 +623,11 @@ extern "C" int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (ctx->pipe_M < 0) return slgc_fail(ctx, SLGC_ESTATE, "no pending pipeline result (call slgc_pipeline_count first)");
+    if (ctx->pipe_gen[0] != ctx->ws_gen[3] || ctx->pipe_gen[1] != ctx->ws_gen[8] || ctx->pipe_gen[2] != ctx->ws_gen[9] ||
+        ctx->pipe_gen[3] != ctx->ws_gen[10]) {
+        ctx->pipe_M = -1;
+        return slgc_fail(ctx, SLGC_ESTATE, "the pipeline result was overwritten by a later call on this context (count again)");
+    }
     const size_t npix = ctx->pipe_npix, M = (size_t)ctx->pipe_M, Mr = (size_t)ctx->pipe_M_raw;
     const int64_t *d_h = (const int64_t *)ctx->ws[3];
     if (npix) {
@@ -753,6 +770,18 @@ extern "C" int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches)
     return SLGC_OK;
 }
 
+extern "C" int slgc_prof_samples(slgc_ctx *ctx, float *ms, int cap, int *n)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!n || cap < 0 || (cap && !ms)) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative capacity");
+    if (ctx->prof_on) return slgc_fail(ctx, SLGC_ESTATE, "slgc_prof_end has not been called");
+    const int m = ctx->prof_n < cap ? ctx->prof_n : cap;
+    for (int i = 0; i < m; ++i) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    *n = ctx->prof_n;
+    return SLGC_OK;
+}
+
 static int dev_geom(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W,
                     double eps, DecodeGeom *g, RunPtrs *runs, int *e)
 {
@@ -821,6 +850,26 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 
+extern "C" int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (rows < 0 || W < 0 || proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad band / projector size");
+    return ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
+}
+
+extern "C" int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
+                                    unsigned long long *d_counts)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_h || !d_v || !d_counts) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (rows < 0 || W < 0 || proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad band / projector size");
+    return launch_guard_count(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, d_counts);
+}
+
 extern "C" int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, int W, int row0, int proj_w, int proj_h, int mode,
                                          int16_t *d_h, int16_t *d_v, float *d_xyz, unsigned long long *d_count)
 {
@@ -883,6 +932,20 @@ extern "C" int slgc_unpack_hv24_dev(slgc_ctx *ctx, const uint8_t *d_wire, size_t
     if (rc) return rc;
     if (!d_h || !d_v || !d_wire) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     return launch_unpack_hv24(ctx, d_wire, npix, d_h, d_v);
+}
+
+extern "C" int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white_rgb,
+                                    int cam_w, int cam_h, int proj_w, int proj_h, float *d_cam_pts, float *d_proj_pts, double *d_pts,
+                                    double *d_colors, unsigned long long *d_total)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_h || !d_v || !d_cam_pts || !d_proj_pts || !d_total) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if ((d_xyz == nullptr) != (d_pts == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "d_xyz and d_pts go together");
+    if (d_colors && !d_white_rgb) return slgc_fail(ctx, SLGC_EINVAL, "colours need the white image");
+    if (cam_w < 0 || cam_h < 0 || proj_w < 1 || proj_h < 1) return slgc_fail(ctx, SLGC_EINVAL, "bad size");
+    return launch_cloud_lists(ctx, d_h, d_v, d_xyz, d_colors ? d_white_rgb : nullptr, cam_w, cam_h, proj_w, proj_h, d_cam_pts, d_proj_pts, d_pts,
+                              d_colors, d_total);
 }
 
 extern "C" int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,

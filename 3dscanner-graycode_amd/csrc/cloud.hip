@@ -4,15 +4,97 @@
 // included, as Open3D's KD-tree query returns it).  Open3D is third-party and not installed in the build container:
 // parity with Open3D is UNPINNED; the kernel is exact k-NN and is checked against scipy's cKDTree.
 //
-// K7  uniform-grid exact k-NN: points are binned into cubic cells of edge s (counting sort: atomics + hipcub scan), every
+// K7  uniform-grid exact k-NN: points are binned into cubic cells of edge s (counting sort: atomics + the exclusive scan below), every
 //     query scans the 3x3x3 block around its cell keeping the K smallest squared distances in registers (static insertion
 //     network, no dynamic register indexing).  A result is exact when its k-th distance <= s (nothing outside the block can
 //     be closer); the others are retried with the cell edge doubled until all are exact.
-#include <hipcub/hipcub.hpp>
-
 #include "slgc_internal.h"
 
 namespace {
+
+// ---- exclusive prefix sum of uint32 (cell counts -> cell starts) -------------------------------------------------------------
+// Three-level reduce-then-scan: a 256-thread workgroup owns a tile of 2048 consecutive elements (8 per lane, two 16-byte loads);
+// pass 1 writes every tile's sum, the sums are scanned recursively (33.5 M cells -> 16 385 tile sums -> 9 -> 1), pass 2 rescans
+// each tile from its prefix.  Inside a tile: per-lane serial prefix, wave64 inclusive scan with __shfl_up, wave totals through LDS.
+constexpr int kScanTile = 2048;
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned &block_total)
+{
+    __shared__ unsigned wtot[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    block_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();                                   // wtot is reused by the caller's next call
+    return before + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const unsigned *__restrict__ in, size_t n, unsigned *__restrict__ sums)
+{
+    const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (base + j < n) ? in[base + j] : 0u;
+    unsigned total;
+    (void)block_exclusive_scan_256(s, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// prefix == nullptr: single tile (top level).  total (optional) receives the grand total from the last tile.
+__global__ void __launch_bounds__(256) k_scan_tiles(const unsigned *__restrict__ in, size_t n, const unsigned *__restrict__ prefix,
+                                                    unsigned *__restrict__ out)
+{
+    const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * 8;
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = (base + j < n) ? in[base + j] : 0u;
+        s += v[j];
+    }
+    unsigned total;
+    unsigned run = block_exclusive_scan_256(s, total) + (prefix ? prefix[blockIdx.x] : 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+}
+
+// out[i] = in[0] + ... + in[i-1], i < n.  scratch: >= scan_scratch_elems(n) uint32.  in and out must not overlap.
+size_t scan_scratch_elems(size_t n)
+{
+    size_t t = 0;
+    while (n > (size_t)kScanTile) {
+        n = (n + kScanTile - 1) / kScanTile;
+        t += 2 * n;                                     // tile sums + their scan
+    }
+    return t + 16;
+}
+
+int exclusive_scan_u32(slgc_ctx *ctx, const unsigned *d_in, unsigned *d_out, size_t n, unsigned *d_scratch)
+{
+    if (n == 0) return SLGC_OK;
+    const size_t tiles = (n + kScanTile - 1) / kScanTile;
+    if (tiles == 1) {
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(256), 0, ctx->stream, d_in, n, (const unsigned *)nullptr, d_out);
+    } else {
+        unsigned *sums = d_scratch, *sums_scanned = d_scratch + tiles;
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, d_in, n, sums);
+        int rc = exclusive_scan_u32(ctx, sums, sums_scanned, tiles, d_scratch + 2 * tiles);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, d_in, n, (const unsigned *)sums_scanned, d_out);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
 
 struct Grid {
     float ox, oy, oz, inv_s;
@@ -121,6 +203,7 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     if (M < 0 || k < 1 || k > 64 || (M && (!pts || !mean))) return slgc_fail(ctx, SLGC_EINVAL, "bad arguments (1 <= k <= 64)");
     if (M == 0) return SLGC_OK;
     if (M > 0x7fffffffll) return slgc_fail(ctx, SLGC_EINVAL, "too many points");
+    if ((int64_t)k > M) return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
     // bounding box on the host (the points come from the host anyway)
     float lo[3] = {pts[0], pts[1], pts[2]}, hi[3] = {pts[0], pts[1], pts[2]};
     for (int64_t i = 0; i < M; ++i)
@@ -171,17 +254,18 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
         HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));
         hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, g,
                            (unsigned *)d_counts, (unsigned *)d_cellof);
-        size_t tmp_bytes = 0;
-        HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (unsigned *)d_counts, (unsigned *)d_start, (int)(ncell + 1), ctx->stream));
-        if ((rc = slgc_ws(ctx, 6, tmp_bytes + 16, &d_tmp))) return rc;
-        HIP_TRY(ctx, hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, (unsigned *)d_counts, (unsigned *)d_start, (int)(ncell + 1), ctx->stream));
+        if ((rc = slgc_ws(ctx, 6, scan_scratch_elems(ncell + 1) * 4, &d_tmp))) return rc;
+        if ((rc = exclusive_scan_u32(ctx, (const unsigned *)d_counts, (unsigned *)d_start, ncell + 1, (unsigned *)d_tmp))) return rc;
         HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));          // reused as the fill cursor
         hipLaunchKernelGGL(k_cell_fill, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M,
                            (const unsigned *)d_cellof, (const unsigned *)d_start, (unsigned *)d_counts, (float4 *)d_sorted);
         HIP_TRY(ctx, hipMemsetAsync(d_nun, 0, 4, ctx->stream));
         const unsigned *cs = (const unsigned *)d_start, *ce = cs + 1;                     // cell_end[c] = cell_start[c + 1]
         unsigned *d_out = (unsigned *)d_unres[cur];
-        const float s_safe = (float)(0.999 / (double)g.inv_s);      // the radius the 3x3x3 block is guaranteed to cover, float rounding included
+        // the radius the 3x3x3 block is guaranteed to cover, float rounding included; a single-cell grid holds every point, so the
+        // scan is exhaustive there and every result is exact whatever its k-th distance (small clouds with k close to M)
+        const bool one_cell = g.nx == 1 && g.ny == 1 && g.nz == 1;
+        const float s_safe = one_cell ? __builtin_huge_valf() : (float)(0.999 / (double)g.inv_s);
         if (k <= 20) launch_knn<20>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
         else if (k <= 32) launch_knn<32>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
         else launch_knn<64>(ctx, (const float *)d_pts, d_q, nq, g, s_safe, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out, (unsigned *)d_nun);
@@ -189,12 +273,10 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
         unsigned nun = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&nun, d_nun, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if ((int64_t)k > M && g.nx == 1 && g.ny == 1 && g.nz == 1)
-            return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
         nq = nun;
         d_q = d_out;
         cur ^= 1;
-        if (g.nx == 1 && g.ny == 1 && g.nz == 1 && nq) return slgc_fail(ctx, SLGC_EINVAL, "k-NN did not converge (k > number of points?)");
+        if (one_cell && nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN: %zu queries unresolved on a single-cell grid (internal error)", nq);
     }
     if (nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN left %zu points unresolved", nq);
     HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -16,7 +16,8 @@ constexpr int kChunkRows = 32;
 __device__ __forceinline__ bool decodable(int64_t h, int64_t v) { return !(h == -1 || v == -1); }  // :56
 
 // ---- x-major: pass A, per (chunk, column) counts ----
-__global__ void __launch_bounds__(256) k_xmajor_count(const int64_t *__restrict__ h, const int64_t *__restrict__ v, int W, int H,
+template <typename MapT>
+__global__ void __launch_bounds__(256) k_xmajor_count(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H,
                                                       unsigned *__restrict__ counts)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -81,14 +82,20 @@ __global__ void __launch_bounds__(1024) k_xmajor_colscan(int W, unsigned long lo
 constexpr int kTileCols = 64;
 constexpr int kInvalid = (int)0x80000000;
 
-__global__ void __launch_bounds__(256) k_xmajor_scatter(const int64_t *__restrict__ h, const int64_t *__restrict__ v, int W, int H,
+// XYZ = true (device-resident product, slgc_cloud_lists_dev): the dense float32 XYZ of the scan rides through the same transpose and
+// leaves as the reference's float64 (3,M) array (triangulate.py:95; M = *total, written by the column scan before this kernel runs).
+template <typename MapT, bool XYZ>
+__global__ void __launch_bounds__(256) k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H,
                                                         int proj_w, int proj_h, const uint8_t *__restrict__ white,
                                                         const unsigned *__restrict__ counts,
                                                         const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
-                                                        float *__restrict__ proj, double *__restrict__ colors)
+                                                        float *__restrict__ proj, double *__restrict__ colors,
+                                                        const float *__restrict__ xyz, double *__restrict__ pts,
+                                                        const unsigned long long *__restrict__ total)
 {
     __shared__ int s_pu[kChunkRows][kTileCols + 1], s_pv[kChunkRows][kTileCols + 1];
     __shared__ unsigned s_rgb[kChunkRows][kTileCols + 1];
+    __shared__ float s_xyz[XYZ ? 3 : 1][kChunkRows][kTileCols + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x_tile = blockIdx.x * kTileCols, chunk = blockIdx.y, y_tile = chunk * kChunkRows;
 #pragma unroll
@@ -104,6 +111,11 @@ __global__ void __launch_bounds__(256) k_xmajor_scatter(const int64_t *__restric
                 pv = (int)(vv < proj_h - 1 ? vv : proj_h - 1);                  // :61
                 if (pu == kInvalid) pu = kInvalid + 1;
                 if (colors) rgb = (unsigned)white[3 * p] | ((unsigned)white[3 * p + 1] << 8) | ((unsigned)white[3 * p + 2] << 16);
+                if constexpr (XYZ) {
+                    s_xyz[0][r][lane] = xyz[3 * p];
+                    s_xyz[1][r][lane] = xyz[3 * p + 1];
+                    s_xyz[2][r][lane] = xyz[3 * p + 2];
+                }
             }
         }
         s_pu[r][lane] = pu;
@@ -128,6 +140,12 @@ __global__ void __launch_bounds__(256) k_xmajor_scatter(const int64_t *__restric
                 colors[3 * o] = (double)(rgb & 0xffu) / 255.0;                   // :64, :69
                 colors[3 * o + 1] = (double)((rgb >> 8) & 0xffu) / 255.0;
                 colors[3 * o + 2] = (double)((rgb >> 16) & 0xffu) / 255.0;
+            }
+            if constexpr (XYZ) {
+                const unsigned long long M = *total;
+                pts[o] = (double)s_xyz[0][r][c];                                 // Pts (3,M) float64, :95
+                pts[M + o] = (double)s_xyz[1][r][c];
+                pts[2 * M + o] = (double)s_xyz[2][r][c];
             }
         }
     }
@@ -331,15 +349,48 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
     rc = slgc_ws(ctx, 5, ((size_t)cam_w + 1) * sizeof(unsigned long long), &colstart);
     if (rc) return rc;
     const dim3 grid((cam_w + 255) / 256, nchunks);
-    if (npix) hipLaunchKernelGGL(k_xmajor_count, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
+    if (npix) hipLaunchKernelGGL(k_xmajor_count<int64_t>, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
     if (cam_w)
         hipLaunchKernelGGL(k_xmajor_colprefix, dim3((cam_w + 255) / 256), dim3(256), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
                            (unsigned long long *)colstart);
     hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
     if (npix)
-        hipLaunchKernelGGL(k_xmajor_scatter, dim3((cam_w + kTileCols - 1) / kTileCols, nchunks), dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h,
-                           proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj,
-                           d_white ? d_colors : nullptr);
+        hipLaunchKernelGGL((k_xmajor_scatter<int64_t, false>), dim3((cam_w + kTileCols - 1) / kTileCols, nchunks), dim3(256), 0, ctx->stream, d_h, d_v,
+                           cam_w, cam_h, proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj,
+                           d_white ? d_colors : nullptr, (const float *)nullptr, (double *)nullptr, (const unsigned long long *)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+// Device-resident form of the reference-shaped product (slgc_cloud_lists_dev): int16 maps + dense float32 XYZ (+ white image) ->
+// x-major cam_pts / proj_pts float32 [M][2], Pts float64 (3,M), colors float64 [M][3]; nothing synchronises with the host.
+int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white, int cam_w, int cam_h,
+                       int proj_w, int proj_h, float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total)
+{
+    const size_t npix = (size_t)cam_w * cam_h;
+    const int nchunks = (cam_h + kChunkRows - 1) / kChunkRows;
+    void *counts, *colstart;
+    int rc = slgc_ws(ctx, 4, ((size_t)nchunks * cam_w + 1) * sizeof(unsigned), &counts);
+    if (rc) return rc;
+    rc = slgc_ws(ctx, 5, ((size_t)cam_w + 1) * sizeof(unsigned long long), &colstart);
+    if (rc) return rc;
+    const dim3 grid((cam_w + 255) / 256, nchunks);
+    if (npix) hipLaunchKernelGGL(k_xmajor_count<int16_t>, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
+    if (cam_w)
+        hipLaunchKernelGGL(k_xmajor_colprefix, dim3((cam_w + 255) / 256), dim3(256), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
+                           (unsigned long long *)colstart);
+    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
+    if (npix) {
+        const dim3 sgrid((cam_w + kTileCols - 1) / kTileCols, nchunks);
+        if (d_xyz && d_pts)
+            hipLaunchKernelGGL((k_xmajor_scatter<int16_t, true>), sgrid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white,
+                               (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_white ? d_colors : nullptr, d_xyz, d_pts,
+                               (const unsigned long long *)d_total);
+        else
+            hipLaunchKernelGGL((k_xmajor_scatter<int16_t, false>), sgrid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white,
+                               (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_white ? d_colors : nullptr,
+                               (const float *)nullptr, (double *)nullptr, (const unsigned long long *)nullptr);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

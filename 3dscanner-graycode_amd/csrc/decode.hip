@@ -731,13 +731,18 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
     const uint32_t groups = a.npix / PX;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + BLOCK - 1) / BLOCK;
+#ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     if (abl == 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), a);
     else if (abl == 2)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), a);
     else if (abl == 3)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), a);
-    else if (a.g.n_runs > 1)
+    else
+#else
+    if (abl != 0) return slgc_fail(ctx, SLGC_EINVAL, "ablation variants exist only in the diagnostic build (make -C 3dscanner-graycode_amd diag)");
+#endif
+    if (a.g.n_runs > 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), a);
     else
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), a);
@@ -764,13 +769,15 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + 127) / 128;
-    const char *abl_env = getenv("SLGC_FUSE_ABL");
-    const int fabl = abl_env ? atoi(abl_env) : 0;
+#ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
+    static const int fabl = xcd_env("SLGC_FUSE_ABL", 0);
     if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), b);
     else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), b);
     else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), b);
     else if (fabl == 8) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 8, true>), dim3(blocks), dim3(128), b);
-    else if (g.n_runs > 1)
+    else
+#endif
+    if (g.n_runs > 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), b);
     else
         SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), b);

@@ -47,6 +47,8 @@ struct slgc_ctx {
     // workspace (grown on demand, reused across calls)
     void *ws[SLGC_WS_SLOTS];
     size_t ws_bytes[SLGC_WS_SLOTS];
+    unsigned ws_gen[SLGC_WS_SLOTS];   // bumped every time a slot is handed out (slgc_ws): a *_fetch checks that the slots holding its
+                                      // pending result have not been handed to another call since its *_count (SLGC_ESTATE otherwise)
     // calibration
     bool have_calib;
     Calib calib;
@@ -60,12 +62,15 @@ struct slgc_ctx {
     int64_t pend_M;
     size_t pend_npix;
     bool pend_colors;
+    unsigned pend_gen;      // ws_gen[6] when the correspondence lists were written
     int64_t filt_M;
     bool filt_colors;
+    unsigned filt_gen;      // ws_gen[6] when the filter result was written
     // slgc_pipeline_* results kept on the device between _count and _fetch
     int64_t pipe_M, pipe_M_raw;
     size_t pipe_npix;
     bool pipe_colors, pipe_filtered;
+    unsigned pipe_gen[4];   // ws_gen of slots 3, 8, 9, 10 when the pipeline result was written
     // per-launch HIP-event timing of the decode kernel (slgc_prof_*), recorded on the launch stream
     bool prof_on;
     hipEvent_t *prof_ev;   // pairs: [2i] before, [2i+1] after the decode launch
@@ -116,6 +121,8 @@ int launch_widen_maps(slgc_ctx *ctx, const int16_t *d_h16, const int16_t *d_v16,
 int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,
                       const uint8_t *d_white, int order, float *d_cam, float *d_proj, double *d_colors,
                       unsigned long long *d_total);
+int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white, int cam_w, int cam_h,
+                       int proj_w, int proj_h, float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total);
 int launch_filter(slgc_ctx *ctx, const double *d_xyz, const double *d_colors, int64_t M, double thr, double *d_xyz_out,
                   double *d_colors_out, unsigned long long *d_total, int pass);
 int launch_compact_dense(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
@@ -125,6 +132,8 @@ int launch_compact_records(slgc_ctx *ctx, const float *d_xyz, int rows, int W, i
 int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz);
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
                             int proj_h, int mode, float *d_xyz, unsigned long long *d_count, const uint8_t *d_wire = nullptr);
+int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
+                       unsigned long long *d_counts);
 // synth.hip
 int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
                  int noise, int shadow);

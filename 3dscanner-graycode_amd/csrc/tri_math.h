@@ -65,6 +65,41 @@ __device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const do
 // for the two comparisons only and the instruction stream holds a single copy of the float32 divide / sqrt expansions.
 // valid: bit j set = pixel j decodable; out = x0 y0 z0 x1 ... (NaN where not decodable).  GUARD = false: fast form everywhere.
 // cam4 / proj_lut + idx: where the lane's rays came from -- the rare path reads them again instead of keeping 16 registers alive.
+// Terms of the cancelled form for one pixel (shared by triangulate4 and the guard-count diagnostic so both apply the same test).
+struct TriTerms {
+    double ta, tb, ra, rb, Sb, D;
+};
+
+__device__ __forceinline__ TriTerms tri_terms(float cxf, float cyf, float pxf, float pyf, const double (&T)[3], double tl2)
+{
+    const double dcx = cxf, dcy = cyf, dpx = pxf, dpy = pyf;
+    const double A = -fma(T[0], dcx, fma(T[1], dcy, T[2]));
+    const double B = fma(T[0], dpx, fma(T[1], dpy, T[2]));
+    TriTerms t;
+    t.ta = tl2 * fma(dcx, dcx, fma(dcy, dcy, 1.0));
+    t.tb = tl2 * fma(dpx, dpx, fma(dpy, dpy, 1.0));
+    t.ra = fma(-A, A, t.ta);
+    t.rb = fma(-B, B, t.tb);
+    const double Sa = fast_sqrt(t.ra);
+    t.Sb = fast_sqrt(t.rb);
+    t.D = fma(Sa, B, A * t.Sb);
+    return t;
+}
+
+// |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], where eps bounds the error of
+// cos(alpha), cos(beta) caused by the float32 steps of the reference (sqrt and three divisions for NormedL, one sqrt for
+// the projector norm: <= 3 * 2^-24 = 1.8e-7).  A pixel is "flat" (redone on the reference's float32 intermediates) when either
+// term can pass 200: the fast form is then never further than 2 * 200 * 1.8e-7 = 7.2e-5 from the reference, inside the 1e-4
+// tolerance even if every rounding aligns.
+//   sin^2(beta) < 5e-3                             <=>  rb < k1 * tb
+//   min(sin a, sin b)^2 * sin^2(gamma) < 1e-4      <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
+__device__ __forceinline__ bool tri_is_flat(const TriTerms &t)
+{
+    constexpr double k1 = 5e-3, k2 = 1e-4;
+    const double tatb = t.ta * t.tb;
+    return (t.rb < k1 * t.tb) | ((t.D * t.D) * fmin(t.ra * t.tb, t.rb * t.ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
+}
+
 template <bool GUARD>
 __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
                                              uint32_t valid, const double (&T)[3], double t_len, float (&out)[12],
@@ -74,26 +109,9 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
     uint32_t ill = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double dcx = cx[j], dcy = cy[j], dpx = px[j], dpy = py[j];
-        const double A = -fma(T[0], dcx, fma(T[1], dcy, T[2]));
-        const double B = fma(T[0], dpx, fma(T[1], dpy, T[2]));
-        const double ta = tl2 * fma(dcx, dcx, fma(dcy, dcy, 1.0)), tb = tl2 * fma(dpx, dpx, fma(dpy, dpy, 1.0));
-        const double ra = fma(-A, A, ta), rb = fma(-B, B, tb);
-        const double Sa = fast_sqrt(ra), Sb = fast_sqrt(rb);
-        const double D = fma(Sa, B, A * Sb);
-        const float s = (float)(tl2 * Sb * fast_rcp(D));
-        if (GUARD) {
-            // |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], where eps bounds the error of
-            // cos(alpha), cos(beta) caused by the float32 steps of the reference (sqrt and three divisions for NormedL, one sqrt for
-            // the projector norm: <= 3 * 2^-24 = 1.8e-7).  Redo the pixel when either term can pass 200: the fast form is then
-            // never further than 2 * 200 * 1.8e-7 = 7.2e-5 from the reference, inside the 1e-4 tolerance even if every rounding aligns.
-            //   sin^2(beta) < 5e-3                             <=>  rb < k1 * tb
-            //   min(sin a, sin b)^2 * sin^2(gamma) < 1e-4      <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
-            constexpr double k1 = 5e-3, k2 = 1e-4;
-            const double tatb = ta * tb;
-            const bool bad = (rb < k1 * tb) | ((D * D) * fmin(ra * tb, rb * ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
-            ill |= bad ? (1u << j) : 0u;
-        }
+        const TriTerms t = tri_terms(cx[j], cy[j], px[j], py[j], T, tl2);
+        const float s = (float)(tl2 * t.Sb * fast_rcp(t.D));
+        if (GUARD) ill |= tri_is_flat(t) ? (1u << j) : 0u;
         const bool ok = (valid >> j) & 1u;
         out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
         out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");

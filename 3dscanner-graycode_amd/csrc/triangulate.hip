@@ -292,7 +292,47 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     if (count) block_count_add(count, nvalid);
 }
 
+// Diagnostic: how many decodable pixels of a band take the guarded (float32-mirror) path of triangulate4 -- the same
+// tri_is_flat test on the same table rays.  counts[0] += decodable pixels, counts[1] += flagged pixels.
+__global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const int16_t *__restrict__ h, const int16_t *__restrict__ v,
+                                                     const float2 *__restrict__ cam_lut, const float2 *__restrict__ proj_lut, size_t npix,
+                                                     int proj_w, int proj_h, int tiles_x, unsigned long long *__restrict__ counts)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned ok = 0, flat = 0;
+    if (p < npix) {
+        const int hv = h[p], vv = v[p];
+        if (!(hv == -1 || vv == -1)) {
+            ok = 1;
+            const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x)];
+            flat = tri_is_flat(tri_terms(c.x, c.y, q.x, q.y, tc.T, tc.t_len * tc.t_len)) ? 1u : 0u;
+        }
+    }
+    unsigned packed = ok | (flat << 16);                       // 64 lanes: both sums fit 16 bits
+    for (int o = 32; o > 0; o >>= 1) packed += __shfl_down(packed, o, 64);
+    if ((threadIdx.x & 63) == 0 && packed) {
+        atomicAdd(counts, (unsigned long long)(packed & 0xffffu));
+        if (packed >> 16) atomicAdd(counts + 1, (unsigned long long)(packed >> 16));
+    }
+}
+
 }  // namespace
+
+int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
+                       unsigned long long *d_counts)
+{
+    const size_t npix = (size_t)rows * W;
+    if (npix == 0) return SLGC_OK;
+    int rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
+    if (rc) return rc;
+    TriConst tc;
+    memcpy(tc.T, ctx->calib.T, sizeof tc.T);
+    tc.t_len = ctx->calib.t_len;
+    hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
+                       (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, (proj_w + 7) / 8, d_counts);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
 
 int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz)
 {
@@ -388,9 +428,11 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+#ifdef SLGC_DIAG      // A/B of the guard's cost: only in the diagnostic build
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
             hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+#endif
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "slgc_selftest_thresholds": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "slgc_selftest_classify": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "slgc_cloud_lists_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slgc_pack_hv24_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
@@ -75,6 +76,9 @@ SIGNATURES = {
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "slgc_prof_begin": (_i, [_vp, _i, _i]),
     "slgc_prof_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
+    "slgc_prof_samples": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
+    "slgc_build_ray_tables_dev": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "slgc_guard_count_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "slgc_comm_unique_id": (_i, [_vp]),
     "slgc_comm_init": (_i, [_vp, _i, _i, _vp]),
     "slgc_comm_destroy": (_i, [_vp]),
@@ -165,6 +169,36 @@ class DeviceBuffer:
                 self.ctx._buffers.remove(self)
 
 
+class CloudLists:
+    """Device buffers of the reference-shaped product (slgc_cloud_lists_dev): capacity ``npix`` entries each."""
+
+    def __init__(self, ctx: "Context", npix: int, colors: bool = True, points: bool = True):
+        self.ctx, self.npix = ctx, int(npix)
+        self.cam = ctx.alloc(max(16, self.npix * 8))
+        self.proj = ctx.alloc(max(16, self.npix * 8))
+        self.pts = ctx.alloc(max(16, self.npix * 24)) if points else None
+        self.colors = ctx.alloc(max(16, self.npix * 24)) if colors else None
+        self.count = ctx.alloc(8).zero()
+
+    def total(self) -> int:
+        """M of the last build (synchronises)."""
+        self.ctx.synchronize()
+        return int(self.count.download((1,), np.uint64)[0])
+
+    def download(self):
+        """-> (cam_pts f32 [M,2], proj_pts f32 [M,2], Pts f64 (3,M) or None, colors f64 [M,3] or None), as the reference returns them."""
+        M = self.total()
+        cam, proj = self.cam.download((M, 2), np.float32), self.proj.download((M, 2), np.float32)
+        pts = self.pts.download((3, M), np.float64) if self.pts is not None else None
+        col = self.colors.download((M, 3), np.float64) if self.colors is not None else None
+        return cam, proj, pts, col
+
+    def free(self):
+        for b in (self.cam, self.proj, self.pts, self.colors, self.count):
+            if b is not None:
+                b.free()
+
+
 class Context:
     """(device, HIP stream, workspace).  One per thread; calls on one context are serialised by the caller."""
 
@@ -209,6 +243,9 @@ class Context:
 
     def synchronize(self):
         self._ck(lib().slgc_synchronize(self._h))
+
+    def dev_memset(self, dptr: int, value: int, nbytes: int):
+        self._ck(lib().slgc_dev_memset(self._h, dptr, int(value), int(nbytes)))
 
     def device_name(self) -> str:
         buf = C.create_string_buffer(256)
@@ -430,6 +467,17 @@ class Context:
         self._ck(lib().slgc_triangulate_maps_dev(self._h, d_h, d_v, rows, W, row0, int(proj_size[0]), int(proj_size[1]),
                                                  int(mode), d_xyz, d_count))
 
+    def alloc_cloud_lists(self, npix: int, colors: bool = True, points: bool = True) -> CloudLists:
+        return CloudLists(self, npix, colors, points)
+
+    def cloud_lists_dev(self, d_h: int, d_v: int, d_xyz, d_white, cam_w, cam_h, proj_size, lists: CloudLists):
+        """int16 maps + dense float32 XYZ (+ device-resident uint8 RGB white image) -> the reference's x-major lists, float64 (3,M)
+        points and colours, all in HBM (asynchronous).  d_xyz / d_white may be None."""
+        self._ck(lib().slgc_cloud_lists_dev(self._h, d_h, d_v, d_xyz if lists.pts is not None else None,
+                                            d_white if lists.colors is not None else None, int(cam_w), int(cam_h), int(proj_size[0]),
+                                            int(proj_size[1]), lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
+                                            lists.colors.ptr if lists.colors is not None else None, lists.count.ptr))
+
     def compact_dev(self, d_xyz: int, rows, W, row0, d_points: int, d_keys, d_count: int):
         self._ck(lib().slgc_compact_dev(self._h, d_xyz, rows, W, row0, d_points, d_keys, d_count))
 
@@ -460,6 +508,23 @@ class Context:
         ms, n = C.c_double(), C.c_int()
         self._ck(lib().slgc_prof_end(self._h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    def prof_samples(self) -> np.ndarray:
+        """Kernel durations (ms) of the launches sampled between the last prof_begin / prof_end, in launch order."""
+        n = C.c_int()
+        self._ck(lib().slgc_prof_samples(self._h, None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 0), np.float32)
+        if n.value:
+            self._ck(lib().slgc_prof_samples(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def build_ray_tables_dev(self, rows, W, row0, proj_size):
+        """Per-calibration ray tables of the dense path (asynchronous); built on first use otherwise."""
+        self._ck(lib().slgc_build_ray_tables_dev(self._h, int(rows), int(W), int(row0), int(proj_size[0]), int(proj_size[1])))
+
+    def guard_count_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_counts: int):
+        """d_counts[0] += decodable pixels, d_counts[1] += pixels on the guarded (float32-mirror) triangulation path."""
+        self._ck(lib().slgc_guard_count_dev(self._h, d_h, d_v, int(rows), int(W), int(row0), int(proj_size[0]), int(proj_size[1]), d_counts))
 
     # ---- RCCL
     @staticmethod

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from .._native import default_context
+from ._native import default_context
 
 __all__ = ["remove_statistical_outlier", "write_ply", "save_point_cloud"]
 

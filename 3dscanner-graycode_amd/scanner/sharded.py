@@ -6,11 +6,14 @@ rank r decodes + triangulates rows [row0, row0+rows) of every frame, compacts it
 reassembled cloud.  Band-major concatenation == row-major order of the full image; the reference's
 x-major order (triangulate.py:52-53) is recovered from the keys (:func:`x_major_permutation`).
 
-Two exchange strategies, both ending with the whole cloud on every rank:
+Three exchange strategies, all ending with the whole cloud on every rank:
 
 * ``exchange="maps"`` (default): the ranks all-gather(v) their int16 (h, v) map bands -- 4 B/pixel, sizes known from the
   plan, so no count exchange and no host synchronisation -- and every rank triangulates the full maps itself (the dense
   triangulation kernel is ~70 us for 4096x3000, far cheaper than moving 12 B/pixel of XYZ over xGMI).
+* ``exchange="xyz"``: each rank runs the FUSED kernel (decode with the triangulation tail) on its band, straight into its slot
+  of full-size maps and XYZ, and the ranks all-gather the three band sets in place (16 B/pixel, fixed sizes, no counts, no
+  replicated triangulation).
 * ``exchange="records"``: each rank triangulates and compacts its band into 16-byte records {x, y, z, key} and the ranks
   all-gatherv those (a count all-gather first; 16 B per VALID pixel).
 
@@ -182,12 +185,13 @@ class ShardedScanner:
     on the communication stream while the compute stream triangulates scan i-1 and decodes scan i+1 (two sets of map buffers)."""
 
     def __init__(self, ctx, exchange, plan: ShardPlan, proj_size, n_frames: int, mode: int = 1, exchange_kind: str = "maps",
-                 wire: str = "auto"):
-        """wire ("maps" strategy): "int16" sends the two int16 maps as they are (4 B/pixel); "hv24" packs them into 3 B/pixel
-        for the exchange (codes of <= 11 bits) and unpacks on arrival -- the exchange bounds a sharded scan, so fewer bytes on
-        the links is worth two small streaming kernels; "auto" = hv24 when there is more than one rank and the codes fit."""
-        if exchange_kind not in ("maps", "records"):
-            raise ValueError("exchange_kind must be 'maps' or 'records'")
+                 wire: str = "int16"):
+        """wire ("maps" strategy): "int16" (default) sends the two int16 maps as they are (4 B/pixel); "hv24" packs them into
+        3 B/pixel for the exchange (codes of <= 11 bits) and unpacks on arrival -- fewer bytes on the links for two small streaming
+        kernels; "auto" = hv24 when there is more than one rank and the codes fit.  EXPERIMENTAL until measured on real xGMI: int16
+        stays the default because no multi-GPU box has run either yet."""
+        if exchange_kind not in ("maps", "records", "xyz"):
+            raise ValueError("exchange_kind must be 'maps', 'xyz' or 'records'")
         if wire not in ("auto", "int16", "hv24"):
             raise ValueError("wire must be 'auto', 'int16' or 'hv24'")
         from ._native import WIRE_MAX_CODE_BITS
@@ -212,6 +216,12 @@ class ShardedScanner:
             self._submitted = 0
             self._pending = None
             self._pair = False
+        elif exchange_kind == "xyz":
+            self.wire = "int16"
+            self._sets = [(ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 12))) for _ in range(2)]
+            self.h_full, self.v_full, self.xyz_full = self._sets[0]
+            self._submitted = 0
+            self._pending = None
         else:
             self.maps = ctx.alloc(max(16, band_px * 4))
             self.xyz = ctx.alloc(max(16, band_px * 12))
@@ -247,11 +257,60 @@ class ShardedScanner:
         displs = [row0 * W * 3 for row0, _ in self.plan.bands()]
         self.exchange.allgatherv_begin(wire.at(displs[self.rank]), wire, counts, displs, slot)
 
-    def submit(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
-        """Pipelined "maps" scan: decode this scan's band, start its exchange on the communication stream, then finish the
-        PREVIOUS scan (wait for its exchange, triangulate).  Call :meth:`flush` after the last one.  No host synchronisation."""
+    def _band_layouts(self, *bytes_per_px):
+        return [([rows * self.plan.W * b for _, rows in self.plan.bands()], [row0 * self.plan.W * b for row0, _ in self.plan.bands()])
+                for b in bytes_per_px]
+
+    def _submit_xyz(self, d_band_stack: int, plane_stride: int, n_runs: int, run_stride: int, eps):
+        """Fused kernel on the band, straight into this rank's slot of set s; in-place all-gather of the three band sets (slots 2s,
+        2s+1 of the communication stream's events); the previous scan only has to be waited for."""
+        c, W = self.ctx, self.plan.W
+        s = self._submitted % 2
+        h_full, v_full, xyz_full = self._sets[s]
+        px0 = self.row0 * W
+        if self.rows:
+            c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0, self.proj_size,
+                       xyz_full.at(px0 * 12), None, h_full.at(px0 * 2), v_full.at(px0 * 2), eps=eps, mode=self.mode)
+        (mc, md), (xc, xd) = self._band_layouts(2, 12)
+        self.exchange.allgatherv_pair_begin(h_full.at(md[self.rank]), h_full, v_full.at(md[self.rank]), v_full, mc, md, 2 * s)
+        self.exchange.allgatherv_begin(xyz_full.at(xd[self.rank]), xyz_full, xc, xd, 2 * s + 1)
+        if self._pending is not None:
+            self._finish(self._pending)
+        self._pending = s
+        self._submitted += 1
+
+    def compute_only(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
+        """The kernels of one sharded scan on this rank WITHOUT the exchange (bench.py: what the links have to keep up with).  The
+        maps / XYZ it leaves behind are not a reassembled result."""
+        c, W = self.ctx, self.plan.W
+        px0 = self.row0 * W
+        if self.kind == "xyz":
+            h_full, v_full, xyz_full = self._sets[0]
+            if self.rows:
+                c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0, self.proj_size,
+                           xyz_full.at(px0 * 12), None, h_full.at(px0 * 2), v_full.at(px0 * 2), eps=eps, mode=self.mode)
+            return
         if self.kind != "maps":
-            raise ValueError("submit()/flush() pipeline the 'maps' strategy")
+            raise ValueError("compute_only() covers the 'maps' and 'xyz' strategies")
+        h_full, v_full = self._sets[0]
+        if self.rows:
+            c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
+                         h_full.at(px0 * 2), v_full.at(px0 * 2), eps=eps)
+        if self.wire == "hv24":
+            if self.rows:
+                c.pack_hv24_dev(h_full.at(px0 * 2), v_full.at(px0 * 2), self.rows * W, self.code_bits, self._wire[0].at(px0 * 3))
+            c.triangulate_wire_dev(self._wire[0].ptr, self.plan.H, W, 0, self.proj_size, h_full.ptr, v_full.ptr, self.xyz_full.ptr, None, mode=self.mode & 1)
+        else:
+            c.triangulate_maps_dev(h_full.ptr, v_full.ptr, self.plan.H, W, 0, self.proj_size, self.xyz_full.ptr, None, mode=self.mode & 3)
+
+    def submit(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
+        """Pipelined scan ("maps": decode this scan's band, start its exchange on the communication stream, then finish the
+        PREVIOUS scan -- wait for its exchange, triangulate; "xyz": fused kernel on the band, start the exchange, wait for the
+        previous one).  Call :meth:`flush` after the last one.  No host synchronisation."""
+        if self.kind == "xyz":
+            return self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
+        if self.kind != "maps":
+            raise ValueError("submit()/flush() pipeline the 'maps' and 'xyz' strategies")
         c, W = self.ctx, self.plan.W
         s = self._submitted % 2
         h_full, v_full = self._sets[s]
@@ -275,6 +334,11 @@ class ShardedScanner:
         self._submitted += 1
 
     def _finish(self, s: int):
+        if self.kind == "xyz":
+            self.exchange.wait(2 * s)
+            self.exchange.wait(2 * s + 1)
+            self.h_full, self.v_full, self.xyz_full = self._sets[s]
+            return
         h_full, v_full = self._sets[s]
         self.exchange.wait(2 * s)
         if not self._pair:
@@ -289,7 +353,7 @@ class ShardedScanner:
 
     def flush(self):
         """Finish the scan still in flight (its maps end up in h_full / v_full, its cloud in xyz_full)."""
-        if self.kind == "maps" and self._pending is not None:
+        if self.kind in ("maps", "xyz") and self._pending is not None:
             self._finish(self._pending)
             self._pending = None
 
@@ -298,6 +362,10 @@ class ShardedScanner:
         ranks); "maps": returns None (the cloud is the dense XYZ map, count it with :meth:`count_valid`)."""
         if self.kind == "maps":
             return self.scan_maps(d_band_stack, plane_stride, n_runs, run_stride, eps)
+        if self.kind == "xyz":
+            self.flush()
+            self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
+            return self.flush()
         c, W = self.ctx, self.plan.W
         band_px = self.rows * W
         c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0,
@@ -313,7 +381,7 @@ class ShardedScanner:
         return self.all_records.download((total,), RECORD_DTYPE)
 
     def fetch_dense(self):
-        """Reassembled products on the host ("maps"): (h int16 [H,W], v int16 [H,W], xyz float32 [H,W,3])."""
+        """Reassembled products on the host ("maps" / "xyz"): (h int16 [H,W], v int16 [H,W], xyz float32 [H,W,3])."""
         self.ctx.synchronize()
         H, W = self.plan.H, self.plan.W
         return (self.h_full.download((H, W), np.int16), self.v_full.download((H, W), np.int16),

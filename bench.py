@@ -2,28 +2,30 @@
 """bench.py -- Mpixels/s of Gray-code decode + triangulation on MI355X (BASELINE.json metric).
 
 One "step" = one scan: the 4096x3000 camera, 44-frame uint8 stack (BASELINE.json configs[2]; resident in HBM
-before the timed region, generated on the device) goes through the decode kernel and the triangulation kernel
-and leaves a dense float32 XYZ map + int16 projector maps in HBM.  No torch: HIP through the ctypes C-ABI.
+before the timed region, generated on the device) goes through ONE fused kernel (decode with the triangulation tail) and
+leaves int16 projector maps + a dense float32 XYZ map in HBM.  No torch anywhere: HIP through the ctypes C-ABI.
 
-  python bench.py --gpus 1 --steps K --warmup W            single GPU
+  python bench.py [--gpus 1] --steps K --warmup W            single GPU
+  python bench.py --gpus N ...                               N > 1: this process starts N fresh rank processes itself (one per
+                                                             GPU, before anything touches a GPU) and relays rank 0's JSON line
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-      one rank per GPU: the same scan row-sharded across the N GPUs (configs[3]); each step ends with the RCCL
-      all-gatherv that reassembles the compacted point cloud (float32 XYZ + uint32 pixel key) on every rank.
+                                                             the driver's launcher: RANK / LOCAL_RANK / WORLD_SIZE from the env
+      N > 1 = the same scan row-sharded across the N GPUs (configs[3]): every step ends with the RCCL exchange that reassembles
+      the whole cloud on every rank; after the timed region every rank hashes what it holds and the hashes are compared across
+      ranks and with a single-GPU scan of the same stack (the run verifies itself: "verify" in the JSON).
 
-The timed region runs the library's default pipeline: ONE kernel per scan (the decode kernel with the triangulation tail,
-`--pipeline fused`).  At N=1 the two-kernel pipeline (`--pipeline split`: the decode kernel as its own launch, then the dense
-triangulation kernel) is timed right after over the same K steps and reported in the extra object "split_pipeline", so the
-decode kernel's own roofline fraction (the north star's 60 % target) is measured in the same run.
-
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      decode kernel: algorithmic bytes (N+4 per pixel) / mean launch duration from HIP events recorded on the
-                launch stream inside the timed region, against the 8 TB/s HBM3E peak
-  cpu_baseline  the reference-equivalent NumPy/Python port (oracle/oracle_np.py, kind "port") timed on this host on a
-                bounded crop of the same workload (N=1 only)
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline          the dominant kernel of the timed region: algorithmic bytes (N+12 B/pixel fused, N+4 decode) /
+                    launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s
+  cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on BASELINE configs[0] at full size,
+                    1 thread, plus the plain-C oracle on 1 and on all host cores (N = 1 only)
+  split_pipeline / decode_kernel_alone / throughput_mode / reference_product    N = 1 extras, same run
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,6 +43,7 @@ WORKLOADS = {
     "c2_1920x1080x46": (1920, 1080, 1920, 1080, 46),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PREHEAT_S = 0.15       # untimed back-to-back scans before the counted warm-up: the clocks of a fresh box ramp for ~100 ms
 
 
 def calibration(cam_w, cam_h, proj_w, proj_h):
@@ -59,87 +62,139 @@ def calibration(cam_w, cam_h, proj_w, proj_h):
     return K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T
 
 
-def rendezvous_uid(rank, world):
-    """Share the RCCL unique id between the ranks torch.distributed.run started (same parent pid)."""
-    from scanner import _native, sharded
-    return sharded.share_unique_id(rank, _native.Context.comm_unique_id)
+# ------------------------------------------------------------------------------------------------ N > 1 launcher
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (fresh interpreters: nothing in THIS process has touched a GPU, and no process that
+    has is ever exec'ed over), one per GPU, with the env torch.distributed.run would give them; relay their output; exit code = worst."""
+    key = f"self_{os.getpid()}_{int(time.time() * 1e6)}"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SLGC_UID_KEY=key, MASTER_ADDR="127.0.0.1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    deadline = time.time() + float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900"))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = any(rc not in (None, 0) for rc in rcs)
+        if failed or time.time() > deadline:             # one rank died (or the run hangs): the others would wait in a collective for ever
+            t_kill = time.time() + (5.0 if failed else 0.0)
+            while time.time() < t_kill and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                            # exact pids this process started
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    sys.exit(max((abs(rc) for rc in rcs), default=0) and 1)
 
 
-def cpu_baseline(N, crop_w, crop_h, calib, proj_size):
-    """Reference-equivalent CPU path on a crop of the same synthetic scene: vectorised NumPy get_codes, then the
-    per-pixel Python loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then NumPy triangulation."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (N = 1)
+def cpu_baseline():
+    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames) at FULL
+    size: get_codes with the reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the per-pixel Python
+    loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
     import oracle_np as onp
-    st, _, _ = onp.synth_scene_int(N, crop_h, crop_w, seed=1)
+    cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
+    K, cd, pk, pd, R, T = calibration(cw, ch, pw, ph)
+    st, _, _ = onp.synth_scene_int(n, ch, cw, seed=1)
     white = np.repeat(st[1][:, :, None], 3, axis=2)
-    K, cd, pk, pd, R, T = calib
     t0 = time.perf_counter()
-    hc, vc = onp.get_codes(st.astype(np.float64))                      # float64 stack like the reference driver
+    hc, vc = onp.get_codes_loops(st.astype(np.float64))                # float64 stack like the reference driver (src/3:68-70)
+    t_codes = time.perf_counter() - t0
     hp, vp = onp.codes_to_pixels_loops(hc, vc)
-    cam, proj, _ = onp.cam_proj_pts_loops(hp, vp, (crop_w, crop_h), proj_size, white)
+    t_pix = time.perf_counter() - t0 - t_codes
+    cam, proj, _ = onp.cam_proj_pts_loops(hp, vp, (cw, ch), (pw, ph), white)
     pts = onp.triangulate(cam, proj, K, cd, pk, pd, R, T)
     dt = time.perf_counter() - t0
-    mpix = crop_w * crop_h / 1e6
-    import oracle_c as oc
+    mpix = cw * ch / 1e6
+    # strong baseline: the plain-C oracle on the headline workload's own size class (a 2048x1024 crop of the 44-frame scene)
+    st2, _, _ = onp.synth_scene_int(44, 1024, 2048, seed=1)
+    cal3 = calibration(4096, 3000, 1920, 1200)
     t1 = time.perf_counter()
-    oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)
+    oc.scan_dense(st2, (1920, 1200), *cal3)
     dt_c = time.perf_counter() - t1
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     dt_mt, used = None, 1
-    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
-        oc.set_threads(n)
-        oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)              # thread pool start-up
+    for nthr in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
+        oc.set_threads(nthr)
+        oc.scan_dense(st2, (1920, 1200), *cal3)                        # thread pool start-up
         t2 = time.perf_counter()
-        oc.scan_dense(st, proj_size, K, cd, pk, pd, R, T)
+        oc.scan_dense(st2, (1920, 1200), *cal3)
         d = time.perf_counter() - t2
         if dt_mt is None or d < dt_mt:
-            dt_mt, used = d, n
+            dt_mt, used = d, nthr
     oc.set_threads(1)
+    mpix2 = 2048 * 1024 / 1e6
     return {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"{crop_w}x{crop_h}x{N} crop of the same synthetic scene, decode+triangulate, {dt:.1f} s, "
-                      f"{pts.shape[1]} points; NumPy/Python port of the reference path (oracle/oracle_np.py), 1 thread; "
-                      f"host has {os.cpu_count()} cores",
-            "c_oracle_value": round(mpix / dt_c, 3), "c_oracle_note": "plain-C scalar oracle, 1 thread, same crop",
-            "c_oracle_all_cores_value": round(mpix / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
-            "c_oracle_all_cores_note": "the same C oracle with its per-pixel loops on host threads (OpenMP), best of 8/16/32/64/128/all visible cores, same crop"}
+            "sample": f"BASELINE configs[0] at full size: {cw}x{ch} camera, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
+                      f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {pts.shape[1]} points; "
+                      "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
+            "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
+                                   "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
+            "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": "plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, 2048x1024x44 crop of the headline scene",
+            "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
+            "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP), best of 8/16/32/64/128/all visible cores, same crop"}
 
 
-def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
-    """BASELINE.json configs[4]: 16 independent 1920x1080x44 scans per step, spread over the G GPUs, no collective
-    (replicas only -- SURVEY.md 8(e)).  Each GPU streams its scans back to back over `n_streams` contexts (HIP streams) so the
-    tail of one scan's kernel overlaps the head of the next.  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
+# ------------------------------------------------------------------------------------------------ configs[4]
+def throughput_lanes(_native, device, per_rank, n_streams=2):
+    """BASELINE.json configs[4] on one GPU: `n_streams` contexts (HIP streams), each with its own rotated 1920x1080x44 stacks
+    (>= 4 distinct stacks in total: 364 MB > Infinity Cache) and one set of output buffers.  -> [(ctx, stacks, maps, xyz)]"""
     cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
-    per_rank = max(1, 16 // G)
     px = cw * ch
     lanes = []
     for sidx in range(max(1, n_streams)):
         c = _native.Context(device)
         c.set_calibration(*calibration(cw, ch, pw, ph))
         stacks = []
-        for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):   # >= 4 distinct stacks in total (364 MB > Infinity Cache)
+        for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):
             st = c.alloc(n * px)
             c.synth_scene_dev(st.ptr, px, n, ch, cw, seed=11 + 7 * sidx + b)
             stacks.append(st)
         lanes.append((c, stacks, c.alloc(px * 4), c.alloc(px * 12)))
+    return lanes
 
-    def one_step(i):
-        for j in range(per_rank):
-            c, stacks, maps, xyz = lanes[j % len(lanes)]
-            st = stacks[(i * per_rank + j) // len(lanes) % len(stacks)]
-            c.scan_dev(st.ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+
+def throughput_step(lanes, per_rank, i, mode):
+    """Issue one step = `per_rank` independent scans, round-robin over the lanes.  -> [(lane index, stack index)] in issue order."""
+    cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
+    px = cw * ch
+    plan = []
+    for j in range(per_rank):
+        li = j % len(lanes)
+        c, stacks, maps, xyz = lanes[li]
+        si = (i * per_rank + j) // len(lanes) % len(stacks)
+        c.scan_dev(stacks[si].ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+        plan.append((li, si))
+    return plan
+
+
+def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
+    """16 independent 1920x1080x44 scans per step spread over the G GPUs, no collective (replicas only -- SURVEY.md 8(e)).  Each GPU
+    streams its scans back to back over `n_streams` HIP streams so the tail of one scan's kernel overlaps the head of the next.
+    Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
+    cw, ch = WORKLOADS["c2_1920x1080x44"][:2]
+    per_rank = max(1, 16 // G)
+    lanes = throughput_lanes(_native, device, per_rank, n_streams)
 
     def sync_all():
         for c, _, _, _ in lanes:
             c.synchronize()
 
     for i in range(3):
-        one_step(i)
+        throughput_step(lanes, per_rank, i, mode)
     sync_all()
     if G > 1:
         ctx.comm_barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        one_step(i)
+        throughput_step(lanes, per_rank, i, mode)
     sync_all()
     if G > 1:
         ctx.comm_barrier()
@@ -148,7 +203,35 @@ def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
         el = ctx.comm_allreduce_max(el)
     for c, _, _, _ in lanes:
         c.close()
-    return el, per_rank * G, px / 1e6
+    return el, per_rank * G, cw * ch / 1e6
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def launch_stats(samples_ms):
+    s = np.sort(np.asarray(samples_ms, dtype=np.float64))
+    if s.size == 0:
+        return {}
+    q = lambda f: float(s[min(s.size - 1, int(round(f * (s.size - 1))))])     # noqa: E731
+    return {"min_launch_ms": round(float(s[0]), 5), "median_launch_ms": round(q(0.5), 5), "p95_launch_ms": round(q(0.95), 5),
+            "max_launch_ms": round(float(s[-1]), 5)}
+
+
+def digest64(*arrays):
+    h = hashlib.blake2b(digest_size=8)
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).view(np.uint8).reshape(-1).data)
+    return int.from_bytes(h.digest(), "little") >> 1          # 63 bits: travels through the int64 all-gather unchanged
+
+
+def csrc_fingerprint():
+    """Hash of the kernel sources: profiles/traffic.json carries the fingerprint it was measured on, a mismatch = stale counters."""
+    h = hashlib.blake2b(digest_size=8)
+    d = os.path.join(ROOT, "3dscanner-graycode_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -164,53 +247,65 @@ def main():
     ap.add_argument("--tri", default="lut", choices=["lut", "direct"], help="ray tables (default) or per-pixel undistortPoints")
     ap.add_argument("--variant", type=int, default=0, help="decode kernel variant (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="bracket every n-th kernel launch of the timed region with a HIP event pair (1 = all; each pair costs ~1.5 %% of a step)")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="bracket every n-th kernel launch of the timed region with a HIP event pair (0 = auto: 1 below 16 steps, 2 below 64, "
+                         "else 4; a pair costs ~1.5 %% of a step)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (contexts) per GPU in the throughput-mode measurement")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
-    ap.add_argument("--exchange", default="maps", choices=["maps", "records"],
-                    help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default), or all-gatherv "
-                         "compacted 16-byte XYZ+key records")
-    ap.add_argument("--wire", default="auto", choices=["auto", "int16", "hv24"],
-                    help="sharded 'maps' exchange: send the int16 maps (4 B/pixel) or the packed 3 B/pixel wire format (auto: hv24 for G > 1)")
-    ap.add_argument("--no-overlap", action="store_true", help="sharded 'maps' mode: do not pipeline the exchange with the neighbouring scans")
-    ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (compaction + RCCL exchange) even on 1 GPU")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline timed region (no split / alone / throughput / reference-product / CPU legs)")
+    ap.add_argument("--exchange", default="maps", choices=["maps", "records", "xyz"],
+                    help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default); all-gather maps + "
+                         "float32 XYZ bands produced by the fused kernel on each band (xyz); or all-gatherv compacted 16-byte XYZ+key records")
+    ap.add_argument("--wire", default="int16", choices=["auto", "int16", "hv24"],
+                    help="sharded 'maps' exchange: send the int16 maps (4 B/pixel, default) or the packed 3 B/pixel wire format")
+    ap.add_argument("--no-overlap", action="store_true", help="sharded modes: do not pipeline the exchange with the neighbouring scans")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (RCCL exchange at nranks = 1) even on 1 GPU")
+    ap.add_argument("--no-verify", action="store_true", help="sharded modes: skip the post-run cross-rank / single-GPU verification")
     ap.add_argument("--plane-pad", type=int, default=0,
                     help="extra bytes between frame planes in HBM (multiple of 16; 0 = contiguous [N,H,W] like the reference)")
     ap.add_argument("--buffers", type=int, default=0,
                     help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])              # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    try:
+        run_rank(args, rank, local_rank, world)
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        if rank == 0:       # the driver still gets a line: what failed, no number
+            print(json.dumps({"metric": "Mpixels/s decode+triangulate", "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus,
+                              "steps": args.steps, "warmup": args.warmup, "error": f"{type(e).__name__}: {e}"}), flush=True)
+        sys.exit(1)
 
+
+def run_rank(args, rank, local_rank, world):
     from scanner import _native
     cam_w, cam_h, proj_w, proj_h, N = WORKLOADS[args.workload]
     G = args.gpus
-    if cam_h % G:
-        sys.exit(f"image height {cam_h} not divisible by {G} GPUs")
-    rows = cam_h // G
-    row0 = rank * rows
+    use_comm = G > 1 or args.force_sharded
     mode = (_native.TRI_ALGEBRAIC if args.mode == "algebraic" else _native.TRI_EXACT) | (2 if args.tri == "direct" else 0)
     mode_split, mode_fused = mode | _native.TRI_SPLIT, mode & ~_native.TRI_SPLIT
     mode = mode_split if args.pipeline == "split" else mode_fused
+    if args.event_stride <= 0:
+        args.event_stride = 1 if args.steps < 16 else 2 if args.steps < 64 else 4
 
     n_dev = max(1, _native.device_count())
     device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
     ctx = _native.Context(device)
     calib = calibration(cam_w, cam_h, proj_w, proj_h)
     ctx.set_calibration(*calib)
-    uid_path = None
-    use_comm = G > 1 or args.force_sharded
     if G == 1 and args.force_sharded:
         ctx.comm_init(0, 1, _native.Context.comm_unique_id())
     if G > 1:
-        uid, uid_path = rendezvous_uid(rank, G)
+        from scanner import sharded
+        uid, uid_path = sharded.share_unique_id(rank, _native.Context.comm_unique_id, key=os.environ.get("SLGC_UID_KEY"))
         ctx.comm_init(rank, G, uid)
         ctx.comm_barrier()
         if rank == 0:
@@ -218,72 +313,97 @@ def main():
                 os.remove(uid_path)
             except OSError:
                 pass
-
     if use_comm:
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL prints its version banner through C stdio: flush it now so rank 0's JSON stays the last line
+
+    from scanner import sharded
+    plan = sharded.ShardPlan(cam_h, cam_w, G)
+    row0, rows = plan.band(rank)
     band_px = rows * cam_w
     plane = band_px + args.plane_pad        # each rank holds only its row band of every frame; pad 0 = the reference's contiguous [N,H,W]
-    stacks = []
     if args.buffers <= 0:                                   # enough distinct stacks to exceed the 256 MB Infinity Cache
-        args.buffers = max(2, -(-300_000_000 // (N * plane)))
+        args.buffers = max(2, -(-300_000_000 // max(1, N * plane)))
+    stacks = []
     for b in range(max(1, args.buffers)):
-        s = ctx.alloc(N * plane)
-        ctx.synth_scene_dev(s.ptr, plane, N, cam_h, cam_w, row0=row0, rows=rows, seed=1 + b, noise=3, shadow=True)
+        s = ctx.alloc(max(16, N * plane))
+        if rows:
+            ctx.synth_scene_dev(s.ptr, plane, N, cam_h, cam_w, row0=row0, rows=rows, seed=1 + b, noise=3, shadow=True)
         stacks.append(s)
-    maps = ctx.alloc(band_px * 4)
-    xyz = ctx.alloc(band_px * 12)
-    count = ctx.alloc(8).zero()
+    maps = ctx.alloc(max(16, band_px * 4))
+    xyz = ctx.alloc(max(16, band_px * 12))
+    count = ctx.alloc(16).zero()
+    # per-calibration work, hoisted out of the scans and timed on its own: both undistortPoints calls evaluated into the two ray tables
+    ctx.synchronize()
+    ctx.event_record(0)
+    ctx.build_ray_tables_dev(cam_h if use_comm and args.exchange == "maps" else rows, cam_w, 0 if use_comm and args.exchange == "maps" else row0,
+                             (proj_w, proj_h))
+    ctx.event_record(1)
+    luts_us = ctx.event_elapsed_ms(0, 1) * 1e3
     sharded_scanner = None
     if use_comm:
-        from scanner import sharded
-        sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(cam_h, cam_w, G),
-                                                 (proj_w, proj_h), N, mode=mode, exchange_kind=args.exchange, wire=args.wire)
+        sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode,
+                                                 exchange_kind=args.exchange, wire=args.wire)
     ctx.synchronize()
+    pipelined = use_comm and args.exchange in ("maps", "xyz") and not args.no_overlap
 
     def step(i, counted=False, mode=mode):
         s = stacks[i % len(stacks)]
-        if use_comm and args.exchange == "maps" and not args.no_overlap:
-            return sharded_scanner.submit(s.ptr, plane)      # pipelined: exchange of this scan overlaps the neighbours' kernels
+        if pipelined:
+            return sharded_scanner.submit(s.ptr, plane)      # exchange of this scan overlaps the neighbours' kernels
         if use_comm:
-            return sharded_scanner.scan(s.ptr, plane)        # band scan + compaction + counts + RCCL all-gatherv
+            return sharded_scanner.scan(s.ptr, plane)
         ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
                      maps.at(0), maps.at(band_px * 2), mode=mode)
         return None
 
-    def timed(K, W_, **kw):
-        for i in range(W_):
-            step(i, **kw)
+    def drain():
         if sharded_scanner is not None:
             sharded_scanner.flush()
         ctx.synchronize()
+
+    def timed(K, W_, stride=None, preheat=True, **kw):
+        if preheat:                                          # untimed: bring the clocks up before the counted warm-up
+            t_end = time.perf_counter() + PREHEAT_S
+            i = 0
+            while time.perf_counter() < t_end:
+                for _ in range(16):
+                    step(i, **kw)
+                    i += 1
+                drain()
+        for i in range(W_):
+            step(i, **kw)
+        drain()
         if G > 1:
             ctx.comm_barrier()
-        ctx.prof_begin(K + 8, args.event_stride)     # HIP-event pair around every event_stride-th kernel launch of the region
+        ctx.prof_begin(K + 8, stride or args.event_stride)   # HIP-event pair bound to every stride-th kernel dispatch of the region
         t0 = time.perf_counter()
         tot = None
         for i in range(K):
             tot = step(i, **kw)
-        if sharded_scanner is not None:
-            sharded_scanner.flush()                          # the K-th scan's exchange + triangulation are inside the timed region
-        ctx.synchronize()
+        drain()                                              # the K-th scan's exchange + triangulation are inside the timed region
         if G > 1:
             ctx.comm_barrier()
         el = time.perf_counter() - t0
         kms, kn = ctx.prof_end()
+        samples = ctx.prof_samples()
         if G > 1:
             el = ctx.comm_allreduce_max(el)
             kms = ctx.comm_allreduce_max(kms)
-        return el, kms, kn, tot
+        return el, kms, kn, tot, samples
 
-    elapsed, dec_ms, dec_n, total_pts = timed(args.steps, args.warmup)
+    elapsed, dec_ms, dec_n, total_pts, dec_samples = timed(args.steps, args.warmup)
+    last_stack = (args.steps - 1) % len(stacks)              # what the output buffers hold now
+    single = G == 1 and not use_comm
+    extras = single and not args.no_extras and args.mode == "algebraic" and args.tri == "lut"
+
     other = None
-    if G == 1 and not use_comm and args.mode == "algebraic" and args.tri == "lut":
+    if extras:
         om = mode_fused if args.pipeline == "split" else mode_split
-        other = timed(args.steps, max(2, args.warmup // 2), mode=om)
+        other = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=om)
 
     dec_alone = None
-    if G == 1 and not use_comm:
+    if extras:
         # the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way)
         for i in range(3):
             ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
@@ -291,83 +411,110 @@ def main():
         ctx.prof_begin(args.steps + 8)
         for i in range(args.steps):
             ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
-        dec_alone = ctx.prof_end()
+        dec_alone = ctx.prof_end() + (ctx.prof_samples(),)
+
+    ref_product = None
+    if extras and hasattr(ctx, "cloud_lists_dev"):
+        ref_product = reference_product(ctx, _native, stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
+
     thr = None
-    if not args.no_throughput_mode and args.mode == "algebraic" and args.tri == "lut":
+    if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
         thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams)
+
+    # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
+    count.zero()
     if not use_comm:
-        count.zero()
-        step(0, counted=True)                                   # untimed: valid-pixel count of one scan, for the report
-        ctx.synchronize()
-        valid = int(count.download((1,), np.uint64)[0])
+        ctx.scan_dev(stacks[0].ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode)
+        ctx.guard_count_dev(maps.at(0), maps.at(band_px * 2), rows, cam_w, row0, (proj_w, proj_h), count.ptr)
     elif args.exchange == "records":
-        valid = float(total_pts)
-    else:                                                       # maps exchange: count the reassembled dense cloud once, untimed
-        count.zero()
-        ctx.triangulate_maps_dev(sharded_scanner.h_full.ptr, sharded_scanner.v_full.ptr, cam_h, cam_w, 0, (proj_w, proj_h),
-                                 sharded_scanner.xyz_full.ptr, count.ptr, mode=mode & 3)
-        ctx.synchronize()
-        valid = int(count.download((1,), np.uint64)[0])
+        pass
+    else:
+        ctx.guard_count_dev(sharded_scanner.h_full.ptr, sharded_scanner.v_full.ptr, cam_h, cam_w, 0, (proj_w, proj_h), count.ptr)
+    ctx.synchronize()
+    valid, flagged = (int(x) for x in count.download((2,), np.uint64))
+    if use_comm and args.exchange == "records":
+        valid, flagged = int(total_pts), None
+
+    verify = None
+    shard_info = None
+    if use_comm:
+        shard_info = sharded_report(ctx, sharded_scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, (proj_w, proj_h), mode, elapsed)
+        if not args.no_verify and args.exchange in ("maps", "xyz"):
+            verify = verify_sharded(ctx, sharded_scanner, G, rank, N, cam_w, cam_h, (proj_w, proj_h), 1 + last_stack, args.plane_pad)
+
     if rank == 0:
         mpix_per_step = cam_w * cam_h / 1e6
         ms_per_step = elapsed / args.steps * 1e3
         value = mpix_per_step * args.steps / elapsed
-        def kernel_roofline(pipeline, kms, kn):
-            """decode kernel: N bytes in + 2x int16 out per pixel; fused kernel: + 12 B float32 XYZ out."""
-            per_px = (N + 4) if pipeline == "split" else (N + 4 + 12)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        try:
+            traffic_db = json.load(open(tpath))
+        except Exception:  # noqa: BLE001
+            traffic_db = {}
+        fp = csrc_fingerprint()
+
+        def kernel_roofline(pipeline, kms, kn, samples):
+            """SURVEY.md 8(d) byte definitions: decode kernel N + 4 B/pixel (N uint8 reads, 2 int16 writes); fused decode -> XYZ
+            N + 12 B/pixel.  The fused kernel also writes the 4 B/pixel maps (a product): frac_incl_maps counts them too."""
+            per_px = (N + 4) if pipeline == "split" else (N + 12)
             avg_ms = kms / max(1, kn)
             ach = per_px * band_px / (avg_ms * 1e-3) / 1e9
-            return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "kernel": "k_decode_pk<4,128,nt>" + ("" if pipeline == "split" else " + triangulation tail (fused)"),
-                    "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, "algorithmic_bytes_per_px": per_px,
-                    "algorithmic_bytes_per_launch": per_px * band_px}
+            r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                 "traffic": None, "kernel": "k_decode_pk<4,128,nt>" + ("" if pipeline == "split" else " + triangulation tail (fused)"),
+                 "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, **launch_stats(samples),
+                 "algorithmic_bytes_per_px": per_px, "algorithmic_bytes_per_launch": per_px * band_px}
+            if pipeline != "split":
+                r["frac_incl_maps"] = round((N + 16) * band_px / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                r["frac_incl_maps_note"] = "N + 16 B/pixel: the 4 B/pixel int16 maps the fused kernel also writes counted as algorithmic"
+            t = traffic_db.get(f"{args.workload}/g{G}/{pipeline}")
+            if t and t.get("csrc_fingerprint") == fp:
+                r["traffic"] = t["hbm_bytes_per_launch"]
+                r["traffic_source"] = t.get("source")
+            elif t:
+                r["traffic_note"] = ("profiles/traffic.json was measured on other kernel sources (fingerprint mismatch): stale, not reported; "
+                                     "re-run tools/pmc.sh")
+            return r
 
+        main_pipeline = "split" if (use_comm and args.exchange == "maps") else args.pipeline
         out = {
             "metric": "Mpixels/s decode+triangulate", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": G,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames (BASELINE.json configs[2]"
-                                   + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL all-gatherv = configs[3]") + ")",
-                       **({} if not use_comm else {"exchange": ((("map bands packed to 3 B/pixel, all-gathered, unpacked" if sharded_scanner.wire == "hv24"
-                                                                  else "int16 map bands all-gathered") + ", every rank triangulates the full maps")
-                                                                + ("" if args.no_overlap else "; exchange of scan i overlaps triangulation of i-1 and decode of i+1")
-                                                                if args.exchange == "maps" else
-                                                                "compacted 16-byte XYZ+key records all-gathered")}),
-                       "pipeline": ("decode kernel per band + full-image triangulation kernel per rank" if (use_comm and args.exchange == "maps")
+                                   + ("" if not use_comm else f", row-sharded over {G} GPUs + RCCL exchange = configs[3]") + ")",
+                       "pipeline": ({"maps": "decode kernel per band, map bands all-gathered, full-image triangulation kernel on every rank",
+                                     "xyz": "fused kernel per band, map + XYZ bands all-gathered in place",
+                                     "records": "fused kernel per band, compaction, 16-byte XYZ+key records all-gatherv'ed"}[args.exchange] if use_comm
                                     else args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)")),
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks), "plane_pad_bytes": args.plane_pad,
-                       "outputs": "int16 h/v maps + dense float32 XYZ in HBM"
-                                  + ("" if not use_comm else "; whole cloud reassembled on every rank")},
-            # the kernel bracketed by the event pairs: the fused scan kernel, or (split / sharded "maps" strategy) the decode kernel
-            "roofline": kernel_roofline("split" if (use_comm and args.exchange == "maps") else args.pipeline, dec_ms, dec_n),
+                       "outputs": "int16 h/v maps + dense float32 XYZ in HBM" + ("" if not use_comm else "; whole cloud reassembled on every rank"),
+                       "preheat_s": PREHEAT_S, "event_stride": args.event_stride,
+                       "luts_hoisted_us": round(luts_us, 1),
+                       "luts_hoisted_note": "per-calibration ray tables (both cv2.undistortPoints calls on integer pixel coordinates) built once "
+                                            "before the timed region, not per scan",
+                       "guard_flagged_pixels": flagged,
+                       "guard_note": "decodable pixels of one scan that triangulation redoes on the reference's float32 intermediates (flat triangles)"},
+            "roofline": kernel_roofline(main_pipeline, dec_ms, dec_n, dec_samples),
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
         }
-        def add_traffic(roof, pipeline):
-            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), same workload only."""
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            try:
-                t = json.load(open(tpath)).get(f"{args.workload}/g{G}/{pipeline}")
-                if t:
-                    roof["traffic"] = t["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = t.get("source")
-            except Exception:
-                pass
-
-        add_traffic(out["roofline"], args.pipeline)
+        if shard_info:
+            out["sharded"] = shard_info
+        if verify is not None:
+            out["verify"] = verify
         if other is not None:
-            o_el, o_kms, o_kn, _ = other
+            o_el, o_kms, o_kn, _, o_samples = other
             o_name = "fused" if args.pipeline == "split" else "split"
             out[o_name + "_pipeline"] = {"value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
                                          "ms_per_step": round(o_el / args.steps * 1e3, 4), "steps": args.steps,
-                                         "roofline": kernel_roofline(o_name, o_kms, o_kn),
+                                         "roofline": kernel_roofline(o_name, o_kms, o_kn, o_samples),
                                          "note": "same scan, same run, timed right after the main region"}
-            add_traffic(out[o_name + "_pipeline"]["roofline"], o_name)
         if dec_alone is not None:
-            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", dec_alone[0], dec_alone[1]),
+            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", *dec_alone),
                                           "note": "decode kernel launched back to back on the rotated stacks, same run (the north star's "
                                                   ">= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
-            add_traffic(out["decode_kernel_alone"]["roofline"], "split")
+        if ref_product is not None:
+            out["reference_product"] = ref_product
         if thr is not None:
             t_el, t_scans, t_mpix = thr
             t_steps = max(5, args.steps // 4)
@@ -376,8 +523,8 @@ def main():
                                                 "(BASELINE.json configs[4], replicas only)",
                                       "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "streams_per_gpu": args.streams,
                                       "scaling": "weak"}
-        if G == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, 2048, 1024, calib, (proj_w, proj_h))
+        if single and not args.no_cpu_baseline and not args.no_extras:
+            out["cpu_baseline"] = cpu_baseline()
         if use_comm:
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -385,6 +532,112 @@ def main():
     if G > 1:
         ctx.comm_barrier()
     ctx.close()
+    if verify is not None and not verify.get("ok", False):
+        sys.exit(3)
+
+
+def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, maps, xyz, band_px, steps, mode_fused):
+    """The reference-shaped product, device resident: fused scan -> x-major cam_pts / proj_pts (float32 [M,2]), Pts float64 (3,M) and
+    colors float64 [M,3] gathered from a device-resident white image (triangulate.py:52-71, 95).  Timed end to end per scan."""
+    white = ctx.alloc(band_px * 3)
+    ctx.dev_memset(white.ptr, 0x80, band_px * 3)
+    lists = ctx.alloc_cloud_lists(band_px, colors=True)
+    K = max(5, steps // 4)
+
+    def one(i):
+        s = stacks[i % len(stacks)]
+        ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, W, row0, proj_size, xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode_fused)
+        ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), xyz.ptr, white.ptr, W, rows, proj_size, lists)
+
+    for i in range(3):
+        one(i)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one(i)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    M = lists.total()
+    # bytes of the list stage: maps read twice (count + scatter) 8, XYZ 12, white 3 per pixel in; 8 + 8 + 24 + 24 per valid pixel out
+    stage_bytes = band_px * (8 + 12 + 3) + M * 64
+    ctx.event_record(2)
+    ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), xyz.ptr, white.ptr, W, rows, proj_size, lists)
+    ctx.event_record(3)
+    stage_ms = ctx.event_elapsed_ms(2, 3)
+    out = {"value": round(band_px / 1e6 * K / el, 1), "unit": "Mpixels/s", "ms_per_scan": round(el / K * 1e3, 4), "steps": K, "points": int(M),
+           "list_stage_ms": round(stage_ms, 4), "list_stage_bytes": int(stage_bytes),
+           "list_stage_roofline": {"bound": "hbm", "achieved": round(stage_bytes / (stage_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "note": "fused scan + x-major list build (count, column prefix, LDS-transposed scatter with the colour gather and the float64 "
+                   "(3,M) points folded in); everything stays in HBM"}
+    white.free()
+    lists.free()
+    return out
+
+
+def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, proj_size, mode, elapsed):
+    """compute-only vs with-exchange rates of the sharded scan and the bytes each rank puts on / takes off the links."""
+    K = max(5, args.steps // 2)
+    t_compute = None
+    if args.exchange in ("maps", "xyz"):
+        for rep in range(2):                                   # first pass warms up
+            ctx.synchronize()
+            if G > 1:
+                ctx.comm_barrier()
+            t0 = time.perf_counter()
+            for i in range(K):
+                scanner.compute_only(stacks[i % len(stacks)].ptr, plane)
+            ctx.synchronize()
+            t_compute = time.perf_counter() - t0
+        if G > 1:
+            t_compute = ctx.comm_allreduce_max(t_compute)
+    px = cam_w * cam_h
+    per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
+    info = {"rccl_nranks": G, "exchange": args.exchange, "wire": scanner.wire if args.exchange == "maps" else None,
+            "overlap": not args.no_overlap and args.exchange != "records",
+            "exchange_bytes_per_rank": {"sent": int(rows * cam_w * per_px), "received": int((px - rows * cam_w) * per_px)},
+            "with_exchange_value": round(px / 1e6 * args.steps / elapsed, 1), "unit": "Mpixels/s"}
+    if t_compute:
+        info["compute_only_value"] = round(px / 1e6 * K / t_compute, 1)
+        info["compute_only_note"] = "the same kernels per rank with the exchange left out (what the links would have to keep up with)"
+    return info
+
+
+def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plane_pad):
+    """After the timed region: (1) every rank hashes the reassembled int16 maps and a strided XYZ sample it holds -> all-gather ->
+    must be equal on all ranks; (2) every rank scans the SAME full image (same seed) alone on its own GPU with the fused kernel ->
+    maps must be bit-identical, the XYZ sample equal to float32 resolution."""
+    from scanner import _native
+    px = cam_w * cam_h
+    h, v, xyz = scanner.fetch_dense()
+    sample = xyz.reshape(-1, 3)[::97]
+    mine = digest64(h, v, np.nan_to_num(sample, nan=-1.0))
+    ranks_equal = True
+    if G > 1:
+        allh = ctx.comm_allgather_i64(mine)
+        ranks_equal = all(x == allh[0] for x in allh)
+    full = ctx.alloc(N * px)
+    ctx.synth_scene_dev(full.ptr, px, N, cam_h, cam_w, row0=0, rows=cam_h, seed=seed, noise=3, shadow=True)
+    m1, x1 = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.scan_dev(full.ptr, 1, N * px, px, N, cam_h, cam_w, 0, proj_size, x1.ptr, None, m1.at(0), m1.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+    ctx.synchronize()
+    h1, v1 = m1.download((cam_h, cam_w), np.int16), m1.download((cam_h, cam_w), np.int16, px * 2)
+    s1 = x1.download((px, 3), np.float32)[::97]
+    maps_equal = bool(np.array_equal(h, h1) and np.array_equal(v, v1))
+    fin = np.isfinite(s1).all(axis=1)
+    xyz_equal = bool(np.array_equal(np.isfinite(sample).all(axis=1), fin) and
+                     np.allclose(sample[fin], s1[fin], rtol=2e-6, atol=0))
+    for b in (full, m1, x1):
+        b.free()
+    ok_local = maps_equal and xyz_equal
+    ok_all = ok_local
+    if G > 1:
+        oks = ctx.comm_allgather_i64(1 if ok_local else 0)
+        ok_all = all(oks)
+    return {"ok": bool(ranks_equal and ok_all), "ranks_hold_identical_results": bool(ranks_equal), "maps_equal_single_gpu_scan": maps_equal,
+            "xyz_sample_equal_single_gpu_scan": xyz_equal, "valid_pixels": int(((h != -1) & (v != -1)).sum()), "digest": f"{mine:016x}",
+            "note": "every rank compared its reassembled maps (bit-exact) and a 1/97 XYZ sample (2e-6) with a single-GPU fused scan of the same "
+                    "stack, and its digest with every other rank's"}
 
 
 if __name__ == "__main__":

@@ -175,6 +175,26 @@ int slgc_selftest_classify(slgc_ctx *ctx, int negative_control, unsigned long lo
 int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                               int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
 
+/* Per-calibration work of the dense path, hoisted out of the scans: both cv2.undistortPoints calls of triangulate.py:84-85 only
+ * ever see integer pixel coordinates there, so their float32 results are evaluated once per (calibration, band, projector size)
+ * into two ray tables.  slgc_scan_dev / slgc_triangulate_maps_dev build them on first use; this entry point builds them
+ * explicitly (asynchronous, on the context's stream) so that a caller -- and bench.py -- can place and time that one-off cost. */
+int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
+
+/* Diagnostic: d_counts[0] += decodable pixels of the band, d_counts[1] += those among them that the dense triangulation redoes
+ * on the reference's float32 intermediates because the triangle is flat (tri_is_flat, csrc/tri_math.h) -- the guarded slow path. */
+int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
+                         unsigned long long *d_counts);
+
+/* The reference-shaped product without leaving HBM: from the int16 maps and the dense XYZ of a (full-image) scan, the x-major
+ * correspondence lists of get_cam_proj_pts (triangulate.py:52-71: columns outer, rows inner, clamp to the projector, colour =
+ * white[y][x][:] / 255.0 from a device-resident uint8 RGB image) and, gathered in the same pass, the float64 (3,M) point array
+ * Triangulate.triangulate returns (:95).  Asynchronous; *d_total (device) receives M; d_pts rows start at d_pts, d_pts + M,
+ * d_pts + 2M.  Capacity of every list: cam_w * cam_h entries.  d_xyz / d_pts and d_white_rgb / d_colors may be NULL (pairwise). */
+int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white_rgb, int cam_w,
+                         int cam_h, int proj_w, int proj_h, float *d_cam_pts, float *d_proj_pts, double *d_pts, double *d_colors,
+                         unsigned long long *d_total);
+
 /* Row-major compaction of a dense band: keeps pixels with finite XYZ; writes float32 [M][3] points and uint32
  * linear pixel keys ((row0+y)*W + x); *d_count (device) receives M.  Capacity of outputs: rows*W records. */
 int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,
@@ -208,6 +228,8 @@ int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms);
  * returns the summed kernel time and the number of launches sampled. */
 int slgc_prof_begin(slgc_ctx *ctx, int max_launches, int stride);
 int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches);
+/* After _end: the individual kernel durations (ms) of the sampled launches, in launch order; *n = number sampled (may exceed cap). */
+int slgc_prof_samples(slgc_ctx *ctx, float *ms, int cap, int *n);
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
 #define SLGC_UNIQUE_ID_BYTES 128

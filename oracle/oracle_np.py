@@ -110,6 +110,41 @@ def get_codes(stack: np.ndarray):
     return is_lit(stack, l_d, l_g)
 
 
+def is_lit_loops(stack: np.ndarray, l_d: np.ndarray, l_g: np.ndarray, eps=1, m=10):
+    """Same result as :func:`is_lit`, with the COST SHAPE of decode_codes.py:149-182, which is 98 % of the reference's
+    ``get_codes`` time: four integer-list fancy-index copies of ``[L,H,W]`` float64 (:157-160), ``L_d`` / ``L_g`` materialised
+    ``L`` times with ``np.repeat`` (:165-166), and ten ``codes[np.where(mask)] = value`` scatters through int64 index tuples
+    (:169-182).  This is the "port" bench.py times as ``cpu_baseline``; tests check it equals the vectorised twin."""
+    st = np.asarray(stack, dtype=np.float64)
+    L = code_len(len(st))
+    pat = st[2:]
+    normal, inverse = pat[:2 * L], pat[2 * L:]
+    col_ids, row_ids = list(range(0, 2 * L, 2)), list(range(1, 2 * L, 2))
+    n_of = {0: normal[col_ids], 1: normal[row_ids]}                    # fancy indexing copies, like :157-158
+    i_of = {0: inverse[col_ids], 1: inverse[row_ids]}                  # :159-160
+    codes = {k: np.zeros(n_of[k].shape, dtype=np.int8) - 1 for k in (0, 1)}        # :162-163
+    d = np.repeat(np.asarray(l_d)[np.newaxis], L, axis=0)              # :165
+    g = np.repeat(np.asarray(l_g)[np.newaxis], L, axis=0)              # :166
+    with np.errstate(invalid="ignore"):
+        for k in (0, 1):
+            codes[k][np.where(d < m)] = -1                             # :169-170 (no-op rule)
+        for k in (0, 1):
+            codes[k][np.where((d > (g + eps)) & (n_of[k] > (i_of[k] + eps)))] = 1          # :172-173
+        for k in (0, 1):
+            codes[k][np.where((d > (g + eps)) & ((n_of[k] + eps) < i_of[k]))] = 0          # :175-176
+        for k in (0, 1):
+            codes[k][np.where(((n_of[k] + eps) < d) & (i_of[k] > (g + eps)))] = 0          # :178-179
+        for k in (0, 1):
+            codes[k][np.where((n_of[k] > (g + eps)) & ((i_of[k] + eps) < d))] = 1          # :181-182
+    return codes[0], codes[1]
+
+
+def get_codes_loops(stack: np.ndarray):
+    """decode_codes.py:231-248 at the reference's cost (see :func:`is_lit_loops`)."""
+    l_d, l_g = direct_indirect(stack)
+    return is_lit_loops(stack, l_d, l_g)
+
+
 def merge_runs(code_runs):
     """src/3-capture_decode.py:95-96 -- elementwise max over runs (1 > 0 > -1)."""
     return np.max(np.asarray(code_runs), axis=0)

@@ -130,7 +130,7 @@ def test_header_is_plain_c_and_links(tmp_path):
 def test_host_only_helpers(tmp_path):
     """Helpers that need no GPU: PLY layout, read_images file order, shard plan."""
     from scanner.grayCode.decode_codes import read_images_order
-    from scanner.utils import pointcloud as pc
+    from scanner import pointcloud as pc
     names = ["frame_10.jpg", "frame_2.jpg", "frame_1.jpg", "frame_100.jpg", "frame_11.jpg"]
     assert read_images_order(names) == ["frame_2.jpg", "frame_1.jpg", "frame_10.jpg", "frame_11.jpg", "frame_100.jpg"]   # stable, by length only
     pts = np.array([[0.0, 0.5, -1.25], [1.0, 2.0, 3.0]])
@@ -145,3 +145,35 @@ def test_host_only_helpers(tmp_path):
     assert b"red" not in open(tmp_path / "n.ply", "rb").read().split(b"end_header")[0]
     with pytest.raises(ValueError):
         pc.write_ply(tmp_path / "bad.ply", pts, col[:1])
+
+
+def test_namespace_package_merges_with_the_reference_tree(tmp_path):
+    """INTEGRATION.md option A: with this package FIRST on sys.path and the reference checkout behind it, the import lines of the
+    reference's own scripts (src/3-capture_decode.py:5-8, src/4-triangulate.py:5-6) must resolve -- hot-path modules to this
+    build, everything else (acquisition, utils.visualize) to the reference.  cv2 / open3d are not installed: empty stand-in
+    modules satisfy the reference's module-level imports (nothing is called)."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "scanner")):
+        pytest.skip("reference checkout not present (GPU box)")
+    assert not os.path.exists(os.path.join(PKG, "scanner", "__init__.py")), "scanner/ must stay a namespace package like the reference's"
+    code = f"""
+import sys, types
+for name in ("cv2", "open3d", "open3d.core"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["open3d"].core = sys.modules["open3d.core"]
+sys.path[:0] = [{PKG!r}, {ref!r}]
+from scanner.acquisition import Camera
+from scanner.grayCode.generate_codes import get_gray_codes, get_image_sequence
+from scanner.grayCode.decode_codes import get_codes, gray_to_decimal
+from scanner.utils import visualize
+from scanner.triangulation import Triangulate
+import scanner.grayCode.decode_codes as dc, scanner.triangulation.triangulate as tr, scanner.utils.visualize as vz, scanner.acquisition.camera as cam
+assert dc.__file__.startswith({PKG!r}) and tr.__file__.startswith({PKG!r}), (dc.__file__, tr.__file__)
+assert vz.__file__.startswith({ref!r}) and cam.__file__.startswith({ref!r}), (vz.__file__, cam.__file__)
+from scanner._native import Context
+from scanner.pipeline import scan_to_cloud
+from scanner import pointcloud, sharded
+print("ok")
+"""
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]

@@ -1,0 +1,217 @@
+"""Exactly what bench.py times, at BASELINE.json's full sizes, EVERY pixel against the CPU oracle (-m gpu).
+
+configs[2] (4096x3000x44, 1920x1200 projector) and configs[1] (1920x1080x44, 1920x1080 projector) with bench.py's own calibration
+and bench.py's own device-generated stack (seed 1, noise 3, shadow) go through the call bench.py makes in its timed region --
+``slgc_scan_dev`` with no count, caller-provided int16 maps, algebraic mode = ONE fused kernel -- and through the two-kernel
+pipeline and a two-run merge.  The oracle (oracle/slgc_oracle.c, all host cores) decodes and triangulates the downloaded stack:
+maps bit-exact, finite mask identical, XYZ within 1e-4 elementwise (reference: decode_codes.py:90-229, src/3-capture_decode.py:95-100,
+triangulate.py:56-61,84-95).  configs[4] (16 independent 1920x1080x44 scans, replicas only) runs through bench.py's own lanes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+import oracle_c as oc
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+XYZ_RTOL = 1e-4   # BASELINE.json: triangulated XYZ within 1e-4 relative
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scanner import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def oracle_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oc.set_threads(max(1, min(64, n)))
+    yield
+    oc.set_threads(1)
+
+
+def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T):
+    """NumPy twin of tri_is_flat (csrc/tri_math.h) on the oracle's float32 rays: which decodable pixels take the guarded path."""
+    H, W = h.shape
+    ok = (h != -1) & (v != -1)
+    yy, xx = np.nonzero(ok)
+    cam = oc.undistort(np.stack([xx, yy], 1).astype(np.float32), K, cd, R).astype(np.float64)
+    pu = np.minimum(proj_size[0] - 1, h[ok])
+    pv = np.minimum(proj_size[1] - 1, v[ok])
+    prj = oc.undistort(np.stack([pu, pv], 1).astype(np.float32), pk, pd).astype(np.float64)
+    t = np.asarray(T, dtype=np.float64).reshape(3)
+    tl2 = float(t @ t)
+    A = -(t[0] * cam[:, 0] + t[1] * cam[:, 1] + t[2])
+    B = t[0] * prj[:, 0] + t[1] * prj[:, 1] + t[2]
+    ta = tl2 * (cam[:, 0] ** 2 + cam[:, 1] ** 2 + 1.0)
+    tb = tl2 * (prj[:, 0] ** 2 + prj[:, 1] ** 2 + 1.0)
+    ra, rb = ta - A * A, tb - B * B
+    D = np.sqrt(np.maximum(ra, 0)) * B + A * np.sqrt(np.maximum(rb, 0))
+    flat = (rb < 5e-3 * tb) | (D * D * np.minimum(ra * tb, rb * ta) < 1e-4 * (ta * tb) ** 2)
+    out = np.zeros((H, W), bool)
+    out[yy, xx] = flat
+    return out
+
+
+def compare_scan(got_h, got_v, got_xyz, ref_h, ref_v, ref_xyz, what):
+    assert np.array_equal(got_h, ref_h), f"{what}: h map differs in {(got_h != ref_h).sum()} pixels"
+    assert np.array_equal(got_v, ref_v), f"{what}: v map differs in {(got_v != ref_v).sum()} pixels"
+    ok = (ref_h != -1) & (ref_v != -1)
+    fin = np.isfinite(got_xyz).all(axis=2)
+    assert np.isnan(got_xyz[~ok]).all(), f"{what}: undecodable pixels must be NaN"
+    ref = np.moveaxis(ref_xyz, 0, -1)
+    rfin = np.isfinite(ref).all(axis=2)
+    assert np.array_equal(fin & ok, rfin & ok), f"{what}: finite mask differs in {((fin & ok) != (rfin & ok)).sum()} pixels"
+    m = ok & rfin
+    err = np.abs(got_xyz[m].astype(np.float64) - ref[m]) / np.maximum(np.abs(ref[m]), 1e-300)
+    worst = float(err.max()) if err.size else 0.0
+    assert worst <= XYZ_RTOL, f"{what}: worst elementwise relative XYZ error {worst:.3e} > {XYZ_RTOL}"
+    return int(ok.sum()), worst
+
+
+@pytest.mark.parametrize("workload,expect_valid", [("c3_4096x3000x44", 9_924_736), ("c2_1920x1080x44", None)])
+def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
+    calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, row0=0, rows=H, seed=1, noise=3, shadow=True)     # bench.py's stacks[0]
+    maps, xyz, cnt = ctx.alloc(px * 4), ctx.alloc(px * 12), ctx.alloc(16)
+    ctx.synchronize()
+    st = stack.download((N, H, W), np.uint8)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+
+    def run(mode):
+        maps.zero()
+        xyz.zero()
+        ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+        ctx.synchronize()
+        return (maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32))
+
+    # (1) the timed region of bench.py: fused kernel, algebraic (guarded) form, no count
+    valid, worst_fused = compare_scan(*run(_native.TRI_ALGEBRAIC), ref_h, ref_v, ref_xyz, workload + " fused")
+    if expect_valid is not None:
+        assert valid == expect_valid
+    # (2) bench.py's "split_pipeline": decode kernel + dense triangulation kernel
+    _, worst_split = compare_scan(*run(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT), ref_h, ref_v, ref_xyz, workload + " split")
+    # (3) the exact (acos / sin) dense kernel on the same maps
+    _, worst_exact = compare_scan(*run(_native.TRI_EXACT), ref_h, ref_v, ref_xyz, workload + " exact")
+    assert worst_exact < 1e-6
+    # guard path: how many pixels the fused / dense kernels redo on the reference's float32 intermediates
+    cnt.zero()
+    ctx.guard_count_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), cnt.ptr)
+    ctx.synchronize()
+    n_ok, n_flat = (int(x) for x in cnt.download((2,), np.uint64))
+    assert n_ok == valid
+    flat_ref = flat_mask_np(ref_h, ref_v, (pw, ph), *calib)
+    assert abs(n_flat - int(flat_ref.sum())) <= 2       # same test on the same rays; fast_sqrt vs sqrt can move a pixel sitting on the threshold
+    print(f"\n{workload}: {valid} / {px} decodable, {n_flat} on the guarded path ({100.0 * n_flat / max(valid, 1):.3f} %), worst rel. XYZ error "
+          f"fused {worst_fused:.2e} split {worst_split:.2e} exact {worst_exact:.2e}")
+    for b in (stack, maps, xyz, cnt):
+        b.free()
+
+
+def test_bench_configuration_two_runs_every_pixel(ctx):
+    """src/3-capture_decode.py:95-96 (MAX_NB_RUNS = 2) at 4096x3000x44: two captures max-merged per code bit inside the fused kernel."""
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS["c3_4096x3000x44"]
+    calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(2 * N * px)
+    ctx.synth_scene_dev(stack.at(0), px, N, H, W, seed=1, noise=3, shadow=True)
+    ctx.synth_scene_dev(stack.at(N * px), px, N, H, W, seed=2, noise=9, shadow=False)    # noisier second capture, no shadow: the merge matters
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.scan_dev(stack.ptr, 2, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+    ctx.synchronize()
+    st = stack.download((2, N, H, W), np.uint8)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+    single_h, _ = oc.decode(st[0])
+    assert (ref_h != single_h).sum() > 1000                                                # the second run really changes the result
+    valid, worst = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32),
+                                ref_h, ref_v, ref_xyz, "two runs fused")
+    print(f"\ntwo runs: {valid} / {px} decodable, worst rel. XYZ error {worst:.2e}")
+    for b in (stack, maps, xyz):
+        b.free()
+
+
+def test_throughput_mode_scans_match_oracle(ctx):
+    """BASELINE.json configs[4]: bench.py's own lanes (contexts / streams / rotated stacks), one step of 16 scans; the results of two
+    of the scans (one per lane) are compared with the oracle, every pixel."""
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS["c2_1920x1080x44"]
+    calib = bench.calibration(W, H, pw, ph)
+    px = W * H
+    lanes = bench.throughput_lanes(_native, 0, 16, 2)
+    try:
+        plan = bench.throughput_step(lanes, 16, 0, _native.TRI_ALGEBRAIC)                 # [(lane index, stack index)] in issue order
+        for c, _, _, _ in lanes:
+            c.synchronize()
+        assert len(plan) == 16
+        checked = set()
+        for li, si in reversed(plan):                     # the LAST scan issued on each lane is what its output buffers hold
+            if li in checked:
+                continue
+            checked.add(li)
+            c, stacks, maps, xyz = lanes[li]
+            st = stacks[si].download((N, H, W), np.uint8)
+            ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+            compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32),
+                         ref_h, ref_v, ref_xyz, f"throughput lane {li} stack {si}")
+        assert len(checked) == 2
+    finally:
+        for c, _, _, _ in lanes:
+            c.close()
+
+
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", None])
+def test_device_resident_reference_product(ctx, workload):
+    """slgc_cloud_lists_dev: the x-major lists of get_cam_proj_pts (triangulate.py:52-71), the colour gather from a device-resident
+    white image and the float64 (3,M) point array (:95), built in HBM from the fused scan's maps + dense XYZ -- vs the oracle."""
+    from scanner import _native
+    rng = np.random.default_rng(5)
+    if workload:
+        W, H, pw, ph, N = bench.WORKLOADS[workload]
+        calib = bench.calibration(W, H, pw, ph)
+    else:                                                    # ragged: W not a multiple of the 64-column tile, H not of the 32-row chunk
+        W, H, pw, ph, N = 332, 77, 300, 200, 44
+        K = np.array([[300.0, 0, W / 2], [0, 300.0, H / 2], [0, 0, 1]])
+        _, cd, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
+        calib = (K, cd, pk, pd, R, T)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=3, noise=3, shadow=True)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    white_h = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    white = ctx.alloc(px * 3).upload(white_h)
+    lists = ctx.alloc_cloud_lists(px, colors=True)
+    ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+    ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), xyz.ptr, white.ptr, W, H, (pw, ph), lists)
+    cam, proj, pts, col = lists.download()
+    h = maps.download((H, W), np.int16).astype(np.int64)
+    v = maps.download((H, W), np.int16, px * 2).astype(np.int64)
+    dense = xyz.download((H, W, 3), np.float32)
+    rcam, rproj, rcol = oc.cam_proj_pts(h, v, (W, H), (pw, ph), white_h, order="x")
+    assert len(rcam) > 0.5 * px
+    assert np.array_equal(cam, rcam) and np.array_equal(proj, rproj) and np.array_equal(col, rcol)
+    xs, ys = rcam[:, 0].astype(np.int64), rcam[:, 1].astype(np.int64)
+    assert pts.shape == (3, len(rcam)) and np.array_equal(pts, dense[ys, xs].astype(np.float64).T)
+    # lists without points / colours
+    bare = ctx.alloc_cloud_lists(px, colors=False, points=False)
+    ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), None, None, W, H, (pw, ph), bare)
+    c2, p2, none_pts, none_col = bare.download()
+    assert none_pts is None and none_col is None and np.array_equal(c2, rcam) and np.array_equal(p2, rproj)
+    for b in (stack, maps, xyz, white):
+        b.free()
+    lists.free()
+    bare.free()

@@ -831,7 +831,7 @@ def test_scan_dev_ragged_sizes(ctx, calib):
 
 def test_scan_to_cloud_matches_reference_pipeline(calib):
     """One-upload pipeline == the reference's script 3 tail + script 4 (restated by the oracle) on the same captures."""
-    from scanner import scan_to_cloud
+    from scanner.pipeline import scan_to_cloud
     N, H, W = 42, 72, 160
     rng = np.random.default_rng(31)
     run0, _, _ = onp.synth_scene_int(N, H, W, seed=3, noise=4)
@@ -900,7 +900,7 @@ def test_to_gray_fixed_point_luma(ctx):
 
 def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
     """k-NN mean distances vs scipy's exact cKDTree on a scanner-like surface with outliers, clusters and duplicates."""
-    from scanner.utils import pointcloud as pc
+    from scanner import pointcloud as pc
     rng = np.random.default_rng(51)
     yy, xx = np.mgrid[0:240, 0:320]
     surf = np.stack([xx * 1e-3, yy * 1e-3, 0.4 + 0.05 * np.sin(xx / 40.0) * np.cos(yy / 30.0)], -1).reshape(-1, 3)
@@ -959,7 +959,7 @@ def test_decode_randomised_configurations(ctx):
 def test_config1_full_size_against_the_reference(calib):
     """BASELINE.json configs[0] at full size through the one-call pipeline, against outputs of the reference itself."""
     import hashlib
-    from scanner import scan_to_cloud
+    from scanner.pipeline import scan_to_cloud
     z = np.load(os.path.join(GOLDEN, "config1.npz"))
     N, H, W, seed, noise = (int(x) for x in z["params"])
     stack, _, _ = onp.synth_scene_int(N, H, W, seed=seed, noise=noise, shadow=True)

@@ -129,6 +129,19 @@ def _worker(rank, world, port, H, W, N, q):
             outs.append(scm.fetch_dense())
             for cp, got in zip(caps, outs):
                 check_dense(got, cp)
+        # ---- "xyz" strategy: fused kernel per band into its slot of the full maps / XYZ, three in-place band all-gathers
+        scx = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_ALGEBRAIC, exchange_kind="xyz")
+        scx.scan(bufs[2].ptr, plane)
+        check_dense(scx.fetch_dense(), caps[2])
+        outs = []
+        for j, b in enumerate(bufs):
+            scx.submit(b.ptr, plane)
+            if j:
+                outs.append(scx.fetch_dense())
+        scx.flush()
+        outs.append(scx.fetch_dense())
+        for cp, got in zip(caps, outs):
+            check_dense(got, cp)
         # ---- "records" strategy: counts all-gather + all-gatherv of {xyz, key} records
         sc = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_EXACT, exchange_kind="records")
         total = sc.scan(bufs[1].ptr, plane)

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3dscanner-graycode_amd")); sys.path.insert(0, ROOT)
 from scanner import _native
-from scanner.utils import pointcloud as pc
+from scanner import pointcloud as pc
 import bench
 W, H, PW, PH, N = (int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "4096,3000,1920,1200,44").split(","))
 ctx = _native.Context(0)
