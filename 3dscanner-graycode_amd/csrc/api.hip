@@ -1,9 +1,12 @@
 // api.hip -- the C-ABI of libslgc.so (declared in include/slgc.h): context, device memory, and the host-buffer
 // entry points that mirror the reference's Python functions.  No CPU fallback anywhere: every entry point runs HIP
 // kernels on the context's device or returns an error.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "slgc_internal.h"
 
@@ -68,15 +71,104 @@ int check_ctx(slgc_ctx *ctx)
 
 size_t esize(int dtype) { return dtype == SLGC_F64 ? 8 : 1; }
 
-// Upload n_runs host stacks into workspace slot 0 back to back.
-int upload_runs(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, size_t npix, RunPtrs *out)
+// The reference's own caller hands over a float64 stack whose values are uint8 grey levels (src/3-capture_decode.py:66-70:
+// cv2.cvtColor output copied into an np.zeros float64 array).  Shipping it as it is costs 8 bytes per sample over PCIe and forces
+// the float64 kernel; instead the host side of the C-ABI narrows it: every sample is checked to be an integer in [0, 255]
+// and written as one byte into pinned staging, on host threads.  The FIRST sample that is not (a fraction, a negative, > 255,
+// NaN, inf) aborts the narrowing and the call falls back to the float64 kernel -- same arithmetic, same results either way
+// (a uint8 stack means "these grey levels").  Returns true when `dst` holds the narrowed samples of all runs.
+bool narrow_f64_to_u8(const void *const *stacks, int n_runs, size_t elems, uint8_t *dst)
 {
-    const size_t run_bytes = (size_t)N * npix * esize(dtype);
+    const size_t total = elems * (size_t)n_runs;
+    if (total == 0) return true;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthr = hw ? hw : 4;
+    if (nthr > 16) nthr = 16;
+    const size_t chunk = 1u << 20;                               // samples per work item (8 MB of float64)
+    const size_t nchunks = (total + chunk - 1) / chunk;
+    if (nthr > nchunks) nthr = nchunks;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto work = [&]() {
+        for (;;) {
+            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= nchunks || bad.load(std::memory_order_relaxed)) return;
+            const size_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
+            size_t i = lo;
+            while (i < hi) {
+                const size_t r = i / elems, off = i - r * elems;
+                const size_t n = (hi - i) < (elems - off) ? (hi - i) : (elems - off);     // stay inside run r
+                const double *src = (const double *)stacks[r] + off;
+                uint8_t *out = dst + i;
+                unsigned wrong = 0;
+                for (size_t k = 0; k < n; ++k) {
+                    const double x = src[k];
+                    const bool in_range = (x >= 0.0) & (x <= 255.0);                      // false for NaN
+                    const int q = in_range ? (int)x : 0;
+                    out[k] = (uint8_t)q;
+                    wrong |= (unsigned)(!in_range) | (unsigned)((double)q != x);
+                }
+                if (wrong) {
+                    bad.store(true, std::memory_order_relaxed);
+                    return;
+                }
+                i += n;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return !bad.load();
+}
+
+int host_staging(slgc_ctx *ctx, size_t bytes, void **out)
+{
+    if (ctx->stage_bytes < bytes) {
+        if (ctx->stage) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipHostFree(ctx->stage);
+            ctx->stage = nullptr;
+            ctx->stage_bytes = 0;
+        }
+        if (hipHostMalloc(&ctx->stage, bytes + bytes / 8, hipHostMallocDefault) != hipSuccess)
+            return slgc_fail(ctx, SLGC_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+        ctx->stage_bytes = bytes + bytes / 8;
+    }
+    *out = ctx->stage;
+    return SLGC_OK;
+}
+
+// Upload n_runs host stacks into workspace slot 0 back to back.  *dtype is in/out: a float64 stack that narrows to uint8 (above)
+// is uploaded as uint8 (1/8 of the bytes, from pinned memory) and *dtype becomes SLGC_U8 for the kernels that follow.
+int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs, int N, size_t npix, RunPtrs *out)
+{
+    for (int r = 0; r < n_runs; ++r)
+        if (!stacks[r]) return slgc_fail(ctx, SLGC_EINVAL, "stack %d is null", r);
+    const size_t elems = (size_t)N * npix;
+    ctx->last_input_path = *dtype == SLGC_U8 ? 0 : 2;
+    static const int pack = xcd_env("SLGC_F64_PACK", 1);          // 0: always ship float64 (A/B of the narrowing)
+    if (*dtype == SLGC_F64 && pack && elems) {
+        void *st;
+        int rc = host_staging(ctx, elems * n_runs, &st);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the staging buffer may still feed the previous call's copy
+        if (narrow_f64_to_u8(stacks, n_runs, elems, (uint8_t *)st)) {
+            void *d;
+            if ((rc = slgc_ws(ctx, 0, elems * n_runs, &d))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(d, st, elems * n_runs, hipMemcpyHostToDevice, ctx->stream));
+            for (int r = 0; r < n_runs; ++r) out->p[r] = (char *)d + (size_t)r * elems;
+            *dtype = SLGC_U8;
+            ctx->last_input_path = 1;
+            return SLGC_OK;
+        }
+    }
+    const size_t run_bytes = elems * esize(*dtype);
     void *d;
     int rc = slgc_ws(ctx, 0, run_bytes * n_runs, &d);
     if (rc) return rc;
     for (int r = 0; r < n_runs; ++r) {
-        if (!stacks[r]) return slgc_fail(ctx, SLGC_EINVAL, "stack %d is null", r);
         out->p[r] = (char *)d + (size_t)r * run_bytes;
         if (run_bytes) HIP_TRY(ctx, hipMemcpyAsync((void *)out->p[r], stacks[r], run_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
@@ -152,6 +244,7 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
     if (ctx->count_slots) (void)hipFree(ctx->count_slots);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int i = 0; i < SLGC_MAX_EVENTS; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);
     for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
@@ -162,6 +255,8 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
 }
 
 extern "C" const char *slgc_last_error(slgc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int slgc_last_input_path(slgc_ctx *ctx) { return ctx ? ctx->last_input_path : SLGC_EINVAL; }
 
 extern "C" int slgc_synchronize(slgc_ctx *ctx)
 {
@@ -193,7 +288,7 @@ extern "C" int slgc_direct_indirect(slgc_ctx *ctx, const void *stack, int dtype,
     if (slgc_make_geom(N, 1, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d", N);
     const size_t npix = (size_t)H * W;
     RunPtrs runs{};
-    if ((rc = upload_runs(ctx, &stack, dtype, 1, N, npix, &runs))) return rc;
+    if ((rc = upload_runs(ctx, &stack, &dtype, 1, N, npix, &runs))) return rc;
     void *d_out;
     if ((rc = slgc_ws(ctx, 1, npix * 16, &d_out))) return rc;
     double *d_ld = (double *)d_out, *d_lg = d_ld + npix;
@@ -220,7 +315,7 @@ static int codes_common(slgc_ctx *ctx, const void *stack, int dtype, int N, int 
     if (slgc_make_geom(N, 1, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d", N);
     const size_t npix = (size_t)H * W;
     RunPtrs runs{};
-    if ((rc = upload_runs(ctx, &stack, dtype, 1, N, npix, &runs))) return rc;
+    if ((rc = upload_runs(ctx, &stack, &dtype, 1, N, npix, &runs))) return rc;
     double *d_ld = nullptr, *d_lg = nullptr;
     if (L_d) {
         void *d_in;
@@ -300,7 +395,7 @@ extern "C" int slgc_decode(slgc_ctx *ctx, const void *const *stacks, int dtype, 
     if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d (max %d)", N, n_runs, SLGC_MAX_RUNS);
     const size_t npix = (size_t)H * W;
     RunPtrs runs{};
-    if ((rc = upload_runs(ctx, stacks, dtype, n_runs, N, npix, &runs))) return rc;
+    if ((rc = upload_runs(ctx, stacks, &dtype, n_runs, N, npix, &runs))) return rc;
     void *d_maps;
     if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
     int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
@@ -433,6 +528,23 @@ extern "C" int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float
     return SLGC_OK;
 }
 
+extern "C" int slgc_undistort_points(slgc_ctx *ctx, int which, const float *pts, int64_t M, float *out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if ((which != 0 && which != 1) || M < 0 || (M && (!pts || !out))) return slgc_fail(ctx, SLGC_EINVAL, "which must be 0 (camera) or 1 (projector); null pointer / negative M");
+    if (M == 0) return SLGC_OK;
+    void *d_in, *d_out;
+    if ((rc = slgc_ws(ctx, 1, (size_t)M * 8, &d_in))) return rc;
+    if ((rc = slgc_ws(ctx, 6, (size_t)M * 8, &d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_in, pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_undistort_list(ctx, which, (const float *)d_in, M, (float *)d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
 extern "C" int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept)
 {
     int rc = check_ctx(ctx);
@@ -550,7 +662,7 @@ extern "C" int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int
     if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d (max %d)", N, n_runs, SLGC_MAX_RUNS);
     const size_t npix = (size_t)H * W;
     RunPtrs runs{};
-    if ((rc = upload_runs(ctx, stacks, dtype, n_runs, N, npix, &runs))) return rc;
+    if ((rc = upload_runs(ctx, stacks, &dtype, n_runs, N, npix, &runs))) return rc;
     // 1. decode -> int64 maps (slot 3)
     void *d_maps;
     if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;

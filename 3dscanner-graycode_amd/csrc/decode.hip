@@ -818,6 +818,9 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
         else variant = max_px * 1000 + 256;
     }
     const int abl = variant / 10000000;
+#ifndef SLGC_DIAG
+    if (abl) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: the timing-only ablation kernels exist only in the diagnostic build (make -C 3dscanner-graycode_amd diag)", variant);
+#endif
     variant %= 10000000;
     const int nt = variant / 1000000, alg = (variant / 100000) % 10, px = (variant / 1000) % 100, block = variant % 1000;
     if ((px != 16 && px != 8 && px != 4 && px != 1) || (block != 64 && block != 128 && block != 256) || alg > 1 || nt > 1)

@@ -49,6 +49,9 @@ struct slgc_ctx {
     size_t ws_bytes[SLGC_WS_SLOTS];
     unsigned ws_gen[SLGC_WS_SLOTS];   // bumped every time a slot is handed out (slgc_ws): a *_fetch checks that the slots holding its
                                       // pending result have not been handed to another call since its *_count (SLGC_ESTATE otherwise)
+    void *stage;            // pinned host staging (float64 stacks narrowed to uint8 before the upload)
+    size_t stage_bytes;
+    int last_input_path;    // slgc_last_input_path
     // calibration
     bool have_calib;
     Calib calib;
@@ -132,6 +135,7 @@ int launch_compact_records(slgc_ctx *ctx, const float *d_xyz, int rows, int W, i
 int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_proj, int64_t M, int mode, double *d_xyz);
 int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w,
                             int proj_h, int mode, float *d_xyz, unsigned long long *d_count, const uint8_t *d_wire = nullptr);
+int launch_undistort_list(slgc_ctx *ctx, int which, const float *d_pts, int64_t M, float *d_out);
 int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
                        unsigned long long *d_counts);
 // synth.hip

@@ -292,6 +292,17 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     if (count) block_count_add(count, nvalid);
 }
 
+// cv2.undistortPoints for a point list, as the two call sites of triangulate.py use it: which = 0 the camera call (:84, R = proj_R),
+// which = 1 the projector call (:85, no R).  float32 [M][2] in, float32 [M][2] out (OpenCV returns CV_32FC2 for float32 input).
+__global__ void __launch_bounds__(256) k_undistort_list(const Calib c, int which, const float *__restrict__ pts, size_t M, float *__restrict__ out)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= M) return;
+    const float2 p = reinterpret_cast<const float2 *>(pts)[q];
+    const Ray2 r = which == 0 ? undistort_point(p.x, p.y, c.cam_k, c.cam_d, c.R) : undistort_point(p.x, p.y, c.proj_k, c.proj_d, nullptr);
+    reinterpret_cast<float2 *>(out)[q] = make_float2(r.x, r.y);
+}
+
 // Diagnostic: how many decodable pixels of a band take the guarded (float32-mirror) path of triangulate4 -- the same
 // tri_is_flat test on the same table rays.  counts[0] += decodable pixels, counts[1] += flagged pixels.
 __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const int16_t *__restrict__ h, const int16_t *__restrict__ v,
@@ -317,6 +328,14 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
 }
 
 }  // namespace
+
+int launch_undistort_list(slgc_ctx *ctx, int which, const float *d_pts, int64_t M, float *d_out)
+{
+    if (M == 0) return SLGC_OK;
+    hipLaunchKernelGGL(k_undistort_list, dim3((unsigned)(((size_t)M + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, which, d_pts, (size_t)M, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
 
 int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
                        unsigned long long *d_counts)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "slgc_destroy": (_i, [_vp]),
     "slgc_last_error": (C.c_char_p, [_vp]),
     "slgc_synchronize": (_i, [_vp]),
+    "slgc_last_input_path": (_i, [_vp]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
     "slgc_direct_indirect": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "slgc_is_lit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _d, _d, _vp, _vp]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "slgc_cam_proj_pts_count": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, C.POINTER(_i64)]),
     "slgc_cam_proj_pts_fetch": (_i, [_vp, _vp, _vp, _vp]),
     "slgc_triangulate": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "slgc_undistort_points": (_i, [_vp, _i, _vp, _i64, _vp]),
     "slgc_filter_count": (_i, [_vp, _vp, _vp, _i64, _d, C.POINTER(_i64)]),
     "slgc_filter_fetch": (_i, [_vp, _vp, _vp]),
     "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -244,6 +246,10 @@ class Context:
     def synchronize(self):
         self._ck(lib().slgc_synchronize(self._h))
 
+    def last_input_path(self) -> int:
+        """0 = uint8 stack as given, 1 = float64 stack narrowed to uint8 on the host, 2 = float64 kernel (slgc_last_input_path)."""
+        return int(lib().slgc_last_input_path(self._h))
+
     def dev_memset(self, dptr: int, value: int, nbytes: int):
         self._ck(lib().slgc_dev_memset(self._h, dptr, int(value), int(nbytes)))
 
@@ -366,6 +372,13 @@ class Context:
         xyz = np.empty((3, len(a)), np.float64)
         self._ck(lib().slgc_triangulate(self._h, _ptr(a), _ptr(b), len(a), int(mode), _ptr(xyz)))
         return xyz
+
+    def undistort_points(self, pts, projector: bool = False):
+        """cv2.undistortPoints as triangulate.py:84 (camera, R = proj_R) / :85 (projector) call it; float32 [M,2] -> float32 [M,2]."""
+        a = np.ascontiguousarray(np.asarray(pts, dtype=np.float32).reshape(-1, 2))
+        out = np.empty_like(a)
+        self._ck(lib().slgc_undistort_points(self._h, 1 if projector else 0, _ptr(a), len(a), _ptr(out)))
+        return out
 
     def filter_3d_pts(self, pts, colors, threshold=0.5):
         x = np.ascontiguousarray(pts, dtype=np.float64)

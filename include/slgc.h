@@ -16,7 +16,8 @@
  *  - a context = (device, HIP stream, workspace).  Calls on one context are serialised by the
  *    caller; separate contexts may be used from separate threads (ctypes releases the GIL).
  *  - image stacks are frame-major [N][H][W] (src/3-capture_decode.py:68-70), dtype SLGC_U8 or
- *    SLGC_F64 (the reference's own float64 stack).  14 <= N <= 65 (code length L=int((N-2)/4) <= 15).
+ *    SLGC_F64 (the reference's own float64 stack; narrowed to uint8 on the host when every sample is a grey level,
+ *    see slgc_last_input_path).  14 <= N <= 65 (code length L=int((N-2)/4) <= 15).
  *  - there is NO CPU fallback: without a HIP device slgc_create fails with SLGC_ENODEV.
  */
 #ifndef SLGC_H
@@ -61,6 +62,11 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
+/* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
+ * integers in [0,255] (what src/3-capture_decode.py:66-70 builds), narrowed to uint8 on host threads into pinned staging and
+ * uploaded as 1 byte per sample; 2 = float64 shipped as it is (a fraction / negative / NaN was found) and decoded by the float64
+ * kernel.  Results are identical on all three. */
+int slgc_last_input_path(slgc_ctx *ctx);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
 
 /* ------------------------------------------------------------------ decode, host buffers */
@@ -103,6 +109,13 @@ int slgc_cam_proj_pts_fetch(slgc_ctx *ctx, float *cam_pts, float *proj_pts, doub
 
 /* triangulate(cam_pts, proj_pts) -- triangulate.py:73-97.  xyz: float64 (3,M) row-major. */
 int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float *proj_pts, int64_t M, int mode, double *xyz);
+
+/* The two cv2.undistortPoints calls inside triangulate (triangulate.py:84-85) on their own: which = 0 the camera call
+ * (cam_mtx, cam_dist, R = proj_R), which = 1 the projector call (proj_mtx, proj_dist).  pts / out: float32 [M][2].  OpenCV
+ * (opencv-contrib-python 4.8.0.76) is third-party and absent from the build container: this is the published algorithm of
+ * cvUndistortPointsInternal restated (5 fixed-point iterations, icdist < 0 bail-out, R after, float32 out) -- PARITY UNPINNED;
+ * tools/pin_third_party.py closes it the day a cv2 wheel is at hand. */
+int slgc_undistort_points(slgc_ctx *ctx, int which, const float *pts, int64_t M, float *out);
 
 /* filter_3d_pts(Pts, colors, threshold) -- triangulate.py:99-122.  _count then _fetch (order preserved). */
 int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept);

@@ -129,7 +129,111 @@ def test_decode_f64_non_integer_stack(ctx):
     assert np.array_equal(a, ra, equal_nan=True) and np.array_equal(b, rb, equal_nan=True)
 
 
+def test_float64_stack_of_grey_levels_is_narrowed_on_the_host(ctx, calib):
+    """The reference's unchanged caller (src/3-capture_decode.py:66-70) hands over float64 holding uint8 grey levels: the C-ABI
+    narrows it to uint8 before the upload (path 1); anything else -- a fraction, NaN, a negative, 256 -- takes the float64 kernel
+    (path 2).  Both branches, every host entry point, against the oracle."""
+    rng = np.random.default_rng(21)
+    N, H, W = 44, 70, 133
+    u8, _, _ = onp.synth_scene_int(N, H, W, seed=5)
+    u8[:, :3, :9] = 0                                       # black = white = 0 -> NaN pixels survive the narrowing
+    f64 = u8.astype(np.float64)
+    f64[7, 10, 11] = -0.0 if u8[7, 10, 11] == 0 else f64[7, 10, 11]
+    ref = oc.decode(u8)
+    for stack, want_path in ((u8, 0), (f64, 1)):
+        hp, vp = ctx.decode(stack)
+        assert ctx.last_input_path() == want_path
+        assert np.array_equal(hp, ref[0]) and np.array_equal(vp, ref[1])
+    hc, vc = ctx.codes(f64)
+    assert ctx.last_input_path() == 1
+    rhc, rvc = oc.get_codes(u8)
+    assert np.array_equal(hc, rhc) and np.array_equal(vc, rvc)
+    ld, lg = ctx.direct_indirect(f64)
+    rld, rlg = oc.direct_indirect(u8)
+    assert ctx.last_input_path() == 1 and np.array_equal(ld, rld, equal_nan=True) and np.array_equal(lg, rlg, equal_nan=True)
+    # two runs: narrowed together
+    u8b, _, _ = onp.synth_scene_int(N, H, W, seed=6, noise=7)
+    ref2 = oc.decode(np.stack([u8, u8b]))
+    hp, vp = ctx.decode([f64, u8b.astype(np.float64)])
+    assert ctx.last_input_path() == 1 and np.array_equal(hp, ref2[0]) and np.array_equal(vp, ref2[1])
+    # the first sample that is not a grey level sends the whole call to the float64 kernel -- wherever it sits
+    for where, val in (((0, 0, 0), 0.5), ((N - 1, H - 1, W - 1), 255.0000001), ((20, 33, 64), np.nan), ((3, 2, 1), -1.0), ((9, 9, 9), 256.0),
+                       ((12, 0, 5), np.inf), ((43, 69, 0), 1e300)):
+        bad = f64.copy()
+        bad[where] = val
+        r = oc.decode(bad)
+        hp, vp = ctx.decode(bad)
+        assert ctx.last_input_path() == 2, (where, val)
+        assert np.array_equal(hp, r[0]) and np.array_equal(vp, r[1]), (where, val)
+    bad2 = u8b.astype(np.float64)
+    bad2[30, 40, 50] += 0.25                                # only the SECOND run carries the fraction
+    r = oc.decode(np.stack([f64, bad2]))
+    hp, vp = ctx.decode([f64, bad2])
+    assert ctx.last_input_path() == 2 and np.array_equal(hp, r[0]) and np.array_equal(vp, r[1])
+    # whole pipeline through the narrowed path
+    from scanner.pipeline import scan_to_cloud
+    K = calib["cam_mtx"].copy()
+    K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 250.0, 250.0
+    R, T = rot_y(-20.0), np.array([[0.25], [0.02], [0.04]])
+    a = scan_to_cloud(f64, K, calib["cam_dist"], (160, 120), (1920, 1080), calib["proj_mtx"], calib["proj_dist"], R, T, ctx=ctx)
+    assert ctx.last_input_path() == 1
+    b = scan_to_cloud(u8, K, calib["cam_dist"], (160, 120), (1920, 1080), calib["proj_mtx"], calib["proj_dist"], R, T, ctx=ctx)
+    assert np.array_equal(a["pts"], b["pts"]) and np.array_equal(a["h_pixels"], b["h_pixels"]) and a["pts"].shape[1] > 1000
+    # an empty stack and float32 / int input still work
+    assert ctx.decode(np.zeros((14, 0, 5)))[0].shape == (0, 5)
+    hp, vp = ctx.decode(u8.astype(np.float32))
+    assert ctx.last_input_path() == 1 and np.array_equal(hp, ref[0])
+
+
+def test_c99_host_decodes_through_the_c_abi(tmp_path):
+    """A C host (no Python between it and libslgc.so) runs slgc_decode on a capture read from a file; the maps must be the oracle's."""
+    import subprocess
+    from conftest import ROOT
+    from scanner import _native
+    N, H, W = 26, 24, 40
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=8)
+    st.tofile(tmp_path / "stack.u8")
+    src = tmp_path / "host.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include "slgc.h"
+int main(int argc, char **argv) {
+    int N = atoi(argv[3]), H = atoi(argv[4]), W = atoi(argv[5]);
+    size_t n = (size_t)N * H * W, npix = (size_t)H * W;
+    unsigned char *stack = malloc(n);
+    int64_t *h = malloc(npix * 8), *v = malloc(npix * 8);
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(stack, 1, n, f) != n) return 2;
+    fclose(f);
+    slgc_ctx *ctx;
+    const void *runs[1];
+    runs[0] = stack;
+    if (slgc_device_count() < 1) return 3;
+    if (slgc_create(0, &ctx)) return 4;
+    if (slgc_decode(ctx, runs, SLGC_U8, 1, N, H, W, 1.0, 10.0, h, v)) { fprintf(stderr, "%s
+", slgc_last_error(ctx)); return 5; }
+    if (slgc_decode(ctx, runs, SLGC_U8, 1, 10, H, W, 1.0, 10.0, h, v) != SLGC_EINVAL) return 6;     /* N < 14: the reference raises too */
+    f = fopen(argv[2], "wb");
+    fwrite(h, 8, npix, f); fwrite(v, 8, npix, f);
+    fclose(f);
+    return slgc_destroy(ctx);
+}
+""")
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lslgc", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([str(exe), str(tmp_path / "stack.u8"), str(tmp_path / "maps.i64"), str(N), str(H), str(W)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "maps.i64", dtype=np.int64).reshape(2, H, W)
+    ref = oc.decode(st)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
 def test_bad_arguments(ctx):
+    with pytest.raises(ValueError, match="diagnostic build"):
+        dev_decode(ctx, np.zeros((1, 44, 8, 64), np.uint8), variant=11104128)      # timing-only ablation kernels are not in the shipped library
     with pytest.raises(ValueError):
         ctx.decode(np.zeros((10, 4, 4), np.uint8))          # the reference raises for N < 14 too
     with pytest.raises(ValueError):
