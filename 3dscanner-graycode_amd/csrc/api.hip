@@ -220,6 +220,12 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     if (!ctx) return SLGC_ENOMEM;
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device;
+    ctx->tune_fuse_tail = xcd_env("SLGC_FUSE_TAIL", 1);
+    ctx->tune_proj_tile = xcd_env("SLGC_PROJ_TILE", 0);
+    ctx->tune_fuse_nt = xcd_env("SLGC_FUSE_NT", 3);
+    ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
+    ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
+    ctx->tune_park = xcd_env("SLGC_PARK", 1);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;
@@ -255,6 +261,24 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
 }
 
 extern "C" const char *slgc_last_error(slgc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+// Tuning knobs: every value gives the same results; they exist so that two settings can be timed in ONE process (interleaved A/B).
+extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return SLGC_EINVAL;
+    if (!strcmp(name, "fuse_tail")) ctx->tune_fuse_tail = value != 0;
+    else if (!strcmp(name, "proj_tile")) ctx->tune_proj_tile = value != 0;      // the projector table is rebuilt on the next use
+    else if (!strcmp(name, "fuse_nt")) ctx->tune_fuse_nt = value & 3;
+    else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
+    else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
+    else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
+    else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
+#ifdef SLGC_DIAG
+    else if (!strcmp(name, "fuse_abl")) ctx->tune_fuse_abl = value;
+#endif
+    else return slgc_fail(ctx, SLGC_EINVAL, "unknown tuning knob '%s'", name);
+    return SLGC_OK;
+}
 
 extern "C" int slgc_last_input_path(slgc_ctx *ctx) { return ctx ? ctx->last_input_path : SLGC_EINVAL; }
 

@@ -259,6 +259,22 @@ extern "C" int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack,
     }
     int16_t *my_h = d_h_full + (size_t)row0 * W, *my_v = d_v_full + (size_t)row0 * W;
     if (rows > 0 && (rc = slgc_decode_dev(ctx, d_band_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, m, my_h, my_v, 0))) return rc;
+    const int code_bits = (int)((double)(N - 2) / 4.0);
+    if (ctx->tune_wire && code_bits <= SLGC_WIRE_MAX_CODE_BITS && (mode & 3) <= SLGC_TRI_ALGEBRAIC) {
+        // 3-byte wire format (slgc_tune "wire" = 1): pack the band into its slot of a packed full-size buffer, ONE in-place all-gather of
+        // 3 B/pixel, and the triangulation kernel unpacks while it loads (it also writes the int16 maps, which stay a product)
+        void *wire;
+        if ((rc = slgc_ws(ctx, 11, (size_t)H * W * 3 + 64, &wire))) return rc;
+        for (int r = 0; r < ctx->nranks; ++r) {
+            counts[r] = counts[r] / 2 * 3;
+            displs[r] = displs[r] / 2 * 3;
+        }
+        uint8_t *my_w = (uint8_t *)wire + displs[ctx->rank];
+        if (rows > 0 && (rc = slgc_pack_hv24_dev(ctx, my_h, my_v, (size_t)rows * W, code_bits, my_w))) return rc;
+        if ((rc = slgc_comm_allgatherv_begin(ctx, my_w, wire, counts, displs, 3))) return rc;
+        if ((rc = slgc_comm_wait(ctx, 3))) return rc;
+        return slgc_triangulate_wire_dev(ctx, (const uint8_t *)wire, H, W, 0, proj_w, proj_h, mode & 1, d_h_full, d_v_full, d_xyz_full, nullptr);
+    }
     if ((rc = slgc_comm_allgatherv_pair_begin(ctx, my_h, d_h_full, my_v, d_v_full, counts, displs, 3))) return rc;
     if ((rc = slgc_comm_wait(ctx, 3))) return rc;
     return slgc_triangulate_maps_dev(ctx, d_h_full, d_v_full, H, W, 0, proj_w, proj_h, mode & 3, d_xyz_full, nullptr);

@@ -234,8 +234,9 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     const float2 *cam_lut;    // [npix] camera rays of this band
     const float2 *proj_lut;   // 8x8-tiled projector rays
     float *xyz;               // [npix][3]
-    int proj_w, proj_h, tiles_x;
+    int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
+    int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     double T[3], t_len;
 };
 
@@ -310,16 +311,54 @@ __device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA,
     else accV &= (y | z);
 }
 
+// Compile-time twin of slgc_make_geom (decode_codes.py:109-111, :149) for the frame counts the generator and BASELINE.json use:
+// which 12 frames feed L_max / L_min, and where each of them is parked in LDS (slot 0..11) for its second use in the bit loop.
+template <int NS>
+struct FrameSpec {
+    static constexpr int L = (NS - 2) / 4;
+    static constexpr int thr(int k)          // absolute frame index of threshold frame k (0..5 -> L_max, 6..11 -> L_min)
+    {
+        const double plf = (double)(NS - 2) / 4.0;
+        const double id[12] = {2 * plf - 2, 2 * plf - 4, 2 * plf - 6, 4 * plf - 2, 4 * plf - 4, 4 * plf - 6, 1, 3, 5, 2 * plf + 1, 2 * plf + 3, 2 * plf + 5};
+        return 2 + (int)(unsigned char)id[k];
+    }
+    struct Table {
+        signed char slot[72];
+    };
+    static constexpr Table make()
+    {
+        Table t{};
+        for (int f = 0; f < 72; ++f) t.slot[f] = -1;
+        for (int k = 11; k >= 0; --k) t.slot[thr(k)] = (signed char)k;     // (a frame used by both lists keeps its lowest slot)
+        return t;
+    }
+    static constexpr Table table = make();
+};
+
+#ifndef SLGC_PARK_DEPTH
+#define SLGC_PARK_DEPTH 2      // steps of frame loads in flight ahead of the step being classified (specialised kernels)
+#endif
+constexpr int kWaveLdsBytes = 4096;     // LDS block of one wave: fused tail [indices 1 KB | rays / XYZ 3 KB], aliased by the 12 parked frames (3 KB)
+
 // ABL (timing-only diagnostic builds, results are wrong): 0 = real kernel; 1 = skip the 14 threshold-frame loads;
 // 2 = loads only (no classification arithmetic).
-template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, bool FUSE = false>
+// NS > 0: specialised for NS frames per run (compile-time frame indices, bit loop fully unrolled) -- the 12 frames that feed the
+// per-pixel thresholds are parked in lane-private LDS words after their first use, so the bit loop reads them from LDS instead of
+// fetching them a second time (the re-reads are L2 hits, but each still costs a vector-memory instruction and its L2 -> CU trip:
+// 11 of the 54 loads per lane at N = 44).  The parked words are read back by the lane that wrote them: no synchronisation.
+template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0>
 __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
+    constexpr bool SPEC = NS > 0;
+    using FS = FrameSpec<SPEC ? NS : 14>;
+    static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
+    uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
     const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
     const uint32_t ps = a.plane_stride;
-    const int L = a.g.L;
+    const int L = SPEC ? FS::L : a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) { mB_h[p] = mB_v[p] = 0u; mV_h[p] = mV_v[p] = MULTI ? 0u : 0xffffffffu; }
@@ -331,12 +370,24 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 #pragma unroll
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
         } else {
-            const Frame<NW, 0> bl = load_frame<NW, 0>(rs, off, 0), wh = load_frame<NW, 0>(rs, off, ps);
-            Frame<NW, 0> hm[6], vm[6];
+            constexpr int TNT = SPEC ? NT : 0;      // parked frames are fetched once: streaming policy; otherwise cacheable (re-read from L2)
+            const Frame<NW, TNT> bl = load_frame<NW, TNT>(rs, off, 0), wh = load_frame<NW, TNT>(rs, off, ps);
+            Frame<NW, TNT> hm[6], vm[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                hm[k] = load_frame<NW, 0>(rs, off, (uint32_t)a.g.hid[k] * ps);
-                vm[k] = load_frame<NW, 0>(rs, off, (uint32_t)a.g.vid[k] * ps);
+                hm[k] = load_frame<NW, TNT>(rs, off, (uint32_t)(SPEC ? FS::thr(k) : a.g.hid[k]) * ps);
+                vm[k] = load_frame<NW, TNT>(rs, off, (uint32_t)(SPEC ? FS::thr(6 + k) : a.g.vid[k]) * ps);
+            }
+            if constexpr (SPEC) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    park[k * 64] = hm[k].w[0];
+                    park[(6 + k) * 64] = vm[k].w[0];
+                }
+                // every parked word is read back by the lane that wrote it; with the loop unrolled the compiler would forward the
+                // stores to those loads, i.e. keep all 12 frames in registers (the variant that loses two waves per SIMD): an opaque
+                // point between the stores and the loads stops that
+                asm volatile("" ::: "memory");
             }
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
@@ -372,23 +423,58 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 #pragma unroll
         for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
         // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
-        uint32_t s_hn = (uint32_t)(2 + 2 * (L - 1)) * ps, s_hi = (uint32_t)(2 + 2 * L + 2 * (L - 1)) * ps;
-        uint32_t s_vn = 3u * ps, s_vi = (uint32_t)(3 + 2 * L) * ps;
-#pragma unroll 2
-        for (int t = 0; t < L; ++t) {
-            const Frame<NW, NT> hn = load_frame<NW, NT>(rs, off, s_hn), hi = load_frame<NW, NT>(rs, off, s_hi);
-            const Frame<NW, NT> vn = load_frame<NW, NT>(rs, off, s_vn), vi = load_frame<NW, NT>(rs, off, s_vi);
-            s_hn -= 2 * ps; s_hi -= 2 * ps; s_vn += 2 * ps; s_vi += 2 * ps;
+        auto step = [&](const Frame<NW, NT> &hn, const Frame<NW, NT> &hi, const Frame<NW, NT> &vn, const Frame<NW, NT> &vi) {
             if constexpr (ABL == 2) {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) { aB_h[2 * q] ^= hn.w[q] + hi.w[q]; aB_v[2 * q] ^= vn.w[q] + vi.w[q]; }
-            } else
+            } else {
 #pragma unroll
-            for (int q = 0; q < NW; ++q) {
-                classify_pk<MULTI>(even_pair(hn.w[q]), even_pair(hi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_h[2 * q], aV_h[2 * q]);
-                classify_pk<MULTI>(odd_pair(hn.w[q]), odd_pair(hi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_h[2 * q + 1], aV_h[2 * q + 1]);
-                classify_pk<MULTI>(even_pair(vn.w[q]), even_pair(vi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_v[2 * q], aV_v[2 * q]);
-                classify_pk<MULTI>(odd_pair(vn.w[q]), odd_pair(vi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_v[2 * q + 1], aV_v[2 * q + 1]);
+                for (int q = 0; q < NW; ++q) {
+                    classify_pk<MULTI>(even_pair(hn.w[q]), even_pair(hi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_h[2 * q], aV_h[2 * q]);
+                    classify_pk<MULTI>(odd_pair(hn.w[q]), odd_pair(hi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_h[2 * q + 1], aV_h[2 * q + 1]);
+                    classify_pk<MULTI>(even_pair(vn.w[q]), even_pair(vi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_v[2 * q], aV_v[2 * q]);
+                    classify_pk<MULTI>(odd_pair(vn.w[q]), odd_pair(vi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_v[2 * q + 1], aV_v[2 * q + 1]);
+                }
+            }
+        };
+        if constexpr (SPEC) {
+            auto fetch = [&](int f) {                   // f is a constant once the loop is unrolled: the choice below folds away
+                Frame<NW, NT> fr;
+                const int slot = FS::table.slot[f];
+                if (slot >= 0) fr.w[0] = park[slot * 64];
+                else fr = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
+                return fr;
+            };
+            // DEPTH steps ahead: the four frames of step t+DEPTH are requested before step t is classified; the scheduling barrier keeps
+            // the unrolled steps from being hoisted on top of each other (unbounded, that costs 270 registers and all but one wave per SIMD)
+            constexpr int DEPTH = SLGC_PARK_DEPTH;
+            Frame<NW, NT> ring[DEPTH + 1][4];
+            auto fetch_step = [&](int t, Frame<NW, NT> (&fr)[4]) {
+                const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
+                fr[0] = fetch(f_hn); fr[1] = fetch(f_hn + 2 * FS::L); fr[2] = fetch(f_vn); fr[3] = fetch(f_vn + 2 * FS::L);
+            };
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+                if (d < FS::L) fetch_step(d, ring[d]);
+#pragma unroll
+            for (int t = 0; t < FS::L; ++t) {
+                if (t + DEPTH < FS::L) fetch_step(t + DEPTH, ring[(t + DEPTH) % (DEPTH + 1)]);
+                Frame<NW, NT> (&cur)[4] = ring[t % (DEPTH + 1)];
+                step(cur[0], cur[1], cur[2], cur[3]);
+                // pin the accumulators here: left alone, the optimiser defers the whole "classified?" chain of every unrolled step to the
+                // end of the loop and keeps each step's intermediates alive until then (230+ registers)
+                asm volatile("" : "+v"(aB_h[0]), "+v"(aB_h[1]), "+v"(aB_v[0]), "+v"(aB_v[1]), "+v"(aV_h[0]), "+v"(aV_h[1]), "+v"(aV_v[0]), "+v"(aV_v[1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            uint32_t s_hn = (uint32_t)(2 + 2 * (L - 1)) * ps, s_hi = (uint32_t)(2 + 2 * L + 2 * (L - 1)) * ps;
+            uint32_t s_vn = 3u * ps, s_vi = (uint32_t)(3 + 2 * L) * ps;
+#pragma unroll 2
+            for (int t = 0; t < L; ++t) {
+                const Frame<NW, NT> hn = load_frame<NW, NT>(rs, off, s_hn), hi = load_frame<NW, NT>(rs, off, s_hi);
+                const Frame<NW, NT> vn = load_frame<NW, NT>(rs, off, s_vn), vi = load_frame<NW, NT>(rs, off, s_vi);
+                s_hn -= 2 * ps; s_hi -= 2 * ps; s_vn += 2 * ps; s_vi += 2 * ps;
+                step(hn, hi, vn, vi);
             }
         }
 #pragma unroll
@@ -445,14 +531,28 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
             __builtin_amdgcn_raw_buffer_store_b128(v4u{wv_[2 * q], wv_[2 * q + 1], wv_[2 * q + 2], wv_[2 * q + 3]}, rv, off * 2u + 8u * q, 0, 0);
         }
     }
-    if constexpr (FUSE) {
+    if constexpr (FUSE != 0) {
         // K3 appended: the maps never leave registers before they are triangulated (triangulate.py:56-61, 86-95 in the
         // cancelled algebraic form; rays from the per-calibration tables).  Same LDS exchange as k_triangulate_maps_lds:
         // indices -> pixel-per-lane gathers -> per-lane triangulation -> wave-contiguous XYZ stores.
-        static_assert(!FUSE || NW == 1, "fused tail is written for 4 pixels per lane");
-        __shared__ uint4 s_idx[BLOCK];
-        __shared__ float4 s_buf[3 * BLOCK];
+        // FUSE == 2: the exchange is WAVE-local -- a wave's 256 pixels (64 lanes x 4) are self-contained, every LDS hand-over
+        // stays inside the wave (LDS operations of one wave execute in order), so the tail has no workgroup barrier at all and
+        // the two waves of a workgroup drift apart freely.  FUSE == 1: the same exchange across the whole workgroup (A/B).
+        static_assert(FUSE == 0 || NW == 1, "fused tail is written for 4 pixels per lane");
+        constexpr bool WAVE = FUSE == 2;
+        constexpr int SPAN = WAVE ? 64 : BLOCK;                     // lanes that exchange with each other
         const int tid = threadIdx.x;
+        const int t = WAVE ? (tid & 63) : tid;                      // index inside the exchanging group
+        const int grp = WAVE ? (tid >> 6) : 0;
+        // a group's block: [SPAN x uint4 indices | 3 * SPAN x float4 rays / XYZ]; with the wave-local tail it is the wave's own 4 KB
+        // block, which the wave's parked frames (dead by now) aliased
+        unsigned char *blk = s_raw + grp * (SPAN * 64);
+        uint4 *s_idx = reinterpret_cast<uint4 *>(blk);
+        float4 *s_buf = reinterpret_cast<float4 *>(blk + SPAN * 16);
+        auto sync = [] {
+            if constexpr (WAVE) wave_lds_sync();
+            else __syncthreads();
+        };
         const bool live = off < a.npix;
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
@@ -464,42 +564,55 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int hv = (int)(short)(hw2[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vw2[j >> 1] >> (16 * (j & 1)));
-                if (!(hv == -1 || vv == -1)) idx[j] = proj_lut_index(min(a.f.proj_w - 1, hv), min(a.f.proj_h - 1, vv), a.f.tiles_x);
+                if (!(hv == -1 || vv == -1)) idx[j] = proj_lut_index(min(a.f.proj_w - 1, hv), min(a.f.proj_h - 1, vv), a.f.tiles_x, a.f.wide);
             }
         }
-        s_idx[tid] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
-        __syncthreads();
+        s_idx[t] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+        sync();
         float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
         const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
+        // four independent gathers in flight per lane: the loads are unconditional (an undecodable pixel reads entry 0, its ray is
+        // never used), so no branch separates them and none waits for the one before
+        if constexpr (ABL == 9) {        // A/B (diagnostic build, correct results): the round-1 form, a branch around every gather
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const uint32_t i = s_idx1[it * BLOCK + tid];
-            s_ray[it * BLOCK + tid] = (i != 0xffffffffu && ABL != 6) ? a.f.proj_lut[i] : make_float2(0.1f, 0.2f);
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t i = s_idx1[it * SPAN + t];
+                s_ray[it * SPAN + t] = (i != 0xffffffffu) ? a.f.proj_lut[i] : make_float2(0.1f, 0.2f);
+            }
+        } else {
+            float2 gr[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const uint32_t i = s_idx1[it * SPAN + t];
+                gr[it] = (ABL != 6) ? a.f.proj_lut[i != 0xffffffffu ? i : 0u] : make_float2(0.1f, 0.2f);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) s_ray[it * SPAN + t] = gr[it];
         }
-        __syncthreads();
-        const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
-        __syncthreads();
+        sync();
+        const float4 r01 = s_buf[2 * t], r23 = s_buf[2 * t + 1];
+        sync();
         const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
         triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
-        s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
-        s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
-        s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
-        __syncthreads();
-        const uint32_t first = blockIdx.x * BLOCK, ngroups = a.npix / 4;           // in 4-pixel groups
-        const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)BLOCK ? ngroups - first : (uint32_t)BLOCK) * 3u) : 0u;
+        s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
+        s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
+        s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
+        sync();
+        const uint32_t first = blockIdx.x * BLOCK + grp * SPAN, ngroups = a.npix / 4;           // in 4-pixel groups
+        const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)SPAN ? ngroups - first : (uint32_t)SPAN) * 3u) : 0u;
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
         for (int it = 0; it < 3; ++it)
-            if ((uint32_t)(it * BLOCK + tid) < nvec && (ABL != 5 || s_buf[it * BLOCK + tid].x == 12345.678f)) {
+            if ((uint32_t)(it * SPAN + t) < nvec && (ABL != 5 || s_buf[it * SPAN + t].x == 12345.678f)) {
                 if (a.f.nt_store & 1) {
                     typedef float v4f __attribute__((ext_vector_type(4)));
-                    const float4 q = s_buf[it * BLOCK + tid];
-                    __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f *>(dst) + it * BLOCK + tid);
+                    const float4 q = s_buf[it * SPAN + t];
+                    __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f *>(dst) + it * SPAN + t);
                 } else {
-                    dst[it * BLOCK + tid] = s_buf[it * BLOCK + tid];
+                    dst[it * SPAN + t] = s_buf[it * SPAN + t];
                 }
             }
     }
@@ -725,12 +838,33 @@ bool decode_fast_eligible(double eps, int *e_out)
     return true;
 }
 
+// The specialised kernels bake the frame indices in: use one only when the run-time geometry (computed on the host exactly like the
+// reference does) agrees with the compile-time table.
+template <int NS>
+static bool spec_matches(const DecodeGeom &g)
+{
+    if (g.N != NS || g.L != FrameSpec<NS>::L) return false;
+    for (int k = 0; k < 6; ++k)
+        if (g.hid[k] != FrameSpec<NS>::thr(k) || g.vid[k] != FrameSpec<NS>::thr(6 + k)) return false;
+    return true;
+}
+
+static int spec_frames(const slgc_ctx *ctx, const DecodeGeom &g)
+{
+    if (!ctx->tune_park) return 0;
+    if (spec_matches<44>(g)) return 44;
+    if (spec_matches<46>(g)) return 46;
+    if (spec_matches<42>(g)) return 42;
+    return 0;
+}
+
 template <int PX, int BLOCK, int NT>
 static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
 {
     const uint32_t groups = a.npix / PX;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + BLOCK - 1) / BLOCK;
+    const int ns = (abl == 0 && PX == 4 && BLOCK == 128 && NT == 1) ? spec_frames(ctx, a.g) : 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     if (abl == 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), a);
@@ -742,10 +876,23 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
 #else
     if (abl != 0) return slgc_fail(ctx, SLGC_EINVAL, "ablation variants exist only in the diagnostic build (make -C 3dscanner-graycode_amd diag)");
 #endif
-    if (a.g.n_runs > 1)
-        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), a);
-    else
-        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), a);
+    {
+    if constexpr (PX == 4 && BLOCK == 128 && NT == 1) {
+#define SLGC_SPEC(NSV)                                                                                             \
+        if (ns == NSV) {                                                                                           \
+            if (a.g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 0, NSV>), dim3(blocks), dim3(128), a);  \
+            else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 0, NSV>), dim3(blocks), dim3(128), a);         \
+        }
+        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42)
+#undef SLGC_SPEC
+    }
+    if (ns == 0) {
+        if (a.g.n_runs > 1)
+            SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, true>), dim3(blocks), dim3(BLOCK), a);
+        else
+            SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false>), dim3(blocks), dim3(BLOCK), a);
+    }
+    }
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -761,26 +908,43 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + npix4);
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
     b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
-    b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = (proj_w + 7) / 8;
-    static const int fuse_nt = xcd_env("SLGC_FUSE_NT", 3);
-    b.f.nt_store = fuse_nt;
+    b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
+    b.f.nt_store = ctx->tune_fuse_nt;
+    b.f.wave_tail = ctx->tune_fuse_tail;
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + 127) / 128;
+    const bool wave = b.f.wave_tail != 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
-    static const int fabl = xcd_env("SLGC_FUSE_ABL", 0);
-    if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, true>), dim3(blocks), dim3(128), b);
-    else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, true>), dim3(blocks), dim3(128), b);
-    else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, true>), dim3(blocks), dim3(128), b);
-    else if (fabl == 8) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 8, true>), dim3(blocks), dim3(128), b);
+    const int fabl = ctx->tune_fuse_abl;
+    if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, 2>), dim3(blocks), dim3(128), b);
+    else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, 2>), dim3(blocks), dim3(128), b);
+    else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, 2>), dim3(blocks), dim3(128), b);
+    else if (fabl == 8) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 8, 2>), dim3(blocks), dim3(128), b);
+    else if (fabl == 9) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 9, 2>), dim3(blocks), dim3(128), b);
     else
 #endif
-    if (g.n_runs > 1)
-        SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, true>), dim3(blocks), dim3(128), b);
-    else
-        SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, true>), dim3(blocks), dim3(128), b);
+    {
+        const int ns = wave ? spec_frames(ctx, g) : 0;
+#define SLGC_SPEC(NSV)                                                                                             \
+        if (ns == NSV) {                                                                                           \
+            if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2, NSV>), dim3(blocks), dim3(128), b);    \
+            else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2, NSV>), dim3(blocks), dim3(128), b);         \
+        }
+        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42)
+#undef SLGC_SPEC
+        if (ns == 0) {
+            if (g.n_runs > 1) {
+                if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2>), dim3(blocks), dim3(128), b);
+                else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 1>), dim3(blocks), dim3(128), b);
+            } else {
+                if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2>), dim3(blocks), dim3(128), b);
+                else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 1>), dim3(blocks), dim3(128), b);
+            }
+        }
+    }
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

@@ -49,6 +49,15 @@ struct slgc_ctx {
     size_t ws_bytes[SLGC_WS_SLOTS];
     unsigned ws_gen[SLGC_WS_SLOTS];   // bumped every time a slot is handed out (slgc_ws): a *_fetch checks that the slots holding its
                                       // pending result have not been handed to another call since its *_count (SLGC_ESTATE otherwise)
+    // tuning knobs (slgc_tune): every setting gives the same results, they exist for same-process A/B timing
+    int tune_fuse_tail;     // fused scan tail: 1 = wave-local LDS exchange (no workgroup barriers), 0 = workgroup-wide exchange
+    int tune_proj_tile;     // projector ray table tiles: 0 = 8x8 pixels (512 B), 1 = 16x8 pixels (one 128-byte line per tile row)
+    int tune_fuse_nt;       // fused scan: bit 0 XYZ, bit 1 maps leave with non-temporal stores
+    int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
+    int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
+    int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
+    int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
+    int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
     void *stage;            // pinned host staging (float64 stacks narrowed to uint8 before the upload)
     size_t stage_bytes;
     int last_input_path;    // slgc_last_input_path
@@ -60,7 +69,7 @@ struct slgc_ctx {
     void *lut_cam, *lut_proj;
     void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
     unsigned lut_cam_ver, lut_proj_ver;
-    int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h;
+    int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h, lut_proj_tile;
     // results kept on the device between *_count and *_fetch
     int64_t pend_M;
     size_t pend_npix;
@@ -116,6 +125,7 @@ int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, un
 int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew);
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
                       int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h);
+inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj_tile ? (proj_w + 15) / 16 : (proj_w + 7) / 8; }
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz);
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
@@ -179,10 +189,9 @@ inline int xcd_env(const char *name, int dflt)
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-inline uint32_t xcd_chunk_for(unsigned blocks)
+inline uint32_t xcd_chunk_for(const slgc_ctx *ctx, unsigned blocks)
 {
-    static const int mode = xcd_env("SLGC_XCD", 1);
-    return (mode && blocks >= 64) ? blocks / 8 : 0u;
+    return (ctx->tune_xcd && blocks >= 64) ? blocks / 8 : 0u;
 }
 
 // Launch on the context's stream.  When the launch is being sampled (slgc_prof_begin .. _end), the event pair is attached to the

@@ -136,10 +136,21 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
     }
 }
 
-// The projector table is stored in 8x8-pixel tiles (512 B) so that a wave's gather stays within a few cache lines
-// whichever way the decoded projector coordinates drift along a camera row.
-__device__ __forceinline__ uint32_t proj_lut_index(int pu, int pv, int tiles_x)
+// The projector table is stored in tiles of 8 rows so that a wave's gather stays within a few cache lines whichever way the
+// decoded projector coordinates drift along a camera row.  wide = 0: 8x8-pixel tiles (512 B, a tile row is half a 128-byte line);
+// wide = 1: 16x8-pixel tiles (1 KB, a tile row is exactly one 128-byte line).  tiles_x counts tiles of the chosen width.
+__device__ __forceinline__ uint32_t proj_lut_index(int pu, int pv, int tiles_x, int wide = 0)
 {
-    return (((uint32_t)(pv >> 3) * (uint32_t)tiles_x + (uint32_t)(pu >> 3)) << 6) | (uint32_t)((pv & 7) << 3) | (uint32_t)(pu & 7);
+    const uint32_t row = (uint32_t)(pv >> 3) * (uint32_t)tiles_x, in_y = (uint32_t)(pv & 7);
+    return wide ? (((row + (uint32_t)(pu >> 4)) << 7) | (in_y << 4) | (uint32_t)(pu & 15))
+                : (((row + (uint32_t)(pu >> 3)) << 6) | (in_y << 3) | (uint32_t)(pu & 7));
 }
 
+// Ordering point for data exchanged through LDS between the lanes of ONE wave: LDS operations of a wave execute in program
+// order, so no s_barrier is needed -- only the compiler must not move the reads above the writes.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -178,12 +178,13 @@ __global__ void __launch_bounds__(256) k_build_cam_lut(const Calib c, float2 *__
 }
 
 __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
-                                                        size_t nslots)
+                                                        size_t nslots, int wide)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= nslots) return;
-    const int tile = (int)(p >> 6), in = (int)(p & 63);
-    const int pu = (tile % tiles_x) * 8 + (in & 7), pv = (tile / tiles_x) * 8 + (in >> 3);
+    const int sh = wide ? 7 : 6, tw = wide ? 16 : 8;                        // slots per tile = 8 rows x tw pixels (proj_lut_index)
+    const int tile = (int)(p >> sh), in = (int)(p & ((1u << sh) - 1u));
+    const int pu = (tile % tiles_x) * tw + (in & (tw - 1)), pv = (tile / tiles_x) * 8 + (in / tw);
     float2 o = make_float2(0.f, 0.f);
     if (pu < proj_w && pv < proj_h) {
         const Ray2 b = undistort_point((float)pu, (float)pv, c.proj_k, c.proj_d, nullptr);
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
                                                               const uint32_t *__restrict__ wire, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
-                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store)
+                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store, int wide)
 {
     __shared__ uint4 s_idx[256];
     __shared__ float4 s_buf[768];
@@ -238,18 +239,21 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
         for (int j = 0; j < 4; ++j) {
             const int hv = (int)(short)(hq[j >> 1] >> (16 * (j & 1))), vv = (int)(short)(vq[j >> 1] >> (16 * (j & 1)));
             if (!(hv == -1 || vv == -1))                                                              // triangulate.py:56
-                idx[j] = proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x);          // :60-61
+                idx[j] = proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide);    // :60-61
         }
     }
     s_idx[tid] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
     __syncthreads();
     float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
     const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
+    float2 gr[4];           // four independent, unconditional gathers in flight per lane (an undecodable pixel reads entry 0, unused)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const uint32_t i = s_idx1[it * 256 + tid];
-        s_ray[it * 256 + tid] = (i != 0xffffffffu) ? proj_lut[i] : make_float2(0.f, 0.f);
+        gr[it] = proj_lut[i != 0xffffffffu ? i : 0u];
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) s_ray[it * 256 + tid] = gr[it];
     __syncthreads();
     const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
     __syncthreads();
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(256) k_undistort_list(const Calib c, int which
 // tri_is_flat test on the same table rays.  counts[0] += decodable pixels, counts[1] += flagged pixels.
 __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const int16_t *__restrict__ h, const int16_t *__restrict__ v,
                                                      const float2 *__restrict__ cam_lut, const float2 *__restrict__ proj_lut, size_t npix,
-                                                     int proj_w, int proj_h, int tiles_x, unsigned long long *__restrict__ counts)
+                                                     int proj_w, int proj_h, int tiles_x, int wide, unsigned long long *__restrict__ counts)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     unsigned ok = 0, flat = 0;
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
         const int hv = h[p], vv = v[p];
         if (!(hv == -1 || vv == -1)) {
             ok = 1;
-            const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x)];
+            const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
             flat = tri_is_flat(tri_terms(c.x, c.y, q.x, q.y, tc.T, tc.t_len * tc.t_len)) ? 1u : 0u;
         }
     }
@@ -348,7 +352,7 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     memcpy(tc.T, ctx->calib.T, sizeof tc.T);
     tc.t_len = ctx->calib.t_len;
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
-                       (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, (proj_w + 7) / 8, d_counts);
+                       (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -368,8 +372,9 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
 // Build (or reuse) the ray tables for this calibration / geometry.
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
 {
-    const int tiles_x = (proj_w + 7) / 8, tiles_y = (proj_h + 7) / 8;
-    const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * 64;
+    const int wide = ctx->tune_proj_tile ? 1 : 0;
+    const int tiles_x = proj_tiles_x(ctx, proj_w), tiles_y = (proj_h + 7) / 8;
+    const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * (wide ? 128 : 64);
     if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows)) {
         if (ctx->lut_cam) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -382,7 +387,7 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
         HIP_TRY(ctx, hipGetLastError());
         ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
     }
-    if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h)) {
+    if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h && ctx->lut_proj_tile == wide)) {
         if (ctx->lut_proj) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipFree(ctx->lut_proj));
@@ -390,9 +395,9 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
         }
         if (hipMalloc(&ctx->lut_proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
         hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib,
-                           (float2 *)ctx->lut_proj, proj_w, proj_h, tiles_x, nproj);
+                           (float2 *)ctx->lut_proj, proj_w, proj_h, tiles_x, nproj, wide);
         HIP_TRY(ctx, hipGetLastError());
-        ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h;
+        ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h; ctx->lut_proj_tile = wide;
     }
     return SLGC_OK;
 }
@@ -443,18 +448,18 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         tc.t_len = ctx->calib.t_len;
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
-        static const int tri_nt = xcd_env("SLGC_TRI_NT", 1);     // XYZ leaves with non-temporal stores (A/B: SLGC_TRI_NT=0)
+        const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
 #ifdef SLGC_DIAG      // A/B of the guard's cost: only in the diagnostic build
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
             hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
 #endif
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, (proj_w + 7) / 8, d_xyz, d_count, xcd_chunk_for(blocks), tri_nt);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;

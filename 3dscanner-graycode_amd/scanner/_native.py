@@ -38,6 +38,7 @@ SIGNATURES = {
     "slgc_last_error": (C.c_char_p, [_vp]),
     "slgc_synchronize": (_i, [_vp]),
     "slgc_last_input_path": (_i, [_vp]),
+    "slgc_tune": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
     "slgc_direct_indirect": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "slgc_is_lit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _d, _d, _vp, _vp]),
@@ -245,6 +246,10 @@ class Context:
 
     def synchronize(self):
         self._ck(lib().slgc_synchronize(self._h))
+
+    def tune(self, name: str, value: int):
+        """Same-process A/B knobs (slgc_tune): results never change."""
+        self._ck(lib().slgc_tune(self._h, name.encode(), int(value)))
 
     def last_input_path(self) -> int:
         """0 = uint8 stack as given, 1 = float64 stack narrowed to uint8 on the host, 2 = float64 kernel (slgc_last_input_path)."""

@@ -30,25 +30,31 @@ def remove_bad_images(images, ctx=None):
     """Indexes of the frames to keep (transition frames dropped), reference decode_codes.py:34-68.
 
     The per-pair ``len(np.argwhere(cv2.absdiff(a, b) > 50))`` counts are one GPU reduction over all consecutive pairs
-    (csrc/ingest.hip); the keep/drop state machine of :56-66 is restated here unchanged in meaning.  ``images`` is the
+    (csrc/ingest.hip); the keep/drop rule of :56-66 is expressed over that count array as a sliding three-count window.  ``images`` is the
     reference's ``[n,H,W,3]`` (or ``[n,H,W]``) array, float64 or uint8."""
-    diff_thresh = 50
     n = len(images)
-    d = [int(x) for x in (ctx or default_context()).frame_diff_counts(images, diff_thresh)]     # d[j] = count(|im[j+1]-im[j]| > 50)
-    diff1, diff2 = d[0], d[1]
+    # e[j] = number of elements that change by more than 50 between frames j and j+1 -- all pairs in ONE GPU reduction
+    e = [int(x) for x in (ctx or default_context()).frame_diff_counts(images, 50)]
     kept = []
-    for i in range(n - 3):                                     # the reference iterates images[2:-1]
-        diff3 = d[i + 2]                                       # absdiff(images[i+3], images[i+2])
-        if diff1 < diff2 and diff1 < diff3 and diff2 < diff3 and i + 1 not in kept:
-            if len(kept) == 0 or (kept[-1] != i and kept[-1] != i + 2):
+
+    def far_from_last(*idx):            # the frame kept last is none of idx (or nothing is kept yet)
+        return not kept or kept[-1] not in idx
+
+    # Window (e[i], e[i+1], e[i+2]) slides over the change counts (the reference walks images[2:-1], :52-66):
+    #   counts rising across the window  -> frame i+1 is the settled frame before a transition (:56-58)
+    #   middle count is the window's low -> frame i+2 sits in a quiet trough (:59-63); its two counts are then spent (-1) so the
+    #                                       next two windows cannot pick the same trough again
+    # A frame is never kept twice, nor directly next to the frame kept last.  The two cases exclude each other (rising needs
+    # e[i+1] > e[i], a trough needs e[i+1] <= e[i]).
+    for i in range(n - 3):
+        a, b, c = e[i], e[i + 1], e[i + 2]
+        if a < b < c:
+            if i + 1 not in kept and far_from_last(i, i + 2):
                 kept.append(i + 1)
-        elif diff2 <= diff1 and diff2 <= diff3 and i + 2 not in kept:
-            if len(kept) == 0 or (kept[-1] != i + 1 and kept[-1] != i + 3):
+        elif b <= a and b <= c and i + 2 not in kept:
+            if far_from_last(i + 1, i + 3):
                 kept.append(i + 2)
-                diff3 = -1
-                diff2 = -1
-        diff1 = diff2
-        diff2 = diff3
+                e[i + 1] = e[i + 2] = -1
     return kept
 
 

@@ -62,6 +62,15 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
+/* Tuning knobs for same-process A/B timing; no setting changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
+ * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 0 = 8x8-pixel projector-table tiles (default) / 1 = 16x8;
+ * "park" 1 = at 42 / 44 / 46 frames
+ * the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) / 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte
+ * wire format / 0 = int16 (default; experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3); "tri_nt" (1); "xcd" XCD-aware tile map of the dense
+ * triangulation kernel (1).  Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT,
+ * SLGC_XCD), read when the context is created. */
+int slgc_tune(slgc_ctx *ctx, const char *name, int value);
+
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
  * integers in [0,255] (what src/3-capture_decode.py:66-70 builds), narrowed to uint8 on host threads into pinned staging and
  * uploaded as 1 byte per sample; 2 = float64 shipped as it is (a fraction / negative / NaN was found) and decoded by the float64
@@ -274,7 +283,8 @@ int slgc_shard_band(int H, int nranks, int rank, int *row0, int *rows);
  * (d_band_stack = its first row of frame 0, band rows from slgc_shard_band with the context's rank / nranks) into its slot of
  * the full-size int16 maps, all-gatherv both maps in place over RCCL, triangulate the full maps.  Afterwards every rank
  * holds d_h_full / d_v_full [H][W] and dense float32 d_xyz_full [H][W][3] (NaN = undecodable) -- the reassembled cloud of
- * BASELINE.json configs[3].  Replaces, for N GPUs, src/3-capture_decode.py:75-100 + src/4-triangulate.py:50-64. */
+ * BASELINE.json configs[3].  Replaces, for N GPUs, src/3-capture_decode.py:75-100 + src/4-triangulate.py:50-64.  With slgc_tune("wire", 1)
+ * and codes of <= SLGC_WIRE_MAX_CODE_BITS bits the bands travel packed to 3 B/pixel (one all-gather; unpacked inside the triangulation). */
 int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack, int n_runs, size_t run_stride, size_t plane_stride,
                           int N, int H, int W, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h_full,
                           int16_t *d_v_full, float *d_xyz_full);

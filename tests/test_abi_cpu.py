@@ -177,3 +177,30 @@ print("ok")
 """
     out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_remove_bad_images_window_rule_equals_the_reference_state_machine():
+    """Host logic only: the product's sliding-window form of decode_codes.py:52-66 against the oracle's literal restatement (which
+    tests/golden/ingest.npz pins to the reference's own output), on 20 000 random change-count sequences full of ties."""
+    import oracle_np as onp
+    from scanner.grayCode import decode_codes as dc
+    rng = np.random.default_rng(0)
+
+    class Counts:                                   # stands in for the GPU reduction: hands back the counts under test
+        def __init__(self, d):
+            self.d = d
+
+        def frame_diff_counts(self, images, thresh):
+            return self.d
+
+    orig = onp.frame_diff_counts
+    try:
+        for case in range(20000):
+            n = int(rng.integers(4, 40))
+            hi = int(rng.choice([2, 3, 5, 50, 100000]))
+            d = rng.integers(0, hi, n - 1)
+            onp.frame_diff_counts = lambda images, thresh=50, d=d: d
+            frames = [None] * n
+            assert dc.remove_bad_images(frames, ctx=Counts(d)) == onp.remove_bad_images(frames), (case, d)
+    finally:
+        onp.frame_diff_counts = orig

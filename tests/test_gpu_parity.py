@@ -211,8 +211,7 @@ int main(int argc, char **argv) {
     runs[0] = stack;
     if (slgc_device_count() < 1) return 3;
     if (slgc_create(0, &ctx)) return 4;
-    if (slgc_decode(ctx, runs, SLGC_U8, 1, N, H, W, 1.0, 10.0, h, v)) { fprintf(stderr, "%s
-", slgc_last_error(ctx)); return 5; }
+    if (slgc_decode(ctx, runs, SLGC_U8, 1, N, H, W, 1.0, 10.0, h, v)) { fprintf(stderr, "%s\n", slgc_last_error(ctx)); return 5; }
     if (slgc_decode(ctx, runs, SLGC_U8, 1, 10, H, W, 1.0, 10.0, h, v) != SLGC_EINVAL) return 6;     /* N < 14: the reference raises too */
     f = fopen(argv[2], "wb");
     fwrite(h, 8, npix, f); fwrite(v, 8, npix, f);
@@ -679,13 +678,16 @@ def test_sharded_scanner_single_rank_rccl(ctx, calib):
         with pytest.raises(ValueError):
             sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, 62, wire="hv24")      # L = 15 does not fit
         # the same scan through the one-call C entry point (slgc_scan_sharded_dev)
-        dh, dv, dx = ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 12).zero()
-        ctx.scan_sharded_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, psize, dh.ptr, dv.ptr, dx.ptr, mode=_native.TRI_EXACT)
-        ctx.synchronize()
-        assert np.array_equal(dh.download((H, W), np.int16), hp) and np.array_equal(dv.download((H, W), np.int16), vp)
-        cx = dx.download((H, W, 3), np.float32)
-        assert np.array_equal(np.isfinite(cx[..., 0]), okm)
-        np.testing.assert_allclose(cx[okm], np.moveaxis(ref, 0, -1)[okm], rtol=XYZ_RTOL, atol=0)
+        for wire_knob in (0, 1):                       # int16 maps (default) / the 3-byte wire format
+            ctx.tune("wire", wire_knob)
+            dh, dv, dx = ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 2).zero(), ctx.alloc(H * W * 12).zero()
+            ctx.scan_sharded_dev(stack.ptr, 1, st.nbytes, H * W, N, H, W, psize, dh.ptr, dv.ptr, dx.ptr, mode=_native.TRI_EXACT)
+            ctx.synchronize()
+            assert np.array_equal(dh.download((H, W), np.int16), hp) and np.array_equal(dv.download((H, W), np.int16), vp)
+            cx = dx.download((H, W, 3), np.float32)
+            assert np.array_equal(np.isfinite(cx[..., 0]), okm)
+            np.testing.assert_allclose(cx[okm], np.moveaxis(ref, 0, -1)[okm], rtol=XYZ_RTOL, atol=0)
+        ctx.tune("wire", 0)
         sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), sharded.ShardPlan(H, W, 1), psize, N, mode=_native.TRI_EXACT,
                                     exchange_kind="records")
         total = sc.scan(stack.ptr, H * W)
@@ -1030,6 +1032,13 @@ def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
     assert len(rec) == len(i2) and np.array_equal(rec["x"], p2[:, 0]) and np.array_equal(rec["g"], np.round(c2[:, 1] * 255).astype(np.uint8))
     with pytest.raises(ValueError):
         ctx.knn_mean_distance(pts[:5], 20)                                           # k > number of points
+    # small clouds with k close to M: the grid collapses to one cell, where the scan is exhaustive whatever the k-th distance is
+    for M, k in ((25, 20), (20, 20), (64, 33), (3, 1), (1, 1)):
+        small = rng.uniform(-1, 1, (M, 3)).astype(np.float32) * np.array([1.0, 0.02, 5.0], np.float32)
+        np.testing.assert_allclose(ctx.knn_mean_distance(small, k), onp.knn_mean_distance(small, k), rtol=1e-12, atol=1e-15)
+    # many cells: the counting sort's exclusive scan runs over several tile levels (own reduce-then-scan, csrc/cloud.hip)
+    big = rng.uniform(0, 1, (300_000, 3)).astype(np.float32) * np.array([1.0, 1.0, 1e-3], np.float32)
+    np.testing.assert_allclose(ctx.knn_mean_distance(big, 4), onp.knn_mean_distance(big, 4), rtol=1e-12, atol=1e-15)
     assert ctx.knn_mean_distance(np.zeros((0, 3), np.float32), 20).shape == (0,)
 
 
