@@ -164,6 +164,19 @@ def map_band_layout(plan: ShardPlan):
     return counts, displs
 
 
+def band_layout(plan: ShardPlan, bytes_per_px: int):
+    """Byte counts / displacements of the row bands inside one full [H][W] array of ``bytes_per_px`` bytes per pixel."""
+    return ([rows * plan.W * bytes_per_px for _, rows in plan.bands()], [row0 * plan.W * bytes_per_px for row0, _ in plan.bands()])
+
+
+def exchange_bands(exchange, plan: ShardPlan, arrays, band_view):
+    """In-place all-gatherv of the row bands of several full-size arrays: ``arrays`` = [(buffer, bytes per pixel), ...] -- the "xyz"
+    strategy sends (h, 2), (v, 2), (xyz, 12).  One exchange per array, fixed sizes from the plan: no counts, no host round trip."""
+    for buf, bpp in arrays:
+        counts, displs = band_layout(plan, bpp)
+        exchange.allgatherv(band_view(buf, displs[exchange.rank]), buf, counts, displs)
+
+
 def exchange_map_bands(exchange, plan: ShardPlan, h_full, v_full, band_view):
     """In-place all-gatherv of the (h, v) map bands: every rank has written its own band into the full-size maps;
     afterwards both maps are complete everywhere.  ``band_view(buf, byte_offset)`` addresses a buffer of the exchange's
@@ -258,8 +271,7 @@ class ShardedScanner:
         self.exchange.allgatherv_begin(wire.at(displs[self.rank]), wire, counts, displs, slot)
 
     def _band_layouts(self, *bytes_per_px):
-        return [([rows * self.plan.W * b for _, rows in self.plan.bands()], [row0 * self.plan.W * b for row0, _ in self.plan.bands()])
-                for b in bytes_per_px]
+        return [band_layout(self.plan, b) for b in bytes_per_px]
 
     def _submit_xyz(self, d_band_stack: int, plane_stride: int, n_runs: int, run_stride: int, eps):
         """Fused kernel on the band, straight into this rank's slot of set s; in-place all-gather of the three band sets (slots 2s,

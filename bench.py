@@ -41,6 +41,9 @@ WORKLOADS = {
     "c3_4096x3000x46": (4096, 3000, 1920, 1200, 46),
     "c1_1280x720x42": (1280, 720, 1280, 800, 42),
     "c2_1920x1080x46": (1920, 1080, 1920, 1080, 46),
+    # small test workloads (tests/test_gpu_rccl_multi.py): an odd height (ragged bands at any G) and an even one
+    "t_516x1031x44": (516, 1031, 300, 200, 44),
+    "t_512x1024x44": (512, 1024, 300, 200, 44),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PREHEAT_S = 0.15       # untimed back-to-back scans before the counted warm-up: the clocks of a fresh box ramp for ~100 ms
@@ -263,6 +266,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="sharded modes: skip the post-run cross-rank / single-GPU verification")
     ap.add_argument("--plane-pad", type=int, default=0,
                     help="extra bytes between frame planes in HBM (multiple of 16; 0 = contiguous [N,H,W] like the reference)")
+    ap.add_argument("--preheat", type=float, default=PREHEAT_S,
+                    help="seconds of untimed back-to-back scans before the counted warm-up (clock ramp of a fresh box); 0 under a counter profiler")
     ap.add_argument("--buffers", type=int, default=0,
                     help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
     args = ap.parse_args()
@@ -363,8 +368,8 @@ def run_rank(args, rank, local_rank, world):
         ctx.synchronize()
 
     def timed(K, W_, stride=None, preheat=True, **kw):
-        if preheat:                                          # untimed: bring the clocks up before the counted warm-up
-            t_end = time.perf_counter() + PREHEAT_S
+        if preheat and args.preheat > 0:                     # untimed: bring the clocks up before the counted warm-up
+            t_end = time.perf_counter() + args.preheat
             i = 0
             while time.perf_counter() < t_end:
                 for _ in range(16):
@@ -488,7 +493,7 @@ def run_rank(args, rank, local_rank, world):
                                     else args.pipeline + (" (decode kernel + triangulation kernel)" if args.pipeline == "split" else " (one kernel)")),
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks), "plane_pad_bytes": args.plane_pad,
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM" + ("" if not use_comm else "; whole cloud reassembled on every rank"),
-                       "preheat_s": PREHEAT_S, "event_stride": args.event_stride,
+                       "preheat_s": args.preheat, "event_stride": args.event_stride,
                        "luts_hoisted_us": round(luts_us, 1),
                        "luts_hoisted_note": "per-calibration ray tables (both cv2.undistortPoints calls on integer pixel coordinates) built once "
                                             "before the timed region, not per scan",

@@ -113,6 +113,18 @@ def _worker(rank, world, port, H, W, N, q):
         sharded.exchange_map_bands(ex, plan, h_full, v_full, lambda buf, o: buf.reshape(-1).view(np.uint8)[o:])
         ex.barrier()
         assert np.array_equal(h_full, fh) and np.array_equal(v_full, fv)                  # bit-exact maps on every rank
+        # ---- "xyz" strategy: every rank fills its band of full-size maps AND dense XYZ, three in-place band all-gathers
+        h2, v2 = np.full((H, W), -9, np.int16), np.full((H, W), -9, np.int16)
+        x2 = np.full((H, W, 3), 123.0, np.float32)
+        if rows:
+            h2[row0:row0 + rows], v2[row0:row0 + rows] = hp, vp
+            x2[row0:row0 + rows] = np.moveaxis(xyz, 0, -1).astype(np.float32)
+        xc, xd = sharded.band_layout(plan, 12)
+        assert sum(xc) == H * W * 12 and xd[rank] == row0 * W * 12
+        sharded.exchange_bands(ex, plan, [(h2, 2), (v2, 2), (x2, 12)], lambda buf, o: buf.reshape(-1).view(np.uint8)[o:])
+        ex.barrier()
+        assert np.array_equal(h2, fh) and np.array_equal(v2, fv)
+        assert np.array_equal(x2.reshape(-1, 3), fdense, equal_nan=True)                   # band by band == the whole image in one go
         dist.destroy_process_group()
         q.put((rank, "ok", counts))
     except Exception as e:  # noqa: BLE001

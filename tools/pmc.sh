@@ -8,7 +8,7 @@ mkdir -p "$out"
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > "$out/pass$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 10 --warmup 2 --preheat 0 --no-cpu-baseline --no-throughput-mode "$@" > "$out/pass$i.log" 2>&1
   echo "pass $i ($ctrs): rc=$?"
 done
 python3 tools/pmc_summary.py "$out"
