@@ -237,6 +237,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
+    CamPolyRef cp;            // cp.tiles != nullptr: camera rays from the tile polynomials instead of cam_lut (tri_math.h)
     double T[3], t_len;
 };
 
@@ -555,11 +556,15 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         };
         const bool live = off < a.npix;
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
+        double cx[4] = {0., 0., 0., 0.}, cy[4] = {0., 0., 0., 0.};
         if (live) {
-            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
-            const float4 c01 = cl[0], c23 = cl[1];
-            cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+            if (a.f.cp.tiles) {
+                cam_rays4_poly(a.f.cp, off, cx, cy);
+            } else {
+                const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
+                const float4 c01 = cl[0], c23 = cl[1];
+                cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+            }
             const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -911,6 +916,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
     b.f.nt_store = ctx->tune_fuse_nt;
     b.f.wave_tail = ctx->tune_fuse_tail;
+    fill_cam_poly(ctx, &b.f.cp, true);
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

@@ -65,14 +65,74 @@ __device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const do
 // for the two comparisons only and the instruction stream holds a single copy of the float32 divide / sqrt expansions.
 // valid: bit j set = pixel j decodable; out = x0 y0 z0 x1 ... (NaN where not decodable).  GUARD = false: fast form everywhere.
 // cam4 / proj_lut + idx: where the lane's rays came from -- the rare path reads them again instead of keeping 16 registers alive.
+// ---- camera rays without the 8 B/pixel table --------------------------------------------------------------------------------
+// The camera call of triangulate.py:84 is cv2.undistortPoints(pixel, cam_mtx, cam_dist, R = proj_R): undistort (5 fixed-point steps,
+// float64), rotate by R, divide by the third component, round to float32.  The undistorted point U(x, y) BEFORE the rotation is a
+// smooth, nearly linear function of the pixel, so it is kept as one biquadratic per TS x TS pixel tile (TS = 16 or 8), fitted at
+// table-build time to the exact float64 U of every pixel of the tile; the rotation and the perspective divide -- the strongly
+// curved part -- are evaluated exactly, in float64, per pixel.  64 bytes per tile (0.25 B/pixel at TS = 16: L2-resident) replace the
+// 8 B/pixel stream.  The build measures max |ray_poly - ray_exact_float32| over the band and the table is only used when that
+// is <= kCamPolyTol (the float32 rounding of the exact ray itself is up to 6e-8 at |ray| ~ 1, so most of that figure is the
+// reference's own rounding, not the fit); otherwise the exact table stays in use.
+struct CamPolyTile {          // constant terms in float64, the five slope / curvature terms of each component in float32
+    double c0x, c0y;
+    float cx[5];              // dx, dy, dx^2, dx*dy, dy^2
+    float cy[5];
+    float pad[2];
+};
+static_assert(sizeof(CamPolyTile) == 64, "one 64-byte segment per tile");
+constexpr double kCamPolyTol = 4.0e-8;
+
+struct CamPolyRef {           // what a kernel needs to evaluate camera rays from the tile table (nullptr tiles = use the exact table)
+    const CamPolyTile *tiles;
+    int tiles_x, shift;       // tile = (x >> shift, y_local >> shift), TS = 1 << shift
+    int W;                    // image width (pixels per row of the band)
+    double R[9];
+};
+
+// Undistorted pre-rotation point of pixel offsets (dx, dy) from the tile centre, then R and the perspective divide: float64 ray.
+__device__ __forceinline__ void cam_poly_row(const CamPolyTile &t, double dy, double (&ax)[3], double (&ay)[3])
+{
+    // U(dx) = a[0] + dx * (a[1] + dx * a[2]) along the row dy
+    ax[0] = fma(dy, fma(dy, (double)t.cx[4], (double)t.cx[1]), t.c0x);
+    ax[1] = fma(dy, (double)t.cx[3], (double)t.cx[0]);
+    ax[2] = (double)t.cx[2];
+    ay[0] = fma(dy, fma(dy, (double)t.cy[4], (double)t.cy[1]), t.c0y);
+    ay[1] = fma(dy, (double)t.cy[3], (double)t.cy[0]);
+    ay[2] = (double)t.cy[2];
+}
+
+__device__ __forceinline__ void cam_poly_ray(const double (&ax)[3], const double (&ay)[3], double dx, const double (&R)[9], double &rx, double &ry)
+{
+    const double xu = fma(dx, fma(dx, ax[2], ax[1]), ax[0]), yu = fma(dx, fma(dx, ay[2], ay[1]), ay[0]);
+    const double nx = fma(R[0], xu, fma(R[1], yu, R[2])), ny = fma(R[3], xu, fma(R[4], yu, R[5]));
+    const double iw = fast_rcp(fma(R[6], xu, fma(R[7], yu, R[8])));
+    rx = nx * iw;
+    ry = ny * iw;
+}
+
+// The four consecutive pixels of a lane (first pixel `pix` of the band, a multiple of 4; W % 4 == 0 so they share a row and, being
+// aligned to 4, a tile).
+__device__ __forceinline__ void cam_rays4_poly(const CamPolyRef &cp, uint32_t pix, double (&cx)[4], double (&cy)[4])
+{
+    const uint32_t y = pix / (uint32_t)cp.W, x = pix - y * (uint32_t)cp.W;
+    const int half = 1 << (cp.shift - 1), mask = (1 << cp.shift) - 1;
+    const CamPolyTile t = cp.tiles[(size_t)(y >> cp.shift) * cp.tiles_x + (x >> cp.shift)];
+    double ax[3], ay[3];
+    cam_poly_row(t, (double)((int)(y & mask) - half), ax, ay);
+    const int dx0 = (int)(x & mask) - half;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cam_poly_ray(ax, ay, (double)(dx0 + j), cp.R, cx[j], cy[j]);
+}
+
 // Terms of the cancelled form for one pixel (shared by triangulate4 and the guard-count diagnostic so both apply the same test).
 struct TriTerms {
     double ta, tb, ra, rb, Sb, D;
 };
 
-__device__ __forceinline__ TriTerms tri_terms(float cxf, float cyf, float pxf, float pyf, const double (&T)[3], double tl2)
+__device__ __forceinline__ TriTerms tri_terms(double dcx, double dcy, float pxf, float pyf, const double (&T)[3], double tl2)
 {
-    const double dcx = cxf, dcy = cyf, dpx = pxf, dpy = pyf;
+    const double dpx = pxf, dpy = pyf;
     const double A = -fma(T[0], dcx, fma(T[1], dcy, T[2]));
     const double B = fma(T[0], dpx, fma(T[1], dpy, T[2]));
     TriTerms t;
@@ -100,8 +160,9 @@ __device__ __forceinline__ bool tri_is_flat(const TriTerms &t)
     return (t.rb < k1 * t.tb) | ((t.D * t.D) * fmin(t.ra * t.tb, t.rb * t.ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
 }
 
+// cx / cy: camera rays in float64 (the exact table's float32 values widened, or the tile-polynomial rays).
 template <bool GUARD>
-__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+__device__ __forceinline__ void triangulate4(const double (&cx)[4], const double (&cy)[4], const float (&px)[4], const float (&py)[4],
                                              uint32_t valid, const double (&T)[3], double t_len, float (&out)[12],
                                              const float2 *__restrict__ cam4, const float2 *__restrict__ proj_lut, const uint32_t (&idx)[4])
 {
@@ -113,8 +174,8 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
         const float s = (float)(tl2 * t.Sb * fast_rcp(t.D));
         if (GUARD) ill |= tri_is_flat(t) ? (1u << j) : 0u;
         const bool ok = (valid >> j) & 1u;
-        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
-        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
+        out[3 * j] = ok ? (float)cx[j] * s : __builtin_nanf("");
+        out[3 * j + 1] = ok ? (float)cy[j] * s : __builtin_nanf("");
         out[3 * j + 2] = ok ? s : __builtin_nanf("");
     }
     if (GUARD) {

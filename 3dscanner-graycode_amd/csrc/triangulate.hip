@@ -26,8 +26,8 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h, const
 
 namespace {
 
-// cv::undistortPoints(src, K, dist, R) for one point, default TermCriteria(MAX_ITER, 5, 0.01).
-__device__ __forceinline__ Ray2 undistort_point(float uf, float vf, const double (&kk)[4], const double (&k)[12], const double *R)
+// cv::undistortPoints(src, K, dist, R) for one point, default TermCriteria(MAX_ITER, 5, 0.01): the undistorted point before R.
+__device__ __forceinline__ void undistort_xy(float uf, float vf, const double (&kk)[4], const double (&k)[12], double &xo, double &yo)
 {
     const double fx = kk[0], fy = kk[1], cx = kk[2], cy = kk[3];
     const double ifx = 1. / fx, ify = 1. / fy;
@@ -48,6 +48,14 @@ __device__ __forceinline__ Ray2 undistort_point(float uf, float vf, const double
         x = (x0 - dx) * icdist;
         y = (y0 - dy) * icdist;
     }
+    xo = x;
+    yo = y;
+}
+
+__device__ __forceinline__ Ray2 undistort_point(float uf, float vf, const double (&kk)[4], const double (&k)[12], const double *R)
+{
+    double x, y;
+    undistort_xy(uf, vf, kk, k, x, y);
     Ray2 o;
     if (R) {
         const double xx = R[0] * x + R[1] * y + R[2];
@@ -196,7 +204,84 @@ __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *_
 struct TriConst {
     double T[3];
     double t_len;
+    CamPolyRef cp;           // cp.tiles == nullptr: camera rays from the exact table
 };
+
+// Fit one tile of the camera-ray polynomial table (tri_math.h) and measure its error.  One workgroup of TS*TS threads per tile;
+// thread (i, j) owns pixel (tx*TS + i, ty*TS + j) of the band -- pixels past the image edge are evaluated too (undistortPoints is
+// defined everywhere), so every tile is fitted over the full TS x TS pattern and one inverse Gram matrix serves all of them.
+struct FitArgs {
+    double ginv[36];          // inverse Gram matrix of the basis {1, dx, dy, dx^2, dx*dy, dy^2} over the centred TS x TS grid
+};
+
+template <int TS>
+__global__ void __launch_bounds__(TS * TS) k_fit_cam_poly(const Calib c, const FitArgs fa, CamPolyTile *__restrict__ tiles, int tiles_x, int W,
+                                                          int rows, int row0, unsigned *__restrict__ max_err_bits)
+{
+    constexpr int NT_ = TS * TS, NWAVE = (NT_ + 63) / 64;
+    __shared__ double s_m[NWAVE][12];
+    __shared__ double s_coef[12];
+    __shared__ float s_err[NWAVE];
+    const int i = threadIdx.x % TS, j = threadIdx.x / TS;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * TS + i, yl = ty * TS + j;
+    double xu, yu;
+    undistort_xy((float)x, (float)(row0 + yl), c.cam_k, c.cam_d, xu, yu);
+    const double dx = (double)(i - TS / 2), dy = (double)(j - TS / 2);
+    const double basis[6] = {1.0, dx, dy, dx * dx, dx * dy, dy * dy};
+    double m[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        m[k] = basis[k] * xu;
+        m[6 + k] = basis[k] * yu;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = m[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int comp = threadIdx.x / 6, k = threadIdx.x % 6;
+        double acc = 0.0;
+        for (int l = 0; l < 6; ++l) {
+            double ml = 0.0;
+            for (int w = 0; w < NWAVE; ++w) ml += s_m[w][comp * 6 + l];
+            acc += fa.ginv[k * 6 + l] * ml;
+        }
+        s_coef[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    CamPolyTile t;
+    t.c0x = s_coef[0];
+    t.c0y = s_coef[6];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        t.cx[k] = (float)s_coef[1 + k];
+        t.cy[k] = (float)s_coef[7 + k];
+    }
+    t.pad[0] = t.pad[1] = 0.f;
+    if (threadIdx.x == 0) tiles[blockIdx.x] = t;
+    // error of the ray a kernel will compute from this tile (float32-rounded slopes, as stored) against the exact float32 ray
+    float err = 0.f;
+    if (x < W && yl < rows) {
+        double ax[3], ay[3], rx, ry;
+        cam_poly_row(t, dy, ax, ay);
+        cam_poly_ray(ax, ay, dx, c.R, rx, ry);
+        const Ray2 ex = undistort_point((float)x, (float)(row0 + yl), c.cam_k, c.cam_d, c.R);
+        const double e = fmax(fabs(rx - (double)ex.x), fabs(ry - (double)ex.y));
+        err = (e == e) ? (float)e : __builtin_huge_valf();                    // NaN (non-finite rays) -> reject the table
+    }
+    for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
+    if ((threadIdx.x & 63) == 0) s_err[threadIdx.x >> 6] = err;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e = s_err[0];
+        for (int w = 1; w < NWAVE; ++w) e = fmaxf(e, s_err[w]);
+        atomicMax(max_err_bits, __float_as_uint(e));                          // non-negative floats order like their bit patterns
+    }
+}
 
 // Dense kernel.  Four pixels per lane (8-byte map loads, 32-byte ray loads).  The per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
 // each projector-table gather instruction touch ~50 cache lines and each XYZ store instruction a 48-byte-strided
@@ -221,7 +306,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const size_t g = (size_t)bid * 256 + tid;
     const bool live = g < ngroups;
     uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f};
+    double cx[4] = {0., 0., 0., 0.}, cy[4] = {0., 0., 0., 0.};
     if (live) {
         uint2 hw, vw;
         if (wire) {
@@ -232,8 +317,12 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             hw = reinterpret_cast<const uint2 *>(h)[g];
             vw = reinterpret_cast<const uint2 *>(v)[g];
         }
-        const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
-        cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+        if (tc.cp.tiles) {
+            cam_rays4_poly(tc.cp, (uint32_t)(4 * g), cx, cy);
+        } else {
+            const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
+            cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+        }
         const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -267,7 +356,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
         for (int j = 0; j < 4; ++j) {
             float X = __builtin_nanf(""), Y = X, Z = X;
             if ((valid >> j) & 1u) {
-                const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
+                const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{(float)cx[j], (float)cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
                 X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
@@ -351,6 +440,7 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     TriConst tc;
     memcpy(tc.T, ctx->calib.T, sizeof tc.T);
     tc.t_len = ctx->calib.t_len;
+    fill_cam_poly(ctx, &tc.cp, false);
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
                        (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
     HIP_TRY(ctx, hipGetLastError());
@@ -367,6 +457,86 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
         hipLaunchKernelGGL(k_triangulate_list<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, ctx->calib, d_cam, d_proj, (size_t)M, d_xyz);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
+}
+
+// Inverse Gram matrix of {1, dx, dy, dx^2, dx*dy, dy^2} over the centred TS x TS grid (dx, dy = -TS/2 .. TS/2 - 1): Gauss-Jordan, float64.
+static void gram_inverse(int ts, double (&ginv)[36])
+{
+    double a[6][12] = {};
+    for (int j = 0; j < ts; ++j)
+        for (int i = 0; i < ts; ++i) {
+            const double dx = i - ts / 2, dy = j - ts / 2, b[6] = {1.0, dx, dy, dx * dx, dx * dy, dy * dy};
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) a[r][c] += b[r] * b[c];
+        }
+    for (int r = 0; r < 6; ++r) a[r][6 + r] = 1.0;
+    for (int p = 0; p < 6; ++p) {
+        int best = p;
+        for (int r = p + 1; r < 6; ++r)
+            if (fabs(a[r][p]) > fabs(a[best][p])) best = r;
+        for (int c = 0; c < 12; ++c) { const double t = a[p][c]; a[p][c] = a[best][c]; a[best][c] = t; }
+        const double inv = 1.0 / a[p][p];
+        for (int c = 0; c < 12; ++c) a[p][c] *= inv;
+        for (int r = 0; r < 6; ++r)
+            if (r != p) {
+                const double f = a[r][p];
+                for (int c = 0; c < 12; ++c) a[r][c] -= f * a[p][c];
+            }
+    }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) ginv[r * 6 + c] = a[r][6 + c];
+}
+
+// Camera-ray tile polynomials for the band: 16 x 16 tiles first, 8 x 8 if their measured error is over kCamPolyTol, none if that
+// fails too (strong distortion: the exact table stays in use).  One-off per calibration / band; synchronises once to read the error.
+static int build_cam_poly(slgc_ctx *ctx, int rows, int W, int row0)
+{
+    if (ctx->lut_cam_poly) {
+        HIP_TRY(ctx, hipFree(ctx->lut_cam_poly));
+        ctx->lut_cam_poly = nullptr;
+    }
+    ctx->cam_poly_shift = 0;
+    ctx->cam_poly_err = -1.f;
+    if (rows <= 0 || W <= 0 || W % 4 != 0) return SLGC_OK;          // lanes own 4 consecutive pixels of one row
+    void *d_err;
+    int rc = slgc_ws(ctx, 7, 64, &d_err);
+    if (rc) return rc;
+    const int tx8 = (W + 7) / 8, ty8 = (rows + 7) / 8;
+    if (hipMalloc(&ctx->lut_cam_poly, (size_t)tx8 * ty8 * sizeof(CamPolyTile) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera ray polynomials");
+    for (int shift = 4; shift >= 3; --shift) {
+        const int ts = 1 << shift, tiles_x = (W + ts - 1) / ts, tiles_y = (rows + ts - 1) / ts;
+        FitArgs fa;
+        gram_inverse(ts, fa.ginv);
+        HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
+        if (shift == 4)
+            hipLaunchKernelGGL(k_fit_cam_poly<16>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, ctx->stream, ctx->calib, fa,
+                               (CamPolyTile *)ctx->lut_cam_poly, tiles_x, W, rows, row0, (unsigned *)d_err);
+        else
+            hipLaunchKernelGGL(k_fit_cam_poly<8>, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), 0, ctx->stream, ctx->calib, fa,
+                               (CamPolyTile *)ctx->lut_cam_poly, tiles_x, W, rows, row0, (unsigned *)d_err);
+        HIP_TRY(ctx, hipGetLastError());
+        float err = 0.f;
+        HIP_TRY(ctx, hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cam_poly_err = err;
+        if (err <= (float)kCamPolyTol) {
+            ctx->cam_poly_shift = shift;
+            ctx->cam_poly_tiles_x = tiles_x;
+            return SLGC_OK;
+        }
+    }
+    return SLGC_OK;          // rejected at both tile sizes: exact table only
+}
+
+void fill_cam_poly(const slgc_ctx *ctx, CamPolyRef *cp, bool allow)
+{
+    memset(cp, 0, sizeof *cp);
+    if (!allow || !ctx->tune_cam_poly || ctx->cam_poly_shift == 0 || !ctx->lut_cam_poly) return;
+    cp->tiles = (const CamPolyTile *)ctx->lut_cam_poly;
+    cp->tiles_x = ctx->cam_poly_tiles_x;
+    cp->shift = ctx->cam_poly_shift;
+    cp->W = ctx->lut_cam_W;
+    memcpy(cp->R, ctx->calib.R, sizeof cp->R);
 }
 
 // Build (or reuse) the ray tables for this calibration / geometry.
@@ -386,6 +556,8 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
                            row0, npix);
         HIP_TRY(ctx, hipGetLastError());
         ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
+        int rc = build_cam_poly(ctx, rows, W, row0);
+        if (rc) return rc;
     }
     if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h && ctx->lut_proj_tile == wide)) {
         if (ctx->lut_proj) {
@@ -446,6 +618,7 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         TriConst tc;
         memcpy(tc.T, ctx->calib.T, sizeof tc.T);
         tc.t_len = ctx->calib.t_len;
+        fill_cam_poly(ctx, &tc.cp, mode != SLGC_TRI_EXACT);          // the acos / sin parity mode always reads the exact float32 rays
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")

@@ -215,3 +215,48 @@ def test_device_resident_reference_product(ctx, workload):
         b.free()
     lists.free()
     bare.free()
+
+
+@pytest.mark.parametrize("which", ["c3", "c2", "cam_1440"])
+def test_camera_ray_polynomials_error_check(ctx, which):
+    """The 64-byte-per-tile camera-ray polynomials that replace the 8 B/pixel table in the scans: accepted only when the build-time
+    check measures max |ray_poly - ray_exact_float32| <= 4e-8 over the image; with both settings of the knob the scan stays within
+    1e-4 of the oracle, maps bit-identical.  The strongly distorted cam_1440 model (bail-out corners) must be REJECTED -> exact table."""
+    from scanner import _native
+    from scanner import reference_calibration as rc
+    if which == "cam_1440":
+        W, H, pw, ph, N = 2560, 1440, 1920, 1080, 44
+        _, _, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
+        calib = (rc.CAM1440_MTX, rc.CAM1440_DIST, pk, pd, R, T)
+    else:
+        W, H, pw, ph, N = bench.WORKLOADS["c3_4096x3000x44" if which == "c3" else "c2_1920x1080x44"]
+        calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
+    ctx.synchronize()
+    tile, err, in_use = ctx.cam_poly_info()
+    print(f"\n{which}: tile {tile}, max |ray_poly - ray_exact| {err:.3e}, in use {in_use}")
+    if which == "cam_1440":
+        assert tile == 0 and not in_use and err > 4e-8
+    else:
+        assert tile in (8, 16) and in_use and 0 <= err <= 4e-8
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=4, noise=3, shadow=True)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    st = stack.download((N, H, W), np.uint8)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+    worst = {}
+    try:
+        for knob in (1, 0):
+            ctx.tune("cam_poly", knob)
+            for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT):
+                ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+                ctx.synchronize()
+                _, worst[(knob, mode)] = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2),
+                                                      xyz.download((H, W, 3), np.float32), ref_h, ref_v, ref_xyz, f"{which} cam_poly={knob} mode={mode}")
+    finally:
+        ctx.tune("cam_poly", 1)
+    print("   worst rel. XYZ error:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for b in (stack, maps, xyz):
+        b.free()
