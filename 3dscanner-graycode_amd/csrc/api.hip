@@ -226,7 +226,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
-    ctx->tune_cam_poly = xcd_env("SLGC_CAM_POLY", 1);
+    ctx->tune_cam_poly = xcd_env("SLGC_CAM_POLY", 0);      // measured slower than streaming the exact table: off
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;

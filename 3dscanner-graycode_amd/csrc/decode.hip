@@ -348,7 +348,7 @@ constexpr int kWaveLdsBytes = 4096;     // LDS block of one wave: fused tail [in
 // fetching them a second time (the re-reads are L2 hits, but each still costs a vector-memory instruction and its L2 -> CU trip:
 // 11 of the 54 loads per lane at N = 44).  The parked words are read back by the lane that wrote them: no synchronisation.
 template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0>
-__global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
+__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
@@ -556,14 +556,13 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         };
         const bool live = off < a.npix;
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        double cx[4] = {0., 0., 0., 0.}, cy[4] = {0., 0., 0., 0.};
+        const bool poly = a.f.cp.tiles != nullptr;          // camera rays from the tile polynomials (evaluated after the exchange: 16 fewer live registers across it)
+        float4 c01 = make_float4(0.f, 0.f, 0.f, 0.f), c23 = c01;
         if (live) {
-            if (a.f.cp.tiles) {
-                cam_rays4_poly(a.f.cp, off, cx, cy);
-            } else {
+            if (!poly) {                                     // exact table: request the rays now, they land during the exchange
                 const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
-                const float4 c01 = cl[0], c23 = cl[1];
-                cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+                c01 = cl[0];
+                c23 = cl[1];
             }
             const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
 #pragma unroll
@@ -601,6 +600,8 @@ __global__ void __launch_bounds__(BLOCK) k_decode_pk(const PkArgs a)
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
+        double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+        if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
         triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);

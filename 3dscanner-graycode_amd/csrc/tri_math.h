@@ -68,20 +68,25 @@ __device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const do
 // ---- camera rays without the 8 B/pixel table --------------------------------------------------------------------------------
 // The camera call of triangulate.py:84 is cv2.undistortPoints(pixel, cam_mtx, cam_dist, R = proj_R): undistort (5 fixed-point steps,
 // float64), rotate by R, divide by the third component, round to float32.  The undistorted point U(x, y) BEFORE the rotation is a
-// smooth, nearly linear function of the pixel, so it is kept as one biquadratic per TS x TS pixel tile (TS = 16 or 8), fitted at
-// table-build time to the exact float64 U of every pixel of the tile; the rotation and the perspective divide -- the strongly
-// curved part -- are evaluated exactly, in float64, per pixel.  64 bytes per tile (0.25 B/pixel at TS = 16: L2-resident) replace the
-// 8 B/pixel stream.  The build measures max |ray_poly - ray_exact_float32| over the band and the table is only used when that
-// is <= kCamPolyTol (the float32 rounding of the exact ray itself is up to 6e-8 at |ray| ~ 1, so most of that figure is the
-// reference's own rounding, not the fit); otherwise the exact table stays in use.
-struct CamPolyTile {          // constant terms in float64, the five slope / curvature terms of each component in float32
-    double c0x, c0y;
-    float cx[5];              // dx, dy, dx^2, dx*dy, dy^2
-    float cy[5];
+// smooth, nearly linear function of the pixel, so it is kept as one bicubic (10 terms per component) per TS x TS pixel tile (TS = 16
+// or 8), least-squares fitted at table-build time to the exact float64 U of every pixel of the tile; the rotation and the perspective
+// divide -- the strongly curved part -- are evaluated exactly, in float64, per pixel.  96 bytes per tile (0.375 B/pixel at TS = 16)
+// replace the 8 B/pixel stream.  The build measures the fit error max |ray_poly - ray_exact| against the exact ray BEFORE its
+// float32 rounding, over the band, and the table is only used when that is <= kCamPolyTol; otherwise the exact table stays in use.
+// A polynomial ray is therefore the reference's ray without its final float32 rounding (+ <= 1e-8): one more half-ulp perturbation
+// of the camera ray, which the guard's error budget counts (tri_is_flat).
+struct CamPolyTile {          // constant terms in float64; the nine higher terms of each component in float32, in the order
+    double c0x, c0y;          //   dy, dy^2, dy^3,  dx, dx dy, dx dy^2,  dx^2, dx^2 dy,  dx^3        (dx, dy from the tile centre)
+    float cx[9];
+    float cy[9];
     float pad[2];
 };
-static_assert(sizeof(CamPolyTile) == 64, "one 64-byte segment per tile");
-constexpr double kCamPolyTol = 4.0e-8;
+static_assert(sizeof(CamPolyTile) == 96, "six 16-byte words per tile");
+constexpr double kCamPolyTol = 1.0e-8;
+constexpr int kCamPolyTerms = 10;
+// term k of the fit basis: (power of dx, power of dy); k = 0 is the constant, k = 1..9 follow the order of CamPolyTile::cx
+__host__ __device__ constexpr int cam_poly_pow_x(int k) { return k < 4 ? 0 : k < 7 ? 1 : k < 9 ? 2 : 3; }
+__host__ __device__ constexpr int cam_poly_pow_y(int k) { return k < 4 ? k : k < 7 ? k - 4 : k < 9 ? k - 7 : 0; }
 
 struct CamPolyRef {           // what a kernel needs to evaluate camera rays from the tile table (nullptr tiles = use the exact table)
     const CamPolyTile *tiles;
@@ -90,21 +95,19 @@ struct CamPolyRef {           // what a kernel needs to evaluate camera rays fro
     double R[9];
 };
 
-// Undistorted pre-rotation point of pixel offsets (dx, dy) from the tile centre, then R and the perspective divide: float64 ray.
-__device__ __forceinline__ void cam_poly_row(const CamPolyTile &t, double dy, double (&ax)[3], double (&ay)[3])
+// Along the row dy of a tile U(dx) = a[0] + dx * (a[1] + dx * (a[2] + dx * a[3])).
+__device__ __forceinline__ void cam_poly_row(const double c0, const float (&c)[9], double dy, double (&a)[4])
 {
-    // U(dx) = a[0] + dx * (a[1] + dx * a[2]) along the row dy
-    ax[0] = fma(dy, fma(dy, (double)t.cx[4], (double)t.cx[1]), t.c0x);
-    ax[1] = fma(dy, (double)t.cx[3], (double)t.cx[0]);
-    ax[2] = (double)t.cx[2];
-    ay[0] = fma(dy, fma(dy, (double)t.cy[4], (double)t.cy[1]), t.c0y);
-    ay[1] = fma(dy, (double)t.cy[3], (double)t.cy[0]);
-    ay[2] = (double)t.cy[2];
+    a[0] = fma(dy, fma(dy, fma(dy, (double)c[2], (double)c[1]), (double)c[0]), c0);
+    a[1] = fma(dy, fma(dy, (double)c[5], (double)c[4]), (double)c[3]);
+    a[2] = fma(dy, (double)c[7], (double)c[6]);
+    a[3] = (double)c[8];
 }
 
-__device__ __forceinline__ void cam_poly_ray(const double (&ax)[3], const double (&ay)[3], double dx, const double (&R)[9], double &rx, double &ry)
+// Undistorted pre-rotation point at dx along the row, then R and the perspective divide: the float64 ray.
+__device__ __forceinline__ void cam_poly_ray(const double (&ax)[4], const double (&ay)[4], double dx, const double (&R)[9], double &rx, double &ry)
 {
-    const double xu = fma(dx, fma(dx, ax[2], ax[1]), ax[0]), yu = fma(dx, fma(dx, ay[2], ay[1]), ay[0]);
+    const double xu = fma(dx, fma(dx, fma(dx, ax[3], ax[2]), ax[1]), ax[0]), yu = fma(dx, fma(dx, fma(dx, ay[3], ay[2]), ay[1]), ay[0]);
     const double nx = fma(R[0], xu, fma(R[1], yu, R[2])), ny = fma(R[3], xu, fma(R[4], yu, R[5]));
     const double iw = fast_rcp(fma(R[6], xu, fma(R[7], yu, R[8])));
     rx = nx * iw;
@@ -118,8 +121,10 @@ __device__ __forceinline__ void cam_rays4_poly(const CamPolyRef &cp, uint32_t pi
     const uint32_t y = pix / (uint32_t)cp.W, x = pix - y * (uint32_t)cp.W;
     const int half = 1 << (cp.shift - 1), mask = (1 << cp.shift) - 1;
     const CamPolyTile t = cp.tiles[(size_t)(y >> cp.shift) * cp.tiles_x + (x >> cp.shift)];
-    double ax[3], ay[3];
-    cam_poly_row(t, (double)((int)(y & mask) - half), ax, ay);
+    double ax[4], ay[4];
+    const double dy = (double)((int)(y & mask) - half);
+    cam_poly_row(t.c0x, t.cx, dy, ax);
+    cam_poly_row(t.c0y, t.cy, dy, ay);
     const int dx0 = (int)(x & mask) - half;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cam_poly_ray(ax, ay, (double)(dx0 + j), cp.R, cx[j], cy[j]);
@@ -147,15 +152,19 @@ __device__ __forceinline__ TriTerms tri_terms(double dcx, double dcy, float pxf,
 }
 
 // |d len / len| <= eps * [1 / sin^2(beta) + (1 / sin(alpha) + 1 / sin(beta)) / sin(gamma)], where eps bounds the error of
-// cos(alpha), cos(beta) caused by the float32 steps of the reference (sqrt and three divisions for NormedL, one sqrt for
-// the projector norm: <= 3 * 2^-24 = 1.8e-7).  A pixel is "flat" (redone on the reference's float32 intermediates) when either
-// term can pass 200: the fast form is then never further than 2 * 200 * 1.8e-7 = 7.2e-5 from the reference, inside the 1e-4
-// tolerance even if every rounding aligns.
-//   sin^2(beta) < 5e-3                             <=>  rb < k1 * tb
-//   min(sin a, sin b)^2 * sin^2(gamma) < 1e-4      <=>  D^2 * min(ra*tb, rb*ta) < k2 * (ta*tb)^2
+// cos(alpha), cos(beta) caused by float32 steps the fast form does not reproduce: in the reference, sqrt and three divisions for
+// NormedL and one sqrt for the projector norm (3 * 2^-24); here, when the camera ray comes from the tile polynomials, the ray's own
+// float32 rounding that the reference has and the polynomial does not (sqrt(2) * 2^-24) plus the fit error (<= 1e-8): eps <= 2.7e-7.
+// A pixel is "flat" (redone on the reference's float32 intermediates, exact table rays) when either term can pass kGuardAmp = 170: the
+// fast form is then never further than 2 * 170 * 2.7e-7 = 9.2e-5 from the reference, inside the 1e-4 tolerance even if every
+// rounding aligns.
+//   1 / sin^2(beta) > A                                  <=>  rb < tb / A
+//   (1/sin a + 1/sin b) / sin(gamma) can exceed A         <=   min(sin a, sin b) * sin(gamma) < 2 / A
+//                                                         <=>  D^2 * min(ra*tb, rb*ta) < (2 / A)^2 * (ta*tb)^2
+constexpr double kGuardAmp = 170.0;
 __device__ __forceinline__ bool tri_is_flat(const TriTerms &t)
 {
-    constexpr double k1 = 5e-3, k2 = 1e-4;
+    constexpr double k1 = 1.0 / kGuardAmp, k2 = (2.0 / kGuardAmp) * (2.0 / kGuardAmp);
     const double tatb = t.ta * t.tb;
     return (t.rb < k1 * t.tb) | ((t.D * t.D) * fmin(t.ra * t.tb, t.rb * t.ta) < (k2 * tatb) * tatb);     // no short-circuit: no branches
 }

@@ -211,16 +211,16 @@ struct TriConst {
 // thread (i, j) owns pixel (tx*TS + i, ty*TS + j) of the band -- pixels past the image edge are evaluated too (undistortPoints is
 // defined everywhere), so every tile is fitted over the full TS x TS pattern and one inverse Gram matrix serves all of them.
 struct FitArgs {
-    double ginv[36];          // inverse Gram matrix of the basis {1, dx, dy, dx^2, dx*dy, dy^2} over the centred TS x TS grid
+    double ginv[kCamPolyTerms * kCamPolyTerms];          // inverse Gram matrix of the ten basis terms over the centred TS x TS grid
 };
 
 template <int TS>
 __global__ void __launch_bounds__(TS * TS) k_fit_cam_poly(const Calib c, const FitArgs fa, CamPolyTile *__restrict__ tiles, int tiles_x, int W,
                                                           int rows, int row0, unsigned *__restrict__ max_err_bits)
 {
-    constexpr int NT_ = TS * TS, NWAVE = (NT_ + 63) / 64;
-    __shared__ double s_m[NWAVE][12];
-    __shared__ double s_coef[12];
+    constexpr int NT_ = TS * TS, NWAVE = (NT_ + 63) / 64, NK = kCamPolyTerms;
+    __shared__ double s_m[NWAVE][2 * NK];
+    __shared__ double s_coef[2 * NK];
     __shared__ float s_err[NWAVE];
     const int i = threadIdx.x % TS, j = threadIdx.x / TS;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -228,49 +228,53 @@ __global__ void __launch_bounds__(TS * TS) k_fit_cam_poly(const Calib c, const F
     double xu, yu;
     undistort_xy((float)x, (float)(row0 + yl), c.cam_k, c.cam_d, xu, yu);
     const double dx = (double)(i - TS / 2), dy = (double)(j - TS / 2);
-    const double basis[6] = {1.0, dx, dy, dx * dx, dx * dy, dy * dy};
-    double m[12];
+    const double px[4] = {1.0, dx, dx * dx, dx * dx * dx}, py[4] = {1.0, dy, dy * dy, dy * dy * dy};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        m[k] = basis[k] * xu;
-        m[6 + k] = basis[k] * yu;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        double v = m[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+    for (int k = 0; k < NK; ++k) {
+        const double b = px[cam_poly_pow_x(k)] * py[cam_poly_pow_y(k)];
+        double vx = b * xu, vy = b * yu;
+        for (int o = 32; o > 0; o >>= 1) {
+            vx += __shfl_down(vx, o, 64);
+            vy += __shfl_down(vy, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_m[threadIdx.x >> 6][k] = vx;
+            s_m[threadIdx.x >> 6][NK + k] = vy;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
-        const int comp = threadIdx.x / 6, k = threadIdx.x % 6;
+    if (threadIdx.x < 2 * NK) {
+        const int comp = threadIdx.x / NK, k = threadIdx.x % NK;
         double acc = 0.0;
-        for (int l = 0; l < 6; ++l) {
+        for (int l = 0; l < NK; ++l) {
             double ml = 0.0;
-            for (int w = 0; w < NWAVE; ++w) ml += s_m[w][comp * 6 + l];
-            acc += fa.ginv[k * 6 + l] * ml;
+            for (int w = 0; w < NWAVE; ++w) ml += s_m[w][comp * NK + l];
+            acc += fa.ginv[k * NK + l] * ml;
         }
         s_coef[threadIdx.x] = acc;
     }
     __syncthreads();
     CamPolyTile t;
     t.c0x = s_coef[0];
-    t.c0y = s_coef[6];
+    t.c0y = s_coef[NK];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < NK - 1; ++k) {
         t.cx[k] = (float)s_coef[1 + k];
-        t.cy[k] = (float)s_coef[7 + k];
+        t.cy[k] = (float)s_coef[NK + 1 + k];
     }
     t.pad[0] = t.pad[1] = 0.f;
     if (threadIdx.x == 0) tiles[blockIdx.x] = t;
-    // error of the ray a kernel will compute from this tile (float32-rounded slopes, as stored) against the exact float32 ray
+    // fit error: the ray a kernel will compute from this tile (float32-rounded higher terms, as stored) against the exact ray
     float err = 0.f;
     if (x < W && yl < rows) {
-        double ax[3], ay[3], rx, ry;
-        cam_poly_row(t, dy, ax, ay);
+        double ax[4], ay[4], rx, ry;
+        cam_poly_row(t.c0x, t.cx, dy, ax);
+        cam_poly_row(t.c0y, t.cy, dy, ay);
         cam_poly_ray(ax, ay, dx, c.R, rx, ry);
-        const Ray2 ex = undistort_point((float)x, (float)(row0 + yl), c.cam_k, c.cam_d, c.R);
-        const double e = fmax(fabs(rx - (double)ex.x), fabs(ry - (double)ex.y));
+        // the exact ray before its float32 rounding: the same arithmetic as undistort_point on the exact undistorted point
+        const double xx = c.R[0] * xu + c.R[1] * yu + c.R[2], yy = c.R[3] * xu + c.R[4] * yu + c.R[5];
+        const double ww = 1. / (c.R[6] * xu + c.R[7] * yu + c.R[8]);
+        const double e = fmax(fabs(rx - xx * ww), fabs(ry - yy * ww));
         err = (e == e) ? (float)e : __builtin_huge_valf();                    // NaN (non-finite rays) -> reject the table
     }
     for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
@@ -306,7 +310,8 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const size_t g = (size_t)bid * 256 + tid;
     const bool live = g < ngroups;
     uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    double cx[4] = {0., 0., 0., 0.}, cy[4] = {0., 0., 0., 0.};
+    const bool poly = tc.cp.tiles != nullptr;
+    float4 c01 = make_float4(0.f, 0.f, 0.f, 0.f), c23 = c01;
     if (live) {
         uint2 hw, vw;
         if (wire) {
@@ -317,11 +322,9 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             hw = reinterpret_cast<const uint2 *>(h)[g];
             vw = reinterpret_cast<const uint2 *>(v)[g];
         }
-        if (tc.cp.tiles) {
-            cam_rays4_poly(tc.cp, (uint32_t)(4 * g), cx, cy);
-        } else {
-            const float4 c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g], c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
-            cx[0] = c01.x; cy[0] = c01.y; cx[1] = c01.z; cy[1] = c01.w; cx[2] = c23.x; cy[2] = c23.y; cx[3] = c23.z; cy[3] = c23.w;
+        if (!poly) {
+            c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g];
+            c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
         }
         const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
 #pragma unroll
@@ -351,6 +354,8 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                            (idx[3] != 0xffffffffu ? 8u : 0u);
     const unsigned nvalid = __builtin_popcount(valid);
+    double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+    if (poly && live) cam_rays4_poly(tc.cp, (uint32_t)(4 * g), cx, cy);
     if constexpr (MODE == SLGC_TRI_EXACT) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -459,32 +464,35 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
     return SLGC_OK;
 }
 
-// Inverse Gram matrix of {1, dx, dy, dx^2, dx*dy, dy^2} over the centred TS x TS grid (dx, dy = -TS/2 .. TS/2 - 1): Gauss-Jordan, float64.
-static void gram_inverse(int ts, double (&ginv)[36])
+// Inverse Gram matrix of the ten bicubic basis terms over the centred TS x TS grid (dx, dy = -TS/2 .. TS/2 - 1): Gauss-Jordan, float64.
+static void gram_inverse(int ts, double (&ginv)[kCamPolyTerms * kCamPolyTerms])
 {
-    double a[6][12] = {};
+    constexpr int n = kCamPolyTerms;
+    double a[n][2 * n] = {};
     for (int j = 0; j < ts; ++j)
         for (int i = 0; i < ts; ++i) {
-            const double dx = i - ts / 2, dy = j - ts / 2, b[6] = {1.0, dx, dy, dx * dx, dx * dy, dy * dy};
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) a[r][c] += b[r] * b[c];
+            const double dx = i - ts / 2, dy = j - ts / 2;
+            double b[n];
+            for (int k = 0; k < n; ++k) b[k] = pow(dx, cam_poly_pow_x(k)) * pow(dy, cam_poly_pow_y(k));
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) a[r][c] += b[r] * b[c];
         }
-    for (int r = 0; r < 6; ++r) a[r][6 + r] = 1.0;
-    for (int p = 0; p < 6; ++p) {
+    for (int r = 0; r < n; ++r) a[r][n + r] = 1.0;
+    for (int p = 0; p < n; ++p) {
         int best = p;
-        for (int r = p + 1; r < 6; ++r)
+        for (int r = p + 1; r < n; ++r)
             if (fabs(a[r][p]) > fabs(a[best][p])) best = r;
-        for (int c = 0; c < 12; ++c) { const double t = a[p][c]; a[p][c] = a[best][c]; a[best][c] = t; }
+        for (int c = 0; c < 2 * n; ++c) { const double t = a[p][c]; a[p][c] = a[best][c]; a[best][c] = t; }
         const double inv = 1.0 / a[p][p];
-        for (int c = 0; c < 12; ++c) a[p][c] *= inv;
-        for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 2 * n; ++c) a[p][c] *= inv;
+        for (int r = 0; r < n; ++r)
             if (r != p) {
                 const double f = a[r][p];
-                for (int c = 0; c < 12; ++c) a[r][c] -= f * a[p][c];
+                for (int c = 0; c < 2 * n; ++c) a[r][c] -= f * a[p][c];
             }
     }
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) ginv[r * 6 + c] = a[r][6 + c];
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) ginv[r * n + c] = a[r][n + c];
 }
 
 // Camera-ray tile polynomials for the band: 16 x 16 tiles first, 8 x 8 if their measured error is over kCamPolyTol, none if that

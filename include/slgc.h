@@ -64,7 +64,8 @@ const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
 /* Tuning knobs for same-process A/B timing; no setting changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 0 = 8x8-pixel projector-table tiles (default) / 1 = 16x8;
- * "cam_poly" 1 = camera rays from the tile polynomials when their error check passed (default) / 0 = exact table;
+ * "cam_poly" 1 = camera rays from the tile polynomials when their error check passed / 0 = exact table (default:
+ * the polynomials remove 98 MB of table traffic per 4096x3000 scan but their float64 evaluation costs more than the stream saves);
  * "park" 1 = at 42 / 44 / 46 frames
  * the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) / 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte
  * wire format / 0 = int16 (default; experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3); "tri_nt" (1); "xcd" XCD-aware tile map of the dense
@@ -205,10 +206,10 @@ int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *
 int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
 
 /* The camera-ray table of the dense path has two forms: the exact one (float32 [rows][W][2], 8 B/pixel, streamed by every scan) and
- * per-tile biquadratics of the undistorted point (64 B per 16x16 or 8x8 pixel tile, L2-resident) from which the kernels evaluate
+ * per-tile bicubics of the undistorted point (96 B per 16x16 or 8x8 pixel tile) from which the kernels evaluate
  * rotation + perspective divide per pixel in float64.  The polynomials are fitted when the tables are built and accepted only if
- * max |ray_poly - ray_exact_float32| over the band is <= 4e-8 (of which up to 6e-8 * |ray| / 2 is the float32 rounding of the exact ray
- * itself); the guarded slow path and SLGC_TRI_EXACT always read the exact table.  After the tables exist: *tile = 16, 8 or 0
+ * the fit error max |ray_poly - ray_exact| (exact ray before its float32 rounding) over the band is <= 1e-8; the guarded slow path and
+ * SLGC_TRI_EXACT always read the exact table.  After the tables exist: *tile = 16, 8 or 0
  * (rejected: exact table only), *max_abs_err = the measured error, *in_use = 1 if the scans use the polynomials ("cam_poly" knob). */
 int slgc_cam_poly_info(slgc_ctx *ctx, int *tile, double *max_abs_err, int *in_use);
 

@@ -54,7 +54,8 @@ def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T):
     tb = tl2 * (prj[:, 0] ** 2 + prj[:, 1] ** 2 + 1.0)
     ra, rb = ta - A * A, tb - B * B
     D = np.sqrt(np.maximum(ra, 0)) * B + A * np.sqrt(np.maximum(rb, 0))
-    flat = (rb < 5e-3 * tb) | (D * D * np.minimum(ra * tb, rb * ta) < 1e-4 * (ta * tb) ** 2)
+    amp = 170.0                                                          # kGuardAmp, csrc/tri_math.h
+    flat = (rb < tb / amp) | (D * D * np.minimum(ra * tb, rb * ta) < (2.0 / amp) ** 2 * (ta * tb) ** 2)
     out = np.zeros((H, W), bool)
     out[yy, xx] = flat
     return out
@@ -219,9 +220,12 @@ def test_device_resident_reference_product(ctx, workload):
 
 @pytest.mark.parametrize("which", ["c3", "c2", "cam_1440"])
 def test_camera_ray_polynomials_error_check(ctx, which):
-    """The 64-byte-per-tile camera-ray polynomials that replace the 8 B/pixel table in the scans: accepted only when the build-time
-    check measures max |ray_poly - ray_exact_float32| <= 4e-8 over the image; with both settings of the knob the scan stays within
-    1e-4 of the oracle, maps bit-identical.  The strongly distorted cam_1440 model (bail-out corners) must be REJECTED -> exact table."""
+    """The 96-byte-per-tile camera-ray bicubics that can replace the 8 B/pixel table in the scans (slgc_tune "cam_poly", off by
+    default): accepted only when the build-time check measures a fit error max |ray_poly - ray_exact| <= 1e-8 over the image.  With
+    the knob on, the maps stay bit-identical and every point stays within 1e-4 of the oracle's RELATIVE TO THE POINT (an additive
+    1e-9 on a ray component is unbounded relative to a component that crosses zero, which the exact-table path never has to face: its
+    rays are the reference's own float32 values); with the knob off the elementwise criterion holds.  The strongly distorted
+    cam_1440 model (bail-out corners) must be REJECTED -> exact table."""
     from scanner import _native
     from scanner import reference_calibration as rc
     if which == "cam_1440":
@@ -232,31 +236,43 @@ def test_camera_ray_polynomials_error_check(ctx, which):
         W, H, pw, ph, N = bench.WORKLOADS["c3_4096x3000x44" if which == "c3" else "c2_1920x1080x44"]
         calib = bench.calibration(W, H, pw, ph)
     ctx.set_calibration(*calib)
-    ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
-    ctx.synchronize()
-    tile, err, in_use = ctx.cam_poly_info()
-    print(f"\n{which}: tile {tile}, max |ray_poly - ray_exact| {err:.3e}, in use {in_use}")
-    if which == "cam_1440":
-        assert tile == 0 and not in_use and err > 4e-8
-    else:
-        assert tile in (8, 16) and in_use and 0 <= err <= 4e-8
     px = W * H
     stack = ctx.alloc(N * px)
     ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=4, noise=3, shadow=True)
     maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
     st = stack.download((N, H, W), np.uint8)
     ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+    ref = np.moveaxis(ref_xyz, 0, -1)
+    ok = (ref_h != -1) & (ref_v != -1) & np.isfinite(ref).all(axis=2)
     worst = {}
     try:
         for knob in (1, 0):
             ctx.tune("cam_poly", knob)
+            ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
+            ctx.synchronize()
+            tile, err, in_use = ctx.cam_poly_info()
+            if knob:
+                print(f"\n{which}: tile {tile}, fit error max |ray_poly - ray_exact| {err:.3e}, in use {in_use}")
+                if which == "cam_1440":
+                    assert tile == 0 and not in_use and err > 1e-8
+                else:
+                    assert tile in (8, 16) and in_use and 0 <= err <= 1e-8
+            else:
+                assert not in_use
             for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT):
                 ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
                 ctx.synchronize()
-                _, worst[(knob, mode)] = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2),
-                                                      xyz.download((H, W, 3), np.float32), ref_h, ref_v, ref_xyz, f"{which} cam_poly={knob} mode={mode}")
+                gh, gv, gx = maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32)
+                if knob and in_use:
+                    assert np.array_equal(gh, ref_h) and np.array_equal(gv, ref_v)
+                    assert np.array_equal(np.isfinite(gx).all(axis=2), ok)
+                    d = np.abs(gx[ok].astype(np.float64) - ref[ok]).max(axis=1) / np.linalg.norm(ref[ok], axis=1)
+                    worst[(knob, mode)] = float(d.max())
+                    assert worst[(knob, mode)] <= XYZ_RTOL
+                else:
+                    _, worst[(knob, mode)] = compare_scan(gh, gv, gx, ref_h, ref_v, ref_xyz, f"{which} cam_poly={knob} mode={mode}")
     finally:
-        ctx.tune("cam_poly", 1)
-    print("   worst rel. XYZ error:", {k: f"{v:.2e}" for k, v in worst.items()})
+        ctx.tune("cam_poly", 0)
+    print("   worst error (knob, mode):", {k: f"{v:.2e}" for k, v in worst.items()})
     for b in (stack, maps, xyz):
         b.free()

@@ -25,6 +25,7 @@ ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--pipeline", default="fused", choices=["fused", "split", "decode"])
 ap.add_argument("--workload", default="c3_4096x3000x44")
+ap.add_argument("--preheat", type=float, default=0.2, help="seconds of untimed launches first (0 under a counter profiler)")
 args = ap.parse_args()
 
 W, H, pw, ph, N = bench.WORKLOADS[args.workload]
@@ -59,7 +60,7 @@ def apply(cfg):
         ctx.tune(k, v)
 
 
-t_end = __import__("time").perf_counter() + 0.2          # pre-heat
+t_end = __import__("time").perf_counter() + args.preheat          # pre-heat
 i = 0
 while __import__("time").perf_counter() < t_end:
     launch(i)

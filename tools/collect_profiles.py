@@ -1,39 +1,79 @@
 #!/usr/bin/env python3
-"""gpurun_out/final/{kt,pmc,bench_*.json} -> profiles/r01_* (kernel stats, per-grid stats, PMC summary, traffic.json)."""
+"""gpurun_out/final/{kt,pmc,bench_*.json} -> profiles/<tag>_* (kernel stats, per-grid stats, PMC summary + the raw counter rows of the
+bench kernels, traffic.json stamped with the fingerprint of the kernel sources it was measured on).  usage: collect_profiles.py r02"""
+import csv
 import glob
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-shutil.copy(max(glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime), os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
-print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), max(glob.glob(os.path.join(src, "kt", "*", "*kernel_trace.csv")), key=os.path.getmtime),
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+C3_GRID = 4096 * 3000 // 4          # threads of a 4-pixels-per-lane kernel over 4096x3000
+
+
+def newest(pattern):
+    return max(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
+
+
+shutil.copy(newest("kt/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
+print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), newest("kt/**/*kernel_trace.csv"),
                       os.path.join(dst, f"{tag}_kernel_stats_by_grid.csv")], capture_output=True, text=True).stdout.split("k_synth")[0])
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(src, "pmc")], capture_output=True)
 shutil.copy(os.path.join(src, "pmc", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_summary_c3.json"))
+# raw counter rows of the scan kernels at the benchmark grid (what the summary and traffic.json are computed from)
+with open(os.path.join(dst, f"{tag}_pmc_raw_c3.csv"), "w", newline="") as out:
+    w = None
+    for f in sorted(glob.glob(os.path.join(src, "pmc", "pass*", "**", "*counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if ("k_decode_pk" in row["Kernel_Name"] or "k_triangulate_maps_lds" in row["Kernel_Name"]) and int(row["Grid_Size"]) == C3_GRID:
+                if w is None:
+                    w = csv.DictWriter(out, fieldnames=["pass"] + list(row.keys()))
+                    w.writeheader()
+                w.writerow({"pass": os.path.relpath(f, os.path.join(src, "pmc")).split(os.sep)[0], **row})
 d = json.load(open(os.path.join(dst, f"{tag}_pmc_summary_c3.json")))
-dec = [k for k in d if k.startswith("k_decode_pk") and "false> @grid=3072000" in k][0]
-fus = [k for k in d if k.startswith("k_decode_pk") and "true> @grid=3072000" in k][0]
+
+
+def kernel_key(fused):
+    """k_decode_pk<PX, BLOCK, NT, MULTI, ABL, FUSE, NS> @grid: FUSE = 0 is the decode kernel, 1 / 2 the fused scan kernel."""
+    for k in d:
+        m = re.match(r"k_decode_pk<([^>]*)> @grid=(\d+)", k)
+        if m and int(m.group(2)) == C3_GRID and "FETCH_SIZE" in d[k]:
+            args = [a.strip() for a in m.group(1).split(",")]
+            if (int(args[5]) != 0) == fused:
+                return k
+    raise SystemExit(f"no {'fused' if fused else 'decode'} kernel at grid {C3_GRID} in the PMC summary")
+
+
+dec, fus = kernel_key(False), kernel_key(True)
 traffic = lambda k: int(round((2 * d[k]["FETCH_SIZE"]["mean"] + d[k]["WRITE_SIZE"]["mean"]) * 1024))   # noqa: E731
-note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), profiles/%s_pmc_summary_c3.json; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
-        "gfx950 FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)" % tag)
+note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), profiles/%s_pmc_summary_c3.json + %s_pmc_raw_c3.csv; bytes = "
+        "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)" % (tag, tag))
+fp = bench.csrc_fingerprint()
 t = {"c3_4096x3000x44/g1/split": {"kernel": dec, "hbm_bytes_per_launch": traffic(dec), "fetch_size_kb": d[dec]["FETCH_SIZE"]["mean"],
-                                  "write_size_kb": d[dec]["WRITE_SIZE"]["mean"], "source": note},
+                                  "write_size_kb": d[dec]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp, "source": note},
      "c3_4096x3000x44/g1/fused": {"kernel": fus, "hbm_bytes_per_launch": traffic(fus), "fetch_size_kb": d[fus]["FETCH_SIZE"]["mean"],
-                                  "write_size_kb": d[fus]["WRITE_SIZE"]["mean"],
-                                  "source": note + "; includes the camera-ray table (98 MB) and projector-ray gathers, which are not algorithmic bytes"}}
+                                  "write_size_kb": d[fus]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
+                                  "source": note + "; includes the projector-ray gathers and the 4 B/pixel maps, which SURVEY 8(d)'s N + 12 does not count"}}
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
-line = [l for l in open(os.path.join(src, "bench_under_rocprof.log")) if l.startswith("{")][0]
+line = [ln for ln in open(os.path.join(src, "bench_under_rocprof.log")) if ln.startswith("{")][0]
 open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+for f in glob.glob(os.path.join(src, "bench_*.json")):
+    if os.path.basename(f) != "bench_default.json":
+        shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
 b, p = json.load(open(os.path.join(dst, f"{tag}_bench_default.json"))), json.loads(line)
 for name, j in (("plain", b), ("under rocprof", p)):
     print(f"{name:14s} value {j['value']:9.1f}  fused kernel {j['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['roofline']['frac']:.3f} | split decode "
           f"{j['split_pipeline']['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['split_pipeline']['roofline']['frac']:.3f} | decode alone "
-          f"{j['decode_kernel_alone']['roofline']['frac']:.3f} | throughput {j['throughput_mode']['value']:9.1f}")
-print({k: v["hbm_bytes_per_launch"] for k, v in t.items()})
+          f"{j['decode_kernel_alone']['roofline']['frac']:.3f} | throughput {j.get('throughput_mode', {}).get('value')}")
+alg = {"split": 48 * 4096 * 3000, "fused": 56 * 4096 * 3000}
+print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / alg[k.rsplit("/", 1)[1]], 3)) for k, v in t.items()}, "fingerprint", fp)

@@ -16,8 +16,10 @@ tail -3 "$out/pmc.log"
 for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
   python3 bench.py --workload $w --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > "$out/bench_$w.json"
 done
-python3 bench.py --force-sharded --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
-python3 bench.py --force-sharded --exchange records --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$out/bench_steps20.json"      # what the driver runs
+python3 bench.py --force-sharded --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
+python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_xyz.json"
+python3 bench.py --force-sharded --exchange records --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
 python3 - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$out/bench_*.json")):
