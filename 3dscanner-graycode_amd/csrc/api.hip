@@ -221,11 +221,12 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device;
     ctx->tune_fuse_tail = xcd_env("SLGC_FUSE_TAIL", 1);
-    ctx->tune_proj_tile = xcd_env("SLGC_PROJ_TILE", 0);
+    ctx->tune_proj_tile = xcd_env("SLGC_PROJ_TILE", 1);
     ctx->tune_fuse_nt = xcd_env("SLGC_FUSE_NT", 3);
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
+    ctx->tune_tri_f32 = xcd_env("SLGC_TRI_F32", 0);        // -1 % on the fused kernel, -6 % on the dense one, +3 % where many pixels sit past its tighter guard: off
     ctx->tune_cam_poly = xcd_env("SLGC_CAM_POLY", 0);      // measured slower than streaming the exact table: off
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -274,6 +275,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
+    else if (!strcmp(name, "tri_f32")) ctx->tune_tri_f32 = value != 0;   // both forms are within the 1e-4 tolerance; they differ in the last float32 bits of XYZ
     else if (!strcmp(name, "cam_poly")) ctx->tune_cam_poly = value != 0;
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG

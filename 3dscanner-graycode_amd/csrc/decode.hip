@@ -237,6 +237,8 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
+    int tri_f32;              // 1: float32 cross-product form of the triangulation (tri_math.h), 0: float64 form
+    TriF32 kf;
     CamPolyRef cp;            // cp.tiles != nullptr: camera rays from the tile polynomials instead of cam_lut (tri_math.h)
     double T[3], t_len;
 };
@@ -600,9 +602,14 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
-        double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
-        if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
-        triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
+        if (a.f.tri_f32 && !poly) {
+            const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
+            triangulate4_f32<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
+        } else {
+            double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+            if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
+            triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded fast form (A/B)
+        }
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
@@ -918,6 +925,8 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.f.nt_store = ctx->tune_fuse_nt;
     b.f.wave_tail = ctx->tune_fuse_tail;
     fill_cam_poly(ctx, &b.f.cp, true);
+    b.f.tri_f32 = ctx->tune_tri_f32;
+    b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

@@ -56,6 +56,7 @@ struct slgc_ctx {
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_cam_poly;      // 1 = camera rays from the tile polynomials when their build-time error check passed, 0 = exact 8 B/pixel table
+    int tune_tri_f32;       // dense / fused triangulation: 1 = float32 cross-product form, 0 = float64 form
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)

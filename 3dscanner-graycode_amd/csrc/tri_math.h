@@ -206,6 +206,91 @@ __device__ __forceinline__ void triangulate4(const double (&cx)[4], const double
     }
 }
 
+// ---- float32 fast path ---------------------------------------------------------------------------------------------------------
+// The same cancelled form with the sines taken from CROSS products, |T x c| = |T||c| sin(alpha), instead of sqrt(|T|^2|c|^2 - (T.c)^2):
+// no subtraction of nearly equal numbers is left in the sines, so float32 carries them to a few 2^-24 of |T||c| however small the
+// angle, and the only cancellation that remains is the one the geometry itself has, in D = Sa*B + A*Sb ~ sin(gamma).  Each of
+// cos(alpha), sin(alpha), cos(beta), sin(beta) then carries an ABSOLUTE error <= ~4 * 2^-24 = 2.4e-7 from the float32 arithmetic (and
+// 6e-8 from rounding T to float32), on top of the 2.7e-7 the reference's own float32 steps differ by (tri_is_flat above), and
+//   |d len / len| <= eps_ref * [1/sin^2 b + (1/sin a + 1/sin b)/sin g]  +  eps_f32 * [1/sin b + 4/sin g].
+// With the guard at kGuardAmpF32 = 60 (sin^2 b >= 1/60, min(sin a, sin b) * sin g >= 2/60 hence sin g >= 1/30):
+//   2 * 60 * 2.7e-7 + 3.0e-7 * (7.8 + 120) = 3.2e-5 + 3.8e-5 = 7.0e-5 < 1e-4.
+// Pixels past the guard are redone by law_of_sines_mirror (float64 on the reference's float32 intermediates), like before.
+constexpr float kGuardAmpF32 = 60.0f;
+
+struct TriF32 {               // per-launch constants of the float32 path
+    float t0, t1, t2, tl2;
+};
+
+struct TriF32Terms {
+    float A, B, Sa2, Sb2, Sa, Sb, D;
+};
+
+__device__ __forceinline__ TriF32Terms tri_f32_terms(float cx, float cy, float px, float py, const TriF32 &k)
+{
+    TriF32Terms t;
+    t.A = -fmaf(k.t0, cx, fmaf(k.t1, cy, k.t2));
+    t.B = fmaf(k.t0, px, fmaf(k.t1, py, k.t2));
+    // T x c and T x p with c = (cx, cy, 1), p = (px, py, 1)
+    const float ux = fmaf(-k.t2, cy, k.t1), uy = fmaf(k.t2, cx, -k.t0), uz = fmaf(k.t0, cy, -k.t1 * cx);
+    const float vx = fmaf(-k.t2, py, k.t1), vy = fmaf(k.t2, px, -k.t0), vz = fmaf(k.t0, py, -k.t1 * px);
+    t.Sa2 = fmaf(ux, ux, fmaf(uy, uy, uz * uz));
+    t.Sb2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+    t.Sa = __builtin_amdgcn_sqrtf(t.Sa2);      // v_sqrt_f32 / v_rcp_f32: 1 ulp, inside eps_f32
+    t.Sb = __builtin_amdgcn_sqrtf(t.Sb2);
+    t.D = fmaf(t.Sa, t.B, t.A * t.Sb);
+    return t;
+}
+
+// sin^2(beta) < 1/A_g   <=>  Sb2 * A_g < tb ;   min(sin a, sin b) * sin g < 2/A_g  <=>  D^2 * min(Sa2*tb, Sb2*ta) < (2/A_g)^2 * (ta*tb)^2
+__device__ __forceinline__ bool tri_f32_flat(const TriF32Terms &t, float cx, float cy, float px, float py, const TriF32 &k)
+{
+    const float ta = k.tl2 * fmaf(cx, cx, fmaf(cy, cy, 1.0f)), tb = k.tl2 * fmaf(px, px, fmaf(py, py, 1.0f));
+    const float tatb = ta * tb;
+    constexpr float k2 = (2.0f / kGuardAmpF32) * (2.0f / kGuardAmpF32);
+    return (t.Sb2 * kGuardAmpF32 < tb) | ((t.D * t.D) * fminf(t.Sa2 * tb, t.Sb2 * ta) < (k2 * tatb) * tatb) | !(t.D == t.D);
+}
+
+__device__ __forceinline__ bool tri_f32_is_flat(float cx, float cy, float px, float py, const TriF32 &k)
+{
+    return tri_f32_flat(tri_f32_terms(cx, cy, px, py, k), cx, cy, px, py, k);
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void triangulate4_f32(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+                                                 uint32_t valid, const TriF32 &k, const double (&T)[3], double t_len, float (&out)[12],
+                                                 const float2 *__restrict__ cam4, const float2 *__restrict__ proj_lut, const uint32_t (&idx)[4])
+{
+    uint32_t ill = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const TriF32Terms t = tri_f32_terms(cx[j], cy[j], px[j], py[j], k);
+        const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
+        if (GUARD) ill |= tri_f32_flat(t, cx[j], cy[j], px[j], py[j], k) ? (1u << j) : 0u;
+        const bool ok = (valid >> j) & 1u;
+        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
+        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
+        out[3 * j + 2] = ok ? s : __builtin_nanf("");
+    }
+    if (GUARD) {
+        ill &= valid;
+        if (ill) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                if (!((ill >> j) & 1u)) continue;
+                const float2 cr = cam4[j], pr = proj_lut[j == 0 ? idx[0] : j == 1 ? idx[1] : j == 2 ? idx[2] : idx[3]];
+                const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, T, t_len);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    out[3 * q] = (q == j) ? r.x : out[3 * q];
+                    out[3 * q + 1] = (q == j) ? r.y : out[3 * q + 1];
+                    out[3 * q + 2] = (q == j) ? r.z : out[3 * q + 2];
+                }
+            }
+        }
+    }
+}
+
 // The projector table is stored in tiles of 8 rows so that a wave's gather stays within a few cache lines whichever way the
 // decoded projector coordinates drift along a camera row.  wide = 0: 8x8-pixel tiles (512 B, a tile row is half a 128-byte line);
 // wide = 1: 16x8-pixel tiles (1 KB, a tile row is exactly one 128-byte line).  tiles_x counts tiles of the chosen width.

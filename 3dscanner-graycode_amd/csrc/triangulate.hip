@@ -205,6 +205,8 @@ struct TriConst {
     double T[3];
     double t_len;
     CamPolyRef cp;           // cp.tiles == nullptr: camera rays from the exact table
+    int tri_f32;             // 1: float32 cross-product form (tri_math.h triangulate4_f32)
+    TriF32 kf;
 };
 
 // Fit one tile of the camera-ray polynomial table (tri_math.h) and measure its error.  One workgroup of TS*TS threads per tile;
@@ -366,6 +368,9 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
+    } else if (tc.tri_f32 && !poly) {
+        const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
+        triangulate4_f32<MODE != 2>(fx, fy, px, py, valid, tc.kf, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);
     } else {
         triangulate4<MODE != 2>(cx, cy, px, py, valid, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);      // MODE 2: unguarded fast form (A/B)
     }
@@ -414,7 +419,12 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
         if (!(hv == -1 || vv == -1)) {
             ok = 1;
             const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
-            flat = tri_is_flat(tri_terms(c.x, c.y, q.x, q.y, tc.T, tc.t_len * tc.t_len)) ? 1u : 0u;
+            if (tc.tri_f32) {                       // the float32 form's own test, through the same function the scans run
+                const float fx[4] = {c.x, 0.f, 0.f, 0.f}, fy[4] = {c.y, 0.f, 0.f, 0.f}, gx[4] = {q.x, 0.f, 0.f, 0.f}, gy[4] = {q.y, 0.f, 0.f, 0.f};
+                flat = tri_f32_is_flat(fx[0], fy[0], gx[0], gy[0], tc.kf) ? 1u : 0u;
+            } else {
+                flat = tri_is_flat(tri_terms(c.x, c.y, q.x, q.y, tc.T, tc.t_len * tc.t_len)) ? 1u : 0u;
+            }
         }
     }
     unsigned packed = ok | (flat << 16);                       // 64 lanes: both sums fit 16 bits
@@ -446,6 +456,8 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     memcpy(tc.T, ctx->calib.T, sizeof tc.T);
     tc.t_len = ctx->calib.t_len;
     fill_cam_poly(ctx, &tc.cp, false);
+    tc.tri_f32 = ctx->tune_tri_f32;
+    tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
                        (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
     HIP_TRY(ctx, hipGetLastError());
@@ -627,6 +639,8 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         memcpy(tc.T, ctx->calib.T, sizeof tc.T);
         tc.t_len = ctx->calib.t_len;
         fill_cam_poly(ctx, &tc.cp, mode != SLGC_TRI_EXACT);          // the acos / sin parity mode always reads the exact float32 rays
+        tc.tri_f32 = ctx->tune_tri_f32;
+        tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")

@@ -62,15 +62,16 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
-/* Tuning knobs for same-process A/B timing; no setting changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
- * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 0 = 8x8-pixel projector-table tiles (default) / 1 = 16x8;
- * "cam_poly" 1 = camera rays from the tile polynomials when their error check passed / 0 = exact table (default:
+/* Tuning knobs for same-process A/B timing; no setting changes the maps, and XYZ only within the tolerance ("tri_f32", "cam_poly").  "fuse_tail" 1 = wave-local LDS exchange in the fused
+ * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
+ * "tri_f32" 1 = float32 cross-product form of the dense / fused triangulation / 0 = float64 form (default; both inside the 1e-4
+ * tolerance, they differ in the last float32 bits of XYZ and in which pixels take the guarded path); "cam_poly" 1 = camera rays from the tile polynomials when their error check passed / 0 = exact table (default:
  * the polynomials remove 98 MB of table traffic per 4096x3000 scan but their float64 evaluation costs more than the stream saves);
  * "park" 1 = at 42 / 44 / 46 frames
  * the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) / 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte
  * wire format / 0 = int16 (default; experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3); "tri_nt" (1); "xcd" XCD-aware tile map of the dense
  * triangulation kernel (1).  Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT,
- * SLGC_XCD), read when the context is created. */
+ * SLGC_XCD, SLGC_TRI_F32, SLGC_CAM_POLY), read when the context is created. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all

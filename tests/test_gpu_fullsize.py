@@ -37,8 +37,9 @@ def oracle_threads():
     oc.set_threads(1)
 
 
-def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T):
-    """NumPy twin of tri_is_flat (csrc/tri_math.h) on the oracle's float32 rays: which decodable pixels take the guarded path."""
+def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T, amp=170.0):
+    """NumPy twin of tri_is_flat / tri_f32_flat (csrc/tri_math.h; amp = kGuardAmp 170 for the float64 form, kGuardAmpF32 60 for the
+    float32 form) on the oracle's float32 rays: which decodable pixels take the guarded path."""
     H, W = h.shape
     ok = (h != -1) & (v != -1)
     yy, xx = np.nonzero(ok)
@@ -54,7 +55,6 @@ def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T):
     tb = tl2 * (prj[:, 0] ** 2 + prj[:, 1] ** 2 + 1.0)
     ra, rb = ta - A * A, tb - B * B
     D = np.sqrt(np.maximum(ra, 0)) * B + A * np.sqrt(np.maximum(rb, 0))
-    amp = 170.0                                                          # kGuardAmp, csrc/tri_math.h
     flat = (rb < tb / amp) | (D * D * np.minimum(ra * tb, rb * ta) < (2.0 / amp) ** 2 * (ta * tb) ** 2)
     out = np.zeros((H, W), bool)
     out[yy, xx] = flat
@@ -107,16 +107,26 @@ def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
     # (3) the exact (acos / sin) dense kernel on the same maps
     _, worst_exact = compare_scan(*run(_native.TRI_EXACT), ref_h, ref_v, ref_xyz, workload + " exact")
     assert worst_exact < 1e-6
-    # guard path: how many pixels the fused / dense kernels redo on the reference's float32 intermediates
-    cnt.zero()
-    ctx.guard_count_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), cnt.ptr)
-    ctx.synchronize()
-    n_ok, n_flat = (int(x) for x in cnt.download((2,), np.uint64))
-    assert n_ok == valid
-    flat_ref = flat_mask_np(ref_h, ref_v, (pw, ph), *calib)
-    assert abs(n_flat - int(flat_ref.sum())) <= 2       # same test on the same rays; fast_sqrt vs sqrt can move a pixel sitting on the threshold
-    print(f"\n{workload}: {valid} / {px} decodable, {n_flat} on the guarded path ({100.0 * n_flat / max(valid, 1):.3f} %), worst rel. XYZ error "
-          f"fused {worst_fused:.2e} split {worst_split:.2e} exact {worst_exact:.2e}")
+    # guard path: how many pixels the fused / dense kernels redo on the reference's float32 intermediates, under both forms of the fast path
+    flagged = {}
+    try:
+        for knob, amp in ((1, 60.0), (0, 170.0)):
+            ctx.tune("tri_f32", knob)
+            cnt.zero()
+            ctx.guard_count_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), cnt.ptr)
+            ctx.synchronize()
+            n_ok, n_flat = (int(x) for x in cnt.download((2,), np.uint64))
+            assert n_ok == valid
+            n_ref = int(flat_mask_np(ref_h, ref_v, (pw, ph), *calib, amp=amp).sum())
+            assert abs(n_flat - n_ref) <= 2 + n_ref // 500      # same test on the same rays; float32 / fast_sqrt rounding moves pixels sitting on the threshold
+            flagged[knob] = n_flat
+            _, worst = compare_scan(*run(_native.TRI_ALGEBRAIC), ref_h, ref_v, ref_xyz, f"{workload} fused tri_f32={knob}")
+            flagged[f"worst{knob}"] = worst
+    finally:
+        ctx.tune("tri_f32", 0)
+    print(f"\n{workload}: {valid} / {px} decodable; guarded path: float32 form {flagged[1]} px ({100.0 * flagged[1] / max(valid, 1):.3f} %), float64 form "
+          f"{flagged[0]} px; worst rel. XYZ error fused {worst_fused:.2e} (f32 {flagged['worst1']:.2e}, f64 {flagged['worst0']:.2e}) split {worst_split:.2e} "
+          f"exact {worst_exact:.2e}")
     for b in (stack, maps, xyz, cnt):
         b.free()
 
