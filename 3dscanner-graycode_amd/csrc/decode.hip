@@ -216,15 +216,20 @@ __global__ void __launch_bounds__(BLOCK) k_decode_fast(const FastArgs a)
 // ------------------------------------------------------------------------------------------
 //
 // A dword of a frame holds pixels p0..p3.  It is split into the pairs E = [p0, p2] and O = [p1, p3] (one v_perm /
-// v_and each), so every later instruction handles two pixels.  For a pair register X (values 0..255 per half):
-//     X + (0x8000 - t)   has bit 15 of a half set   <=>  x >= t          (threshold tests, t in 0..256)
-//     D = N - I          (v_pk_sub_i16)             ;    sign(D - c) = !r1 ;  sign(D + c - 1) = r2
-// and the rule table is evaluated on bit 15 / bit 31 with three-input boolean ops (v_bitop3_b32):
-//     bit   = (Nb & ~Ia) | (~S1 & (Na | ~Ib))                 (r4 | (r1 & ~r3))
-//     valid = (~S1 | (~Na & Ib)) | (S2 | (Nb & ~Ia))          (r1 | r3 | r2 | r4)
-// Code bits are shifted in LSB-first (acc = (acc >> 1) | bit15), so the column code walks k = L-1 .. 0 and the row
-// code k = 0 .. L-1.  Frames are fetched with buffer loads: per-lane 32-bit offset in a VGPR, per-frame offset in an
-// SGPR, hardware bounds check instead of a tail branch.
+// v_and each), so every later instruction handles two pixels.  For a pair register X (values 0..255 per 16-bit half):
+//     X + (0x8000 - t)             has bit 15 of a half set  <=>  x >= t         (threshold tests, t in 0..256)
+//     D' = N + (0x0100 - I)        = n - i + 256 in 1..511 per half
+//     D' + (0x8000 - 256 - c)      has bit 15 set  <=>  n - i >= c  (r1) ;    D' + (0x8000 - 257 + c)  has bit 15 clear  <=>  i - n >= c  (r2)
+// Every one of these sums stays inside its 16-bit half (no carry, no borrow: ranges in pack_pair_consts), so they are plain 32-bit
+// v_add_u32 / v_sub_u32 -- full rate on gfx950, where the packed v_pk_add_u16 / v_pk_sub_i16 / v_pk_lshrrev_b16 / v_and_or_b32 this
+// kernel first used issue at HALF rate (tools/ubench/valu_rates.hip: 2.5 vs 4.5 cycles per wave instruction).  The rule table is
+// evaluated on bit 15 / bit 31 with three-input boolean ops (v_bitop3_b32, full rate):
+//     bit   = (Nb & ~Ia) | (R1 & (Na | ~Ib))                  (r4 | (r1 & ~r3))
+//     valid = (R1 | (~Na & Ib)) | (~R2 | (Nb & ~Ia))          (r1 | r3 | r2 | r4)
+// Step t deposits its bit at position t of each half (acc |= (bit >> (15 - t)) & (0x00010001 << t): a 32-bit shift and one bitop3; the
+// bits a 32-bit shift drags across the halves are masked away), so the column code walks k = L-1 .. 0 and the row code k = 0 .. L-1.
+// Frames are fetched with buffer loads: per-lane 32-bit offset in a VGPR, per-frame offset in an SGPR, hardware bounds check instead of
+// a tail branch.
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 typedef short v2ss __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -237,8 +242,6 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
-    int tri_f32;              // 1: float32 cross-product form of the triangulation (tri_math.h), 0: float64 form
-    TriF32 kf;
     CamPolyRef cp;            // cp.tiles != nullptr: camera rays from the tile polynomials instead of cam_lut (tri_math.h)
     double T[3], t_len;
 };
@@ -287,31 +290,53 @@ __device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, u
     return f;
 }
 
-// Thresholds of the two pixels of a pair register -> the four packed constants classify_pk compares against
-// (tt = tnd | tg << 16 and cc = cA from pixel_thresholds; lo / hi = the register's low / high half).
-__device__ __forceinline__ void pack_pair_consts(int tt_lo, int cc_lo, int tt_hi, int cc_hi, uint32_t &KA, uint32_t &KB, uint32_t &C1, uint32_t &C2)
+// Thresholds of the two pixels of a pair register -> the four packed constants classify_pk adds
+// (tt = tnd | tg << 16 and cc = cA from pixel_thresholds; lo / hi = the register's low / high half).  Ranges, per half, with
+// n, i in 0..255, tnd, tg in 0..256, cA in 1..256 or kUnreachable = 0x4000:
+//   x + KA,  x + KB   in 0x7f00 .. 0x80ff          D' = n - i + 256 in 1 .. 511
+//   D' + K1 (K1 = 0x8000 - 256 - cA in 0x3f00 .. 0x7eff)   in 0x3f01 .. 0x80fe
+//   D' + K2 (K2 = 0x8000 - 257 + cA in 0x7f00 .. 0xbeff)   in 0x7f01 .. 0xc0fe          -- all inside 16 bits: no carry between the halves.
+__device__ __forceinline__ void pack_pair_consts(int tt_lo, int cc_lo, int tt_hi, int cc_hi, uint32_t &KA, uint32_t &KB, uint32_t &K1, uint32_t &K2)
 {
     const uint32_t a_lo = (uint32_t)tt_lo & 0xffffu, a_hi = (uint32_t)tt_hi & 0xffffu;
     const uint32_t b_lo = (uint32_t)tt_lo >> 16, b_hi = (uint32_t)tt_hi >> 16;
     KA = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
     KB = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
-    C1 = (uint32_t)cc_lo | ((uint32_t)cc_hi << 16);
-    C2 = (uint32_t)(cc_lo - 1) | ((uint32_t)(cc_hi - 1) << 16);
+    K1 = (0x8000u - 256u - (uint32_t)cc_lo) | ((0x8000u - 256u - (uint32_t)cc_hi) << 16);
+    K2 = (0x8000u - 257u + (uint32_t)cc_lo) | ((0x8000u - 257u + (uint32_t)cc_hi) << 16);
 }
 
-// One (normal, inverse) pair register through the rule table; updates the code-bit and validity accumulators.
-template <bool MULTI>
-__device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t C1, uint32_t C2,
-                                            uint32_t &accB, uint32_t &accV)
+// (a & b) | c as ONE full-rate v_bitop3_b32 (the compiler's own choice for this shape, v_and_or_b32, issues at half rate on gfx950)
+__device__ __forceinline__ uint32_t and_or_full_rate(uint32_t a, uint32_t b, uint32_t c)
 {
-    const uint32_t Na = pk_add(N, KA), Nb = pk_add(N, KB), Ia = pk_add(I, KA), Ib = pk_add(I, KB);
-    const uint32_t D = pk_sub(N, I);
-    const uint32_t S1 = pk_sub(D, C1), S2 = pk_add(D, C2);
-    const uint32_t bit = (Nb & ~Ia) | (~S1 & (Na | ~Ib));
-    const uint32_t y = ~S1 | (~Na & Ib), z = S2 | (Nb & ~Ia);
-    accB = pk_shr1(accB) | (bit & 0x80008000u);
-    if constexpr (MULTI) accV = pk_shr1(accV) | ((y | z) & 0x80008000u);
-    else accV &= (y | z);
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA);
+}
+
+// One (normal, inverse) pair register through the rule table: bit 15 / bit 31 of `bit` = the code bit, of `ok` = "classified".
+__device__ __forceinline__ void classify_bits(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t K1, uint32_t K2, uint32_t &bit, uint32_t &ok)
+{
+    const uint32_t Na = N + KA, Nb = N + KB, Ia = I + KA, Ib = I + KB;
+    const uint32_t Dp = N + (0x01000100u - I);
+    const uint32_t R1 = Dp + K1, R2 = Dp + K2;
+    // five v_bitop3_b32 (truth-table index = a << 2 | b << 1 | c), spelled out: left to itself the compiler closes these expressions
+    // with v_and_or_b32 / v_or3_b32, which issue at half rate
+    const uint32_t r4 = __builtin_amdgcn_bitop3_b32(Nb, Ia, Nb, 0x30);         // Nb & ~Ia
+    const uint32_t n3 = __builtin_amdgcn_bitop3_b32(Na, Ib, Na, 0xF3);         // Na | ~Ib            = ~r3
+    bit = __builtin_amdgcn_bitop3_b32(R1, n3, r4, 0xEA);                       // (R1 & ~r3) | r4
+    const uint32_t r23 = __builtin_amdgcn_bitop3_b32(Na, Ib, R2, 0x5D);        // (~Na & Ib) | ~R2    = r3 | r2
+    ok = __builtin_amdgcn_bitop3_b32(R1, r23, r4, 0xFE);                       // r1 | r2 | r3 | r4
+}
+
+// ... and into the accumulators: step t deposits at bit t of each half (shift = 15 - t, mask = 0x00010001 << t).
+template <bool MULTI>
+__device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t K1, uint32_t K2,
+                                            uint32_t &accB, uint32_t &accV, uint32_t shift, uint32_t mask)
+{
+    uint32_t bit, ok;
+    classify_bits(N, I, KA, KB, K1, K2, bit, ok);
+    accB = and_or_full_rate(bit >> shift, mask, accB);
+    if constexpr (MULTI) accV = and_or_full_rate(ok >> shift, mask, accV);
+    else accV &= ok;
 }
 
 // Compile-time twin of slgc_make_geom (decode_codes.py:109-111, :149) for the frame counts the generator and BASELINE.json use:
@@ -338,6 +363,9 @@ struct FrameSpec {
     static constexpr Table table = make();
 };
 
+#ifndef SLGC_FUSED_TRI_F32
+#define SLGC_FUSED_TRI_F32 0
+#endif
 #ifndef SLGC_PARK_DEPTH
 #define SLGC_PARK_DEPTH 2      // steps of frame loads in flight ahead of the step being classified (specialised kernels)
 #endif
@@ -368,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
 
     for (int r = 0; r < a.g.n_runs; ++r) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[r], 0, a.run_bytes, 0x00020000);
-        uint32_t KA[NP], KB[NP], C1[NP], C2[NP];
+        uint32_t KA[NP], KB[NP], C1[NP], C2[NP];      // C1 / C2 hold K1 / K2 of pack_pair_consts
         if constexpr (ABL == 1 || ABL == 2) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
@@ -426,17 +454,18 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
 #pragma unroll
         for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
         // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
-        auto step = [&](const Frame<NW, NT> &hn, const Frame<NW, NT> &hi, const Frame<NW, NT> &vn, const Frame<NW, NT> &vi) {
+        auto step = [&](const Frame<NW, NT> &hn, const Frame<NW, NT> &hi, const Frame<NW, NT> &vn, const Frame<NW, NT> &vi, uint32_t t) {
+            const uint32_t sh = 15u - t, mk = 0x00010001u << t;
             if constexpr (ABL == 2) {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) { aB_h[2 * q] ^= hn.w[q] + hi.w[q]; aB_v[2 * q] ^= vn.w[q] + vi.w[q]; }
             } else {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) {
-                    classify_pk<MULTI>(even_pair(hn.w[q]), even_pair(hi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_h[2 * q], aV_h[2 * q]);
-                    classify_pk<MULTI>(odd_pair(hn.w[q]), odd_pair(hi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_h[2 * q + 1], aV_h[2 * q + 1]);
-                    classify_pk<MULTI>(even_pair(vn.w[q]), even_pair(vi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_v[2 * q], aV_v[2 * q]);
-                    classify_pk<MULTI>(odd_pair(vn.w[q]), odd_pair(vi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_v[2 * q + 1], aV_v[2 * q + 1]);
+                    classify_pk<MULTI>(even_pair(hn.w[q]), even_pair(hi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_h[2 * q], aV_h[2 * q], sh, mk);
+                    classify_pk<MULTI>(odd_pair(hn.w[q]), odd_pair(hi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_h[2 * q + 1], aV_h[2 * q + 1], sh, mk);
+                    classify_pk<MULTI>(even_pair(vn.w[q]), even_pair(vi.w[q]), KA[2 * q], KB[2 * q], C1[2 * q], C2[2 * q], aB_v[2 * q], aV_v[2 * q], sh, mk);
+                    classify_pk<MULTI>(odd_pair(vn.w[q]), odd_pair(vi.w[q]), KA[2 * q + 1], KB[2 * q + 1], C1[2 * q + 1], C2[2 * q + 1], aB_v[2 * q + 1], aV_v[2 * q + 1], sh, mk);
                 }
             }
         };
@@ -463,7 +492,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
             for (int t = 0; t < FS::L; ++t) {
                 if (t + DEPTH < FS::L) fetch_step(t + DEPTH, ring[(t + DEPTH) % (DEPTH + 1)]);
                 Frame<NW, NT> (&cur)[4] = ring[t % (DEPTH + 1)];
-                step(cur[0], cur[1], cur[2], cur[3]);
+                step(cur[0], cur[1], cur[2], cur[3], (uint32_t)t);
                 // pin the accumulators here: left alone, the optimiser defers the whole "classified?" chain of every unrolled step to the
                 // end of the loop and keeps each step's intermediates alive until then (230+ registers)
                 asm volatile("" : "+v"(aB_h[0]), "+v"(aB_h[1]), "+v"(aB_v[0]), "+v"(aB_v[1]), "+v"(aV_h[0]), "+v"(aV_h[1]), "+v"(aV_v[0]), "+v"(aV_v[1]));
@@ -477,7 +506,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
                 const Frame<NW, NT> hn = load_frame<NW, NT>(rs, off, s_hn), hi = load_frame<NW, NT>(rs, off, s_hi);
                 const Frame<NW, NT> vn = load_frame<NW, NT>(rs, off, s_vn), vi = load_frame<NW, NT>(rs, off, s_vi);
                 s_hn -= 2 * ps; s_hi -= 2 * ps; s_vn += 2 * ps; s_vi += 2 * ps;
-                step(hn, hi, vn, vi);
+                step(hn, hi, vn, vi, (uint32_t)t);
             }
         }
 #pragma unroll
@@ -488,18 +517,16 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         }
     }
 
-    // accumulators hold the L code bits in the top L bits of each half
-    const unsigned short sh = (unsigned short)(16 - L);
+    // accumulators hold the L code bits in bits 0 .. L-1 of each half
     const uint32_t full = ((1u << L) - 1u) * 0x00010001u;
     uint32_t oh[NP], ov[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const uint32_t gh = as_u(as_us(mB_h[p]) >> sh), gv = as_u(as_us(mB_v[p]) >> sh);
+        const uint32_t gh = mB_h[p], gv = mB_v[p];
         uint32_t okh, okv;  // 0xffff per half where every code was classified
         if constexpr (MULTI) {
-            const uint32_t vh = as_u(as_us(mV_h[p]) >> sh), vv = as_u(as_us(mV_v[p]) >> sh);
-            okh = as_u(as_ss(pk_add(vh ^ full, 0x7fff7fffu) ) >> (short)15);   // half != 0 -> bit15 set -> 0xffff = NOT ok
-            okv = as_u(as_ss(pk_add(vv ^ full, 0x7fff7fffu) ) >> (short)15);
+            okh = as_u(as_ss(pk_add(mV_h[p] ^ full, 0x7fff7fffu)) >> (short)15);   // half != 0 -> bit15 set -> 0xffff = NOT ok
+            okv = as_u(as_ss(pk_add(mV_v[p] ^ full, 0x7fff7fffu)) >> (short)15);
             okh = ~okh; okv = ~okv;
         } else {
             okh = as_u(as_ss(mV_h[p]) >> (short)15);
@@ -602,14 +629,15 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
-        if (a.f.tri_f32 && !poly) {
-            const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
-            triangulate4_f32<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
-        } else {
-            double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
-            if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
-            triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded fast form (A/B)
-        }
+#if SLGC_FUSED_TRI_F32        // build-time A/B (make variant EXTRA=-DSLGC_FUSED_TRI_F32=1): the float32 cross-product form in the fused tail
+        const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
+        const TriF32 kf{(float)a.f.T[0], (float)a.f.T[1], (float)a.f.T[2], (float)(a.f.t_len * a.f.t_len)};
+        triangulate4_f32<ABL != 8>(fx, fy, px, py, valid, kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
+#else
+        double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+        if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
+        triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
+#endif
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
@@ -810,8 +838,14 @@ __global__ void __launch_bounds__(256) k_selftest_classify(unsigned long long *b
     unsigned n_bad = 0;
     for (int i = 0; i < 256; ++i) {
         const int n2 = 255 - n, i2 = (i * 37 + 11) & 255;
-        uint32_t accB = 0u, accV = 0xffffffffu;
-        classify_pk<false>((uint32_t)n | ((uint32_t)n2 << 16), (uint32_t)i | ((uint32_t)i2 << 16), KA, KB, C1, C2, accB, accV);
+        // through the accumulating form the kernels use, at a step t that varies (deposit position t of each half), single-run and multi-run
+        const uint32_t t = (uint32_t)((n + i) % 15), sh = 15u - t, mk = 0x00010001u << t;
+        const uint32_t junk = 0x5a5a5a5au & ~mk;                      // bits of other steps already in the accumulator must survive
+        uint32_t accB = junk, accV = 0xffffffffu, accVm = junk;
+        const uint32_t Np = (uint32_t)n | ((uint32_t)n2 << 16), Ip = (uint32_t)i | ((uint32_t)i2 << 16);
+        classify_pk<false>(Np, Ip, KA, KB, C1, C2, accB, accV, sh, mk);
+        uint32_t accB2 = junk;
+        classify_pk<true>(Np, Ip, KA, KB, C1, C2, accB2, accVm, sh, mk);
         auto expect = [](int n_, int i_, int tnd_, int tg_, int cA_, bool &bit, bool &valid) {
             const bool r1 = (n_ - i_) >= cA_, r2 = (i_ - n_) >= cA_;
             const bool r3 = (n_ < tnd_) & (i_ >= tg_), r4 = (n_ >= tg_) & (i_ < tnd_);
@@ -823,7 +857,9 @@ __global__ void __launch_bounds__(256) k_selftest_classify(unsigned long long *b
         expect(n2, i2, tnd2, tg2, cA2, b_hi, v_hi);
         // an unclassified pair leaves the code bit unspecified (the pixel becomes -1): compare it only where valid
         n_bad += (((accV >> 15) & 1u) != (unsigned)v_lo) + (((accV >> 31) & 1u) != (unsigned)v_hi);
-        n_bad += (v_lo && (((accB >> 15) & 1u) != (unsigned)b_lo)) + (v_hi && (((accB >> 31) & 1u) != (unsigned)b_hi));
+        n_bad += (((accVm >> t) & 1u) != (unsigned)v_lo) + (((accVm >> (16 + t)) & 1u) != (unsigned)v_hi);
+        n_bad += (v_lo && (((accB >> t) & 1u) != (unsigned)b_lo)) + (v_hi && (((accB >> (16 + t)) & 1u) != (unsigned)b_hi));
+        n_bad += ((accB & ~mk) != junk) + ((accVm & ~mk) != junk) + (accB2 != accB);
     }
     if (n_bad) atomicAdd(bad, (unsigned long long)n_bad);
 }
@@ -925,8 +961,6 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.f.nt_store = ctx->tune_fuse_nt;
     b.f.wave_tail = ctx->tune_fuse_tail;
     fill_cam_poly(ctx, &b.f.cp, true);
-    b.f.tri_f32 = ctx->tune_tri_f32;
-    b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

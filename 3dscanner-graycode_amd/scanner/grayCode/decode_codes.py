@@ -15,7 +15,7 @@ import numpy as np
 
 from .._native import default_context
 
-__all__ = ["read_images_order", "remove_bad_images", "to_gray", "get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
+__all__ = ["read_images", "read_images_order", "remove_bad_images", "to_gray", "get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
            "codes_to_pixels", "decode"]
 
 
@@ -24,6 +24,32 @@ def read_images_order(file_names):
     sort by NAME LENGTH only, so frame_2.jpg sorts before frame_10.jpg but equal-length names keep listdir order.  The image
     decoding itself (cv2.imread) stays with the caller: JPEG decoding is outside this build's scope."""
     return sorted(file_names, key=len)
+
+
+def read_images(folder, dtype=np.float64):
+    """Reference decode_codes.py:6-32: every image of ``folder`` in ``sorted(os.listdir(folder), key=len)`` order ->
+    ``(images [n,H,W,3] BGR, file_names)`` -- float64 like the reference's ``np.empty`` buffer (``dtype=np.uint8`` keeps the bytes).
+
+    Host-side ingest helper, like the reference's (cv2.imread runs on the CPU there too): the JPEG decoding is Pillow's here -- the ROCm
+    image ships no rocJPEG, and OpenCV is not installed -- so byte-for-byte parity with ``cv2.imread`` (another libjpeg build, another
+    IDCT) is UNPINNED; the file order, shapes, channel order and return types are the reference's.  Feed the images to
+    ``Context.to_gray`` (GPU BGR -> grey, uint8 stack) and then to ``decode``."""
+    import os
+    try:
+        from PIL import Image
+    except ImportError as e:                                   # no silent fallback: say what is missing
+        raise ImportError("read_images needs Pillow to decode the image files (JPEG decoding is not part of libslgc)") from e
+    names = read_images_order(os.listdir(folder))
+    images = None
+    for i, name in enumerate(names):
+        with Image.open(os.path.join(folder, name)) as im:
+            bgr = np.asarray(im.convert("RGB"), dtype=np.uint8)[:, :, ::-1]          # cv2.imread returns BGR
+        if images is None:
+            images = np.empty((len(names),) + bgr.shape, dtype=dtype)               # :28
+        images[i] = bgr
+    if images is None:
+        images = np.empty((0, 0, 0, 3), dtype=dtype)
+    return images, np.array(names)
 
 
 def remove_bad_images(images, ctx=None):

@@ -64,7 +64,7 @@ const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
 /* Tuning knobs for same-process A/B timing; no setting changes the maps, and XYZ only within the tolerance ("tri_f32", "cam_poly").  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
- * "tri_f32" 1 = float32 cross-product form of the dense / fused triangulation / 0 = float64 form (default; both inside the 1e-4
+ * "tri_f32" 1 = float32 cross-product form in the DENSE triangulation kernel / 0 = float64 form (default; both inside the 1e-4
  * tolerance, they differ in the last float32 bits of XYZ and in which pixels take the guarded path); "cam_poly" 1 = camera rays from the tile polynomials when their error check passed / 0 = exact table (default:
  * the polynomials remove 98 MB of table traffic per 4096x3000 scan but their float64 evaluation costs more than the stream saves);
  * "park" 1 = at 42 / 44 / 46 frames

@@ -204,3 +204,26 @@ def test_remove_bad_images_window_rule_equals_the_reference_state_machine():
             assert dc.remove_bad_images(frames, ctx=Counts(d)) == onp.remove_bad_images(frames), (case, d)
     finally:
         onp.frame_diff_counts = orig
+
+
+def test_read_images_order_shapes_and_types(tmp_path):
+    """read_images (decode_codes.py:6-32): sorted(key=len) file order, BGR channel order, float64 [n,H,W,3] + file names like the
+    reference.  (Decoded values are Pillow's: parity with cv2.imread is unpinned, PNG is used here so the bytes are exact.)"""
+    PIL = pytest.importorskip("PIL.Image")
+    from scanner.grayCode.decode_codes import read_images
+    rng = np.random.default_rng(3)
+    frames = {}
+    for name in ("frame_10.png", "frame_2.png", "frame_1.png", "frame_100.png"):
+        rgb = rng.integers(0, 256, (6, 9, 3), dtype=np.uint8)
+        PIL.fromarray(rgb).save(tmp_path / name)
+        frames[name] = rgb
+    images, names = read_images(str(tmp_path))
+    want = sorted(os.listdir(tmp_path), key=len)
+    assert list(names) == want and images.shape == (4, 6, 9, 3) and images.dtype == np.float64
+    for i, n in enumerate(want):
+        assert np.array_equal(images[i], frames[n][:, :, ::-1])                      # BGR
+    u8, _ = read_images(str(tmp_path), dtype=np.uint8)
+    assert u8.dtype == np.uint8 and np.array_equal(u8, images.astype(np.uint8))
+    empty = tmp_path / "none"
+    empty.mkdir()
+    assert read_images(str(empty))[0].shape[0] == 0
