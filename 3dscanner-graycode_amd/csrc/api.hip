@@ -226,8 +226,6 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
-    ctx->tune_tri_f32 = xcd_env("SLGC_TRI_F32", 0);        // -1 % on the fused kernel, -6 % on the dense one, +3 % where many pixels sit past its tighter guard: off
-    ctx->tune_cam_poly = xcd_env("SLGC_CAM_POLY", 0);      // measured slower than streaming the exact table: off
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;
@@ -250,7 +248,6 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     for (int i = 0; i < SLGC_WS_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
-    if (ctx->lut_cam_poly) (void)hipFree(ctx->lut_cam_poly);
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
     if (ctx->count_slots) (void)hipFree(ctx->count_slots);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -275,8 +272,6 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
-    else if (!strcmp(name, "tri_f32")) ctx->tune_tri_f32 = value != 0;   // both forms are within the 1e-4 tolerance; they differ in the last float32 bits of XYZ
-    else if (!strcmp(name, "cam_poly")) ctx->tune_cam_poly = value != 0;
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG
     else if (!strcmp(name, "fuse_abl")) ctx->tune_fuse_abl = value;
@@ -998,15 +993,6 @@ extern "C" int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (rows < 0 || W < 0 || proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad band / projector size");
     return ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
-}
-
-extern "C" int slgc_cam_poly_info(slgc_ctx *ctx, int *tile, double *max_abs_err, int *in_use)
-{
-    if (!ctx || !tile || !max_abs_err || !in_use) return SLGC_EINVAL;
-    *tile = ctx->cam_poly_shift ? (1 << ctx->cam_poly_shift) : 0;
-    *max_abs_err = (double)ctx->cam_poly_err;
-    *in_use = (ctx->cam_poly_shift != 0 && ctx->tune_cam_poly) ? 1 : 0;
-    return SLGC_OK;
 }
 
 extern "C" int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,

@@ -242,7 +242,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
-    CamPolyRef cp;            // cp.tiles != nullptr: camera rays from the tile polynomials instead of cam_lut (tri_math.h)
+    TriF32 kf;                // T and |T|^2 in float32 for the fast form
     double T[3], t_len;
 };
 
@@ -363,9 +363,6 @@ struct FrameSpec {
     static constexpr Table table = make();
 };
 
-#ifndef SLGC_FUSED_TRI_F32
-#define SLGC_FUSED_TRI_F32 0
-#endif
 #ifndef SLGC_PARK_DEPTH
 #define SLGC_PARK_DEPTH 2      // steps of frame loads in flight ahead of the step being classified (specialised kernels)
 #endif
@@ -585,14 +582,11 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         };
         const bool live = off < a.npix;
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        const bool poly = a.f.cp.tiles != nullptr;          // camera rays from the tile polynomials (evaluated after the exchange: 16 fewer live registers across it)
         float4 c01 = make_float4(0.f, 0.f, 0.f, 0.f), c23 = c01;
         if (live) {
-            if (!poly) {                                     // exact table: request the rays now, they land during the exchange
-                const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
-                c01 = cl[0];
-                c23 = cl[1];
-            }
+            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));     // requested now, lands during the exchange
+            c01 = cl[0];
+            c23 = cl[1];
             const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -629,15 +623,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
-#if SLGC_FUSED_TRI_F32        // build-time A/B (make variant EXTRA=-DSLGC_FUSED_TRI_F32=1): the float32 cross-product form in the fused tail
         const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
-        const TriF32 kf{(float)a.f.T[0], (float)a.f.T[1], (float)a.f.T[2], (float)(a.f.t_len * a.f.t_len)};
-        triangulate4_f32<ABL != 8>(fx, fy, px, py, valid, kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
-#else
-        double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
-        if (poly && live) cam_rays4_poly(a.f.cp, off, cx, cy);
-        triangulate4<ABL != 8>(cx, cy, px, py, valid, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);       // ABL 8: unguarded fast form (A/B)
-#endif
+        triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
@@ -960,7 +947,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
     b.f.nt_store = ctx->tune_fuse_nt;
     b.f.wave_tail = ctx->tune_fuse_tail;
-    fill_cam_poly(ctx, &b.f.cp, true);
+    b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

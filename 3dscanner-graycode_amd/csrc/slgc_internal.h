@@ -55,8 +55,6 @@ struct slgc_ctx {
     int tune_fuse_nt;       // fused scan: bit 0 XYZ, bit 1 maps leave with non-temporal stores
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
-    int tune_cam_poly;      // 1 = camera rays from the tile polynomials when their build-time error check passed, 0 = exact 8 B/pixel table
-    int tune_tri_f32;       // dense / fused triangulation: 1 = float32 cross-product form, 0 = float64 form
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
@@ -72,10 +70,6 @@ struct slgc_ctx {
     void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
     unsigned lut_cam_ver, lut_proj_ver;
     int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h, lut_proj_tile;
-    // camera-ray tile polynomials (tri_math.h CamPolyTile), fitted with the exact table; usable iff cam_poly_shift > 0
-    void *lut_cam_poly;
-    int cam_poly_shift, cam_poly_tiles_x;
-    float cam_poly_err;     // max |ray_poly - ray_exact_float32| over the band measured at build time (of the accepted tile size, else of the last tried)
     // results kept on the device between *_count and *_fetch
     int64_t pend_M;
     size_t pend_npix;
@@ -135,8 +129,6 @@ inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz);
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
-struct CamPolyRef;
-void fill_cam_poly(const slgc_ctx *ctx, CamPolyRef *cp, bool allow);     // cp->tiles = nullptr when the polynomial table is off / rejected / not allowed
 int launch_widen_maps(slgc_ctx *ctx, const int16_t *d_h16, const int16_t *d_v16, size_t npix, int64_t *d_h, int64_t *d_v);
 // correspond.hip
 int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,

@@ -204,90 +204,8 @@ __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *_
 struct TriConst {
     double T[3];
     double t_len;
-    CamPolyRef cp;           // cp.tiles == nullptr: camera rays from the exact table
-    int tri_f32;             // 1: float32 cross-product form (tri_math.h triangulate4_f32)
-    TriF32 kf;
+    TriF32 kf;               // T and |T|^2 in float32 for the fast form (tri_math.h)
 };
-
-// Fit one tile of the camera-ray polynomial table (tri_math.h) and measure its error.  One workgroup of TS*TS threads per tile;
-// thread (i, j) owns pixel (tx*TS + i, ty*TS + j) of the band -- pixels past the image edge are evaluated too (undistortPoints is
-// defined everywhere), so every tile is fitted over the full TS x TS pattern and one inverse Gram matrix serves all of them.
-struct FitArgs {
-    double ginv[kCamPolyTerms * kCamPolyTerms];          // inverse Gram matrix of the ten basis terms over the centred TS x TS grid
-};
-
-template <int TS>
-__global__ void __launch_bounds__(TS * TS) k_fit_cam_poly(const Calib c, const FitArgs fa, CamPolyTile *__restrict__ tiles, int tiles_x, int W,
-                                                          int rows, int row0, unsigned *__restrict__ max_err_bits)
-{
-    constexpr int NT_ = TS * TS, NWAVE = (NT_ + 63) / 64, NK = kCamPolyTerms;
-    __shared__ double s_m[NWAVE][2 * NK];
-    __shared__ double s_coef[2 * NK];
-    __shared__ float s_err[NWAVE];
-    const int i = threadIdx.x % TS, j = threadIdx.x / TS;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * TS + i, yl = ty * TS + j;
-    double xu, yu;
-    undistort_xy((float)x, (float)(row0 + yl), c.cam_k, c.cam_d, xu, yu);
-    const double dx = (double)(i - TS / 2), dy = (double)(j - TS / 2);
-    const double px[4] = {1.0, dx, dx * dx, dx * dx * dx}, py[4] = {1.0, dy, dy * dy, dy * dy * dy};
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const double b = px[cam_poly_pow_x(k)] * py[cam_poly_pow_y(k)];
-        double vx = b * xu, vy = b * yu;
-        for (int o = 32; o > 0; o >>= 1) {
-            vx += __shfl_down(vx, o, 64);
-            vy += __shfl_down(vy, o, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            s_m[threadIdx.x >> 6][k] = vx;
-            s_m[threadIdx.x >> 6][NK + k] = vy;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * NK) {
-        const int comp = threadIdx.x / NK, k = threadIdx.x % NK;
-        double acc = 0.0;
-        for (int l = 0; l < NK; ++l) {
-            double ml = 0.0;
-            for (int w = 0; w < NWAVE; ++w) ml += s_m[w][comp * NK + l];
-            acc += fa.ginv[k * NK + l] * ml;
-        }
-        s_coef[threadIdx.x] = acc;
-    }
-    __syncthreads();
-    CamPolyTile t;
-    t.c0x = s_coef[0];
-    t.c0y = s_coef[NK];
-#pragma unroll
-    for (int k = 0; k < NK - 1; ++k) {
-        t.cx[k] = (float)s_coef[1 + k];
-        t.cy[k] = (float)s_coef[NK + 1 + k];
-    }
-    t.pad[0] = t.pad[1] = 0.f;
-    if (threadIdx.x == 0) tiles[blockIdx.x] = t;
-    // fit error: the ray a kernel will compute from this tile (float32-rounded higher terms, as stored) against the exact ray
-    float err = 0.f;
-    if (x < W && yl < rows) {
-        double ax[4], ay[4], rx, ry;
-        cam_poly_row(t.c0x, t.cx, dy, ax);
-        cam_poly_row(t.c0y, t.cy, dy, ay);
-        cam_poly_ray(ax, ay, dx, c.R, rx, ry);
-        // the exact ray before its float32 rounding: the same arithmetic as undistort_point on the exact undistorted point
-        const double xx = c.R[0] * xu + c.R[1] * yu + c.R[2], yy = c.R[3] * xu + c.R[4] * yu + c.R[5];
-        const double ww = 1. / (c.R[6] * xu + c.R[7] * yu + c.R[8]);
-        const double e = fmax(fabs(rx - xx * ww), fabs(ry - yy * ww));
-        err = (e == e) ? (float)e : __builtin_huge_valf();                    // NaN (non-finite rays) -> reject the table
-    }
-    for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
-    if ((threadIdx.x & 63) == 0) s_err[threadIdx.x >> 6] = err;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float e = s_err[0];
-        for (int w = 1; w < NWAVE; ++w) e = fmaxf(e, s_err[w]);
-        atomicMax(max_err_bits, __float_as_uint(e));                          // non-negative floats order like their bit patterns
-    }
-}
 
 // Dense kernel.  Four pixels per lane (8-byte map loads, 32-byte ray loads).  The per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
 // each projector-table gather instruction touch ~50 cache lines and each XYZ store instruction a 48-byte-strided
@@ -312,7 +230,6 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const size_t g = (size_t)bid * 256 + tid;
     const bool live = g < ngroups;
     uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    const bool poly = tc.cp.tiles != nullptr;
     float4 c01 = make_float4(0.f, 0.f, 0.f, 0.f), c23 = c01;
     if (live) {
         uint2 hw, vw;
@@ -324,10 +241,8 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             hw = reinterpret_cast<const uint2 *>(h)[g];
             vw = reinterpret_cast<const uint2 *>(v)[g];
         }
-        if (!poly) {
-            c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g];
-            c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
-        }
+        c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g];
+        c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
         const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -356,23 +271,19 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                            (idx[3] != 0xffffffffu ? 8u : 0u);
     const unsigned nvalid = __builtin_popcount(valid);
-    double cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
-    if (poly && live) cam_rays4_poly(tc.cp, (uint32_t)(4 * g), cx, cy);
+    const float cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
     if constexpr (MODE == SLGC_TRI_EXACT) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float X = __builtin_nanf(""), Y = X, Z = X;
             if ((valid >> j) & 1u) {
-                const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{(float)cx[j], (float)cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
+                const Xyz r = law_of_sines<SLGC_TRI_EXACT>(Ray2{cx[j], cy[j]}, Ray2{px[j], py[j]}, tc.T, tc.t_len);
                 X = (float)r.x; Y = (float)r.y; Z = (float)r.z;
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
-    } else if (tc.tri_f32 && !poly) {
-        const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
-        triangulate4_f32<MODE != 2>(fx, fy, px, py, valid, tc.kf, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);
     } else {
-        triangulate4<MODE != 2>(cx, cy, px, py, valid, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);      // MODE 2: unguarded fast form (A/B)
+        triangulate4<MODE != 2>(cx, cy, px, py, valid, tc.kf, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);      // MODE 2: unguarded (A/B, diagnostic build)
     }
     s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
     s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
@@ -419,12 +330,7 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
         if (!(hv == -1 || vv == -1)) {
             ok = 1;
             const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
-            if (tc.tri_f32) {                       // the float32 form's own test, through the same function the scans run
-                const float fx[4] = {c.x, 0.f, 0.f, 0.f}, fy[4] = {c.y, 0.f, 0.f, 0.f}, gx[4] = {q.x, 0.f, 0.f, 0.f}, gy[4] = {q.y, 0.f, 0.f, 0.f};
-                flat = tri_f32_is_flat(fx[0], fy[0], gx[0], gy[0], tc.kf) ? 1u : 0u;
-            } else {
-                flat = tri_is_flat(tri_terms(c.x, c.y, q.x, q.y, tc.T, tc.t_len * tc.t_len)) ? 1u : 0u;
-            }
+            flat = tri_is_flat(c.x, c.y, q.x, q.y, tc.kf) ? 1u : 0u;
         }
     }
     unsigned packed = ok | (flat << 16);                       // 64 lanes: both sums fit 16 bits
@@ -455,8 +361,6 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     TriConst tc;
     memcpy(tc.T, ctx->calib.T, sizeof tc.T);
     tc.t_len = ctx->calib.t_len;
-    fill_cam_poly(ctx, &tc.cp, false);
-    tc.tri_f32 = ctx->tune_tri_f32;
     tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
                        (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
@@ -476,89 +380,6 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
     return SLGC_OK;
 }
 
-// Inverse Gram matrix of the ten bicubic basis terms over the centred TS x TS grid (dx, dy = -TS/2 .. TS/2 - 1): Gauss-Jordan, float64.
-static void gram_inverse(int ts, double (&ginv)[kCamPolyTerms * kCamPolyTerms])
-{
-    constexpr int n = kCamPolyTerms;
-    double a[n][2 * n] = {};
-    for (int j = 0; j < ts; ++j)
-        for (int i = 0; i < ts; ++i) {
-            const double dx = i - ts / 2, dy = j - ts / 2;
-            double b[n];
-            for (int k = 0; k < n; ++k) b[k] = pow(dx, cam_poly_pow_x(k)) * pow(dy, cam_poly_pow_y(k));
-            for (int r = 0; r < n; ++r)
-                for (int c = 0; c < n; ++c) a[r][c] += b[r] * b[c];
-        }
-    for (int r = 0; r < n; ++r) a[r][n + r] = 1.0;
-    for (int p = 0; p < n; ++p) {
-        int best = p;
-        for (int r = p + 1; r < n; ++r)
-            if (fabs(a[r][p]) > fabs(a[best][p])) best = r;
-        for (int c = 0; c < 2 * n; ++c) { const double t = a[p][c]; a[p][c] = a[best][c]; a[best][c] = t; }
-        const double inv = 1.0 / a[p][p];
-        for (int c = 0; c < 2 * n; ++c) a[p][c] *= inv;
-        for (int r = 0; r < n; ++r)
-            if (r != p) {
-                const double f = a[r][p];
-                for (int c = 0; c < 2 * n; ++c) a[r][c] -= f * a[p][c];
-            }
-    }
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n; ++c) ginv[r * n + c] = a[r][n + c];
-}
-
-// Camera-ray tile polynomials for the band: 16 x 16 tiles first, 8 x 8 if their measured error is over kCamPolyTol, none if that
-// fails too (strong distortion: the exact table stays in use).  One-off per calibration / band; synchronises once to read the error.
-static int build_cam_poly(slgc_ctx *ctx, int rows, int W, int row0)
-{
-    if (ctx->lut_cam_poly) {
-        HIP_TRY(ctx, hipFree(ctx->lut_cam_poly));
-        ctx->lut_cam_poly = nullptr;
-    }
-    ctx->cam_poly_shift = 0;
-    ctx->cam_poly_err = -1.f;
-    if (rows <= 0 || W <= 0 || W % 4 != 0) return SLGC_OK;          // lanes own 4 consecutive pixels of one row
-    void *d_err;
-    int rc = slgc_ws(ctx, 7, 64, &d_err);
-    if (rc) return rc;
-    const int tx8 = (W + 7) / 8, ty8 = (rows + 7) / 8;
-    if (hipMalloc(&ctx->lut_cam_poly, (size_t)tx8 * ty8 * sizeof(CamPolyTile) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera ray polynomials");
-    for (int shift = 4; shift >= 3; --shift) {
-        const int ts = 1 << shift, tiles_x = (W + ts - 1) / ts, tiles_y = (rows + ts - 1) / ts;
-        FitArgs fa;
-        gram_inverse(ts, fa.ginv);
-        HIP_TRY(ctx, hipMemsetAsync(d_err, 0, 4, ctx->stream));
-        if (shift == 4)
-            hipLaunchKernelGGL(k_fit_cam_poly<16>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, ctx->stream, ctx->calib, fa,
-                               (CamPolyTile *)ctx->lut_cam_poly, tiles_x, W, rows, row0, (unsigned *)d_err);
-        else
-            hipLaunchKernelGGL(k_fit_cam_poly<8>, dim3((unsigned)(tiles_x * tiles_y)), dim3(64), 0, ctx->stream, ctx->calib, fa,
-                               (CamPolyTile *)ctx->lut_cam_poly, tiles_x, W, rows, row0, (unsigned *)d_err);
-        HIP_TRY(ctx, hipGetLastError());
-        float err = 0.f;
-        HIP_TRY(ctx, hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->cam_poly_err = err;
-        if (err <= (float)kCamPolyTol) {
-            ctx->cam_poly_shift = shift;
-            ctx->cam_poly_tiles_x = tiles_x;
-            return SLGC_OK;
-        }
-    }
-    return SLGC_OK;          // rejected at both tile sizes: exact table only
-}
-
-void fill_cam_poly(const slgc_ctx *ctx, CamPolyRef *cp, bool allow)
-{
-    memset(cp, 0, sizeof *cp);
-    if (!allow || !ctx->tune_cam_poly || ctx->cam_poly_shift == 0 || !ctx->lut_cam_poly) return;
-    cp->tiles = (const CamPolyTile *)ctx->lut_cam_poly;
-    cp->tiles_x = ctx->cam_poly_tiles_x;
-    cp->shift = ctx->cam_poly_shift;
-    cp->W = ctx->lut_cam_W;
-    memcpy(cp->R, ctx->calib.R, sizeof cp->R);
-}
-
 // Build (or reuse) the ray tables for this calibration / geometry.
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
 {
@@ -576,8 +397,6 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
                            row0, npix);
         HIP_TRY(ctx, hipGetLastError());
         ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
-        int rc = build_cam_poly(ctx, rows, W, row0);
-        if (rc) return rc;
     }
     if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h && ctx->lut_proj_tile == wide)) {
         if (ctx->lut_proj) {
@@ -638,8 +457,6 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         TriConst tc;
         memcpy(tc.T, ctx->calib.T, sizeof tc.T);
         tc.t_len = ctx->calib.t_len;
-        fill_cam_poly(ctx, &tc.cp, mode != SLGC_TRI_EXACT);          // the acos / sin parity mode always reads the exact float32 rays
-        tc.tri_f32 = ctx->tune_tri_f32;
         tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);

@@ -81,7 +81,6 @@ SIGNATURES = {
     "slgc_prof_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "slgc_prof_samples": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "slgc_build_ray_tables_dev": (_i, [_vp, _i, _i, _i, _i, _i]),
-    "slgc_cam_poly_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_d), C.POINTER(_i)]),
     "slgc_guard_count_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "slgc_comm_unique_id": (_i, [_vp]),
     "slgc_comm_init": (_i, [_vp, _i, _i, _vp]),
@@ -540,12 +539,6 @@ class Context:
     def build_ray_tables_dev(self, rows, W, row0, proj_size):
         """Per-calibration ray tables of the dense path (asynchronous); built on first use otherwise."""
         self._ck(lib().slgc_build_ray_tables_dev(self._h, int(rows), int(W), int(row0), int(proj_size[0]), int(proj_size[1])))
-
-    def cam_poly_info(self):
-        """-> (tile size 16 / 8 / 0 = rejected, max |ray_poly - ray_exact| measured at build time, in use) of the camera-ray polynomials."""
-        t, e, u = C.c_int(), C.c_double(), C.c_int()
-        self._ck(lib().slgc_cam_poly_info(self._h, C.byref(t), C.byref(e), C.byref(u)))
-        return t.value, e.value, bool(u.value)
 
     def guard_count_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_counts: int):
         """d_counts[0] += decodable pixels, d_counts[1] += pixels on the guarded (float32-mirror) triangulation path."""

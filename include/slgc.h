@@ -62,16 +62,13 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
-/* Tuning knobs for same-process A/B timing; no setting changes the maps, and XYZ only within the tolerance ("tri_f32", "cam_poly").  "fuse_tail" 1 = wave-local LDS exchange in the fused
+/* Tuning knobs for same-process A/B timing; no setting changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
- * "tri_f32" 1 = float32 cross-product form in the DENSE triangulation kernel / 0 = float64 form (default; both inside the 1e-4
- * tolerance, they differ in the last float32 bits of XYZ and in which pixels take the guarded path); "cam_poly" 1 = camera rays from the tile polynomials when their error check passed / 0 = exact table (default:
- * the polynomials remove 98 MB of table traffic per 4096x3000 scan but their float64 evaluation costs more than the stream saves);
- * "park" 1 = at 42 / 44 / 46 frames
- * the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) / 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte
- * wire format / 0 = int16 (default; experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3); "tri_nt" (1); "xcd" XCD-aware tile map of the dense
- * triangulation kernel (1).  Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT,
- * SLGC_XCD, SLGC_TRI_F32, SLGC_CAM_POLY), read when the context is created. */
+ * "park" 1 = at 42 / 44 / 46 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
+ * 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte wire format / 0 = int16 (default;
+ * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3);
+ * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1).  Defaults can also be set with the environment
+ * (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD), read when the context is created. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
@@ -205,14 +202,6 @@ int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *
  * into two ray tables.  slgc_scan_dev / slgc_triangulate_maps_dev build them on first use; this entry point builds them
  * explicitly (asynchronous, on the context's stream) so that a caller -- and bench.py -- can place and time that one-off cost. */
 int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
-
-/* The camera-ray table of the dense path has two forms: the exact one (float32 [rows][W][2], 8 B/pixel, streamed by every scan) and
- * per-tile bicubics of the undistorted point (96 B per 16x16 or 8x8 pixel tile) from which the kernels evaluate
- * rotation + perspective divide per pixel in float64.  The polynomials are fitted when the tables are built and accepted only if
- * the fit error max |ray_poly - ray_exact| (exact ray before its float32 rounding) over the band is <= 1e-8; the guarded slow path and
- * SLGC_TRI_EXACT always read the exact table.  After the tables exist: *tile = 16, 8 or 0
- * (rejected: exact table only), *max_abs_err = the measured error, *in_use = 1 if the scans use the polynomials ("cam_poly" knob). */
-int slgc_cam_poly_info(slgc_ctx *ctx, int *tile, double *max_abs_err, int *in_use);
 
 /* Diagnostic: d_counts[0] += decodable pixels of the band, d_counts[1] += those among them that the dense triangulation redoes
  * on the reference's float32 intermediates because the triangle is flat (tri_is_flat, csrc/tri_math.h) -- the guarded slow path. */

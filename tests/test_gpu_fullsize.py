@@ -37,9 +37,9 @@ def oracle_threads():
     oc.set_threads(1)
 
 
-def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T, amp=170.0):
-    """NumPy twin of tri_is_flat / tri_f32_flat (csrc/tri_math.h; amp = kGuardAmp 170 for the float64 form, kGuardAmpF32 60 for the
-    float32 form) on the oracle's float32 rays: which decodable pixels take the guarded path."""
+def flat_mask_np(h, v, proj_size, K, cd, pk, pd, R, T, amp=60.0):
+    """NumPy twin of tri_is_flat (csrc/tri_math.h, amp = kGuardAmp) on the oracle's float32 rays: which decodable pixels take the
+    guarded path."""
     H, W = h.shape
     ok = (h != -1) & (v != -1)
     yy, xx = np.nonzero(ok)
@@ -107,26 +107,16 @@ def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
     # (3) the exact (acos / sin) dense kernel on the same maps
     _, worst_exact = compare_scan(*run(_native.TRI_EXACT), ref_h, ref_v, ref_xyz, workload + " exact")
     assert worst_exact < 1e-6
-    # guard path: how many pixels the fused / dense kernels redo on the reference's float32 intermediates, under both forms of the fast path
-    flagged = {}
-    try:
-        for knob, amp in ((1, 60.0), (0, 170.0)):
-            ctx.tune("tri_f32", knob)
-            cnt.zero()
-            ctx.guard_count_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), cnt.ptr)
-            ctx.synchronize()
-            n_ok, n_flat = (int(x) for x in cnt.download((2,), np.uint64))
-            assert n_ok == valid
-            n_ref = int(flat_mask_np(ref_h, ref_v, (pw, ph), *calib, amp=amp).sum())
-            assert abs(n_flat - n_ref) <= 2 + n_ref // 500      # same test on the same rays; float32 / fast_sqrt rounding moves pixels sitting on the threshold
-            flagged[knob] = n_flat
-            _, worst = compare_scan(*run(_native.TRI_ALGEBRAIC), ref_h, ref_v, ref_xyz, f"{workload} fused tri_f32={knob}")
-            flagged[f"worst{knob}"] = worst
-    finally:
-        ctx.tune("tri_f32", 0)
-    print(f"\n{workload}: {valid} / {px} decodable; guarded path: float32 form {flagged[1]} px ({100.0 * flagged[1] / max(valid, 1):.3f} %), float64 form "
-          f"{flagged[0]} px; worst rel. XYZ error fused {worst_fused:.2e} (f32 {flagged['worst1']:.2e}, f64 {flagged['worst0']:.2e}) split {worst_split:.2e} "
-          f"exact {worst_exact:.2e}")
+    # guard path: how many pixels the fused / dense kernels redo on the reference's float32 intermediates
+    cnt.zero()
+    ctx.guard_count_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), cnt.ptr)
+    ctx.synchronize()
+    n_ok, n_flat = (int(x) for x in cnt.download((2,), np.uint64))
+    assert n_ok == valid
+    n_ref = int(flat_mask_np(ref_h, ref_v, (pw, ph), *calib).sum())
+    assert abs(n_flat - n_ref) <= 2 + n_ref // 500          # same test on the same rays; float32 rounding moves pixels sitting on the threshold
+    print(f"\n{workload}: {valid} / {px} decodable, {n_flat} on the guarded path ({100.0 * n_flat / max(valid, 1):.3f} %), worst rel. XYZ error "
+          f"fused {worst_fused:.2e} split {worst_split:.2e} exact {worst_exact:.2e}")
     for b in (stack, maps, xyz, cnt):
         b.free()
 
@@ -226,63 +216,3 @@ def test_device_resident_reference_product(ctx, workload):
         b.free()
     lists.free()
     bare.free()
-
-
-@pytest.mark.parametrize("which", ["c3", "c2", "cam_1440"])
-def test_camera_ray_polynomials_error_check(ctx, which):
-    """The 96-byte-per-tile camera-ray bicubics that can replace the 8 B/pixel table in the scans (slgc_tune "cam_poly", off by
-    default): accepted only when the build-time check measures a fit error max |ray_poly - ray_exact| <= 1e-8 over the image.  With
-    the knob on, the maps stay bit-identical and every point stays within 1e-4 of the oracle's RELATIVE TO THE POINT (an additive
-    1e-9 on a ray component is unbounded relative to a component that crosses zero, which the exact-table path never has to face: its
-    rays are the reference's own float32 values); with the knob off the elementwise criterion holds.  The strongly distorted
-    cam_1440 model (bail-out corners) must be REJECTED -> exact table."""
-    from scanner import _native
-    from scanner import reference_calibration as rc
-    if which == "cam_1440":
-        W, H, pw, ph, N = 2560, 1440, 1920, 1080, 44
-        _, _, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
-        calib = (rc.CAM1440_MTX, rc.CAM1440_DIST, pk, pd, R, T)
-    else:
-        W, H, pw, ph, N = bench.WORKLOADS["c3_4096x3000x44" if which == "c3" else "c2_1920x1080x44"]
-        calib = bench.calibration(W, H, pw, ph)
-    ctx.set_calibration(*calib)
-    px = W * H
-    stack = ctx.alloc(N * px)
-    ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=4, noise=3, shadow=True)
-    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
-    st = stack.download((N, H, W), np.uint8)
-    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
-    ref = np.moveaxis(ref_xyz, 0, -1)
-    ok = (ref_h != -1) & (ref_v != -1) & np.isfinite(ref).all(axis=2)
-    worst = {}
-    try:
-        for knob in (1, 0):
-            ctx.tune("cam_poly", knob)
-            ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
-            ctx.synchronize()
-            tile, err, in_use = ctx.cam_poly_info()
-            if knob:
-                print(f"\n{which}: tile {tile}, fit error max |ray_poly - ray_exact| {err:.3e}, in use {in_use}")
-                if which == "cam_1440":
-                    assert tile == 0 and not in_use and err > 1e-8
-                else:
-                    assert tile in (8, 16) and in_use and 0 <= err <= 1e-8
-            else:
-                assert not in_use
-            for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT):
-                ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
-                ctx.synchronize()
-                gh, gv, gx = maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32)
-                if knob and in_use:
-                    assert np.array_equal(gh, ref_h) and np.array_equal(gv, ref_v)
-                    assert np.array_equal(np.isfinite(gx).all(axis=2), ok)
-                    d = np.abs(gx[ok].astype(np.float64) - ref[ok]).max(axis=1) / np.linalg.norm(ref[ok], axis=1)
-                    worst[(knob, mode)] = float(d.max())
-                    assert worst[(knob, mode)] <= XYZ_RTOL
-                else:
-                    _, worst[(knob, mode)] = compare_scan(gh, gv, gx, ref_h, ref_v, ref_xyz, f"{which} cam_poly={knob} mode={mode}")
-    finally:
-        ctx.tune("cam_poly", 0)
-    print("   worst error (knob, mode):", {k: f"{v:.2e}" for k, v in worst.items()})
-    for b in (stack, maps, xyz):
-        b.free()
