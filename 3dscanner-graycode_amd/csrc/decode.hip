@@ -394,6 +394,20 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     for (int r = 0; r < a.g.n_runs; ++r) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[r], 0, a.run_bytes, 0x00020000);
         uint32_t KA[NP], KB[NP], C1[NP], C2[NP];      // C1 / C2 hold K1 / K2 of pack_pair_consts
+        // specialised kernels: DEPTH steps of frame loads stay in flight ahead of the step being classified
+        constexpr int DEPTH = SLGC_PARK_DEPTH;
+        Frame<NW, NT> ring[SPEC ? DEPTH + 1 : 1][4];
+        auto fetch = [&](int f) {                   // f is a constant once the loop is unrolled: the choice below folds away
+            Frame<NW, NT> fr;
+            const int slot = FS::table.slot[f];
+            if (slot >= 0) fr.w[0] = park[slot * 64];
+            else fr = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
+            return fr;
+        };
+        auto fetch_step = [&](int t, Frame<NW, NT> (&fr)[4]) {
+            const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
+            fr[0] = fetch(f_hn); fr[1] = fetch(f_hn + 2 * FS::L); fr[2] = fetch(f_vn); fr[3] = fetch(f_vn + 2 * FS::L);
+        };
         if constexpr (ABL == 1 || ABL == 2) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
@@ -416,6 +430,12 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
                 // stores to those loads, i.e. keep all 12 frames in registers (the variant that loses two waves per SIMD): an opaque
                 // point between the stores and the loads stops that
                 asm volatile("" ::: "memory");
+                // the first DEPTH steps of the bit loop are requested NOW, before the float64 threshold arithmetic (~600 cycles per wave):
+                // their latency runs under it instead of after it
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d)
+                    if (d < FS::L) fetch_step(d, ring[d]);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
@@ -467,24 +487,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
             }
         };
         if constexpr (SPEC) {
-            auto fetch = [&](int f) {                   // f is a constant once the loop is unrolled: the choice below folds away
-                Frame<NW, NT> fr;
-                const int slot = FS::table.slot[f];
-                if (slot >= 0) fr.w[0] = park[slot * 64];
-                else fr = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
-                return fr;
-            };
-            // DEPTH steps ahead: the four frames of step t+DEPTH are requested before step t is classified; the scheduling barrier keeps
-            // the unrolled steps from being hoisted on top of each other (unbounded, that costs 270 registers and all but one wave per SIMD)
-            constexpr int DEPTH = SLGC_PARK_DEPTH;
-            Frame<NW, NT> ring[DEPTH + 1][4];
-            auto fetch_step = [&](int t, Frame<NW, NT> (&fr)[4]) {
-                const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
-                fr[0] = fetch(f_hn); fr[1] = fetch(f_hn + 2 * FS::L); fr[2] = fetch(f_vn); fr[3] = fetch(f_vn + 2 * FS::L);
-            };
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d)
-                if (d < FS::L) fetch_step(d, ring[d]);
+            // the scheduling barrier keeps the unrolled steps from being hoisted on top of each other (unbounded, that costs 270 registers and
+            // all but one wave per SIMD)
 #pragma unroll
             for (int t = 0; t < FS::L; ++t) {
                 if (t + DEPTH < FS::L) fetch_step(t + DEPTH, ring[(t + DEPTH) % (DEPTH + 1)]);
