@@ -226,14 +226,16 @@ def digest64(*arrays):
     return int.from_bytes(h.digest(), "little") >> 1          # 63 bits: travels through the int64 all-gather unchanged
 
 
+SCAN_SOURCES = ("api.hip", "decode.hip", "slgc_internal.h", "tri_math.h", "triangulate.hip")   # what the scan kernels and their launch defaults compile from
+
+
 def csrc_fingerprint():
-    """Hash of the kernel sources: profiles/traffic.json carries the fingerprint it was measured on, a mismatch = stale counters."""
+    """Hash of the scan kernels' sources: profiles/traffic.json carries the fingerprint it was measured on, a mismatch = stale counters."""
     h = hashlib.blake2b(digest_size=8)
     d = os.path.join(ROOT, "3dscanner-graycode_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in SCAN_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()
 
 
