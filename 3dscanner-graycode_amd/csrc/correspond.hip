@@ -8,65 +8,117 @@
 // K2b  row-major stream compaction (wave64 ballot + mbcnt prefix) used for the row-major correspondence order,
 //      filter_3d_pts (triangulate.py:99-122) and the dense-XYZ -> point-list step of the multi-GPU path.
 #include "slgc_internal.h"
+#include "tri_math.h"
 
 namespace {
 
 constexpr int kChunkRows = 32;
 
+// Diagnostic build only (make diag): SLGC_LISTS_ABL = bit mask of timing-only ablations of the x-major scatter kernel (wrong results):
+// 1 no cam / proj stores, 2 no point stores, 4 no colour stores, 8 no XYZ loads, 16 no white loads, 32 records written tile after tile.
+#ifdef SLGC_DIAG
+#define LISTS_ABL(bit) ((abl & (bit)) != 0)
+inline int lists_abl()
+{
+    const char *e = getenv("SLGC_LISTS_ABL");
+    return e ? atoi(e) : 0;
+}
+#else
+#define LISTS_ABL(bit) false
+inline int lists_abl() { return 0; }
+#endif
+
 __device__ __forceinline__ bool decodable(int64_t h, int64_t v) { return !(h == -1 || v == -1); }  // :56
 
 // ---- x-major: pass A, per (chunk, column) counts ----
+// A workgroup = 64 columns x one chunk of 32 rows; its 4 waves take 8 rows each with every load issued before the first use (one
+// memory round trip per workgroup), and meet in LDS.
 template <typename MapT>
 __global__ void __launch_bounds__(256) k_xmajor_count(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H,
                                                       unsigned *__restrict__ counts)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int chunk = blockIdx.y;
-    if (x >= W) return;
-    const int y0 = chunk * kChunkRows, y1 = min(H, y0 + kChunkRows);
+    __shared__ unsigned part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, chunk = blockIdx.y;
+    const int y0 = chunk * kChunkRows + wave * (kChunkRows / 4);
+    const int xc = min(x, W - 1);                      // every load unconditional on a clamped address, masked afterwards:
+    MapT hv[kChunkRows / 4], vv[kChunkRows / 4];       // the 16 loads of a lane are in flight together
+#pragma unroll
+    for (int i = 0; i < kChunkRows / 4; ++i) {
+        const size_t p = (size_t)min(y0 + i, H - 1) * W + xc;
+        hv[i] = h[p];
+        vv[i] = v[p];
+    }
     unsigned c = 0;
-    for (int y = y0; y < y1; ++y) c += decodable(h[(size_t)y * W + x], v[(size_t)y * W + x]) ? 1u : 0u;
-    counts[(size_t)chunk * W + x] = c;
+#pragma unroll
+    for (int i = 0; i < kChunkRows / 4; ++i) c += (x < W && y0 + i < H && decodable(hv[i], vv[i])) ? 1u : 0u;
+    part[wave][lane] = c;
+    __syncthreads();
+    if (wave == 0 && x < W) counts[(size_t)chunk * W + x] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
-// ---- x-major: pass B1, one thread per column: prefix over the row chunks (lanes along x: coalesced), column totals ----
-__global__ void __launch_bounds__(256) k_xmajor_colprefix(unsigned *__restrict__ counts, int W, int nchunks,
-                                                          unsigned long long *__restrict__ colstart)
+// ---- x-major: pass B1, prefix over the row chunks of each column + column totals ----
+// A workgroup = 64 columns x 16 groups of consecutive chunks (lanes along x: coalesced).  Every thread sums its group, the groups meet in
+// LDS, then every thread rewrites its group's counts as "valid pixels above this chunk in column x".
+constexpr int kPrefixGroups = 16;
+__global__ void __launch_bounds__(64 * kPrefixGroups) k_xmajor_colprefix(unsigned *__restrict__ counts, int W, int nchunks,
+                                                                         unsigned long long *__restrict__ colstart)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    unsigned run = 0;
+    __shared__ unsigned part[kPrefixGroups][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int per = (nchunks + kPrefixGroups - 1) / kPrefixGroups;
+    const int c0 = min(nchunks, g * per), c1 = min(nchunks, c0 + per);
+    unsigned sum = 0;
+    if (x < W) {
 #pragma unroll 8
-    for (int c = 0; c < nchunks; ++c) {
+        for (int c = c0; c < c1; ++c) sum += counts[(size_t)c * W + x];
+    }
+    part[g][lane] = sum;
+    __syncthreads();
+    unsigned run = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kPrefixGroups; ++i) {
+        const unsigned n = part[i][lane];
+        run += i < g ? n : 0u;
+        all += n;
+    }
+    if (x >= W) return;
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
         const unsigned n = counts[(size_t)c * W + x];
         counts[(size_t)c * W + x] = run;  // valid pixels above this chunk in column x
         run += n;
     }
-    colstart[x] = run;  // column total for now
+    if (g == 0) colstart[x] = all;  // column total for now
 }
 
 // ---- x-major: pass B2, one workgroup: exclusive scan of the column totals ----
 __global__ void __launch_bounds__(1024) k_xmajor_colscan(int W, unsigned long long *__restrict__ colstart, unsigned long long *__restrict__ total)
 {
-    __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (W + 1023) / 1024;                 // each thread owns a contiguous slab of columns: the scan stays ordered
     const int x0 = min(W, t * per), x1 = min(W, x0 + per);
     unsigned long long mine = 0;
     for (int x = x0; x < x1; ++x) mine += colstart[x];
-    part[t] = mine;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long acc = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const unsigned long long n = part[i];
-            part[i] = acc;
-            acc += n;
-        }
-        *total = acc;
+    unsigned long long inc = mine;                     // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    unsigned long long acc = part[t];
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned long long n = wsum[w];
+        before += w < wave ? n : 0ull;
+        all += n;
+    }
+    if (t == 0) *total = all;
+    unsigned long long acc = before + inc - mine;
     for (int x = x0; x < x1; ++x) {
         const unsigned long long n = colstart[x];
         colstart[x] = acc;
@@ -75,77 +127,186 @@ __global__ void __launch_bounds__(1024) k_xmajor_colscan(int W, unsigned long lo
 }
 
 // ---- x-major: pass C, scatter through an LDS transpose ----
-// A workgroup owns a tile of kChunkRows (32) rows x 64 columns.  Phase 1 reads it with lanes along x (coalesced 512-byte rows
-// of the int64 maps) and parks the clamped projector coordinates (and the packed colour) in LDS.  Phase 2 turns the tile: a
-// half-wave takes one column, its 32 lanes are the 32 rows, a ballot gives every valid pixel its rank inside the column
-// segment, and the segment leaves as one contiguous run of records (x-major order = column after column, rows ascending).
-constexpr int kTileCols = 64;
+// A workgroup (512 threads) owns a tile of TC columns x TR = 2048 / TC rows (64 x 32).
+//   Phase 1 reads it with lanes along the row bytes of the tile -- 128 B of each int16 map, 768 B of XYZ, 192 B of the white image per row,
+//   every load unconditional (clamped addresses) and in flight before the first LDS store: one memory round trip per workgroup -- and
+//   parks the clamped projector coordinates, the dense XYZ and the colour bytes in LDS.
+//   Phase 2 turns the tile: a half-wave takes one column; its 32 lanes are the 32 rows of a segment, a ballot gives every valid pixel its
+//   rank inside the segment, and the segment leaves as contiguous runs of records (x-major order = column after column, rows ascending)
+//   -- the 24-byte colour records compacted and re-spread over the lanes with ds_permute / ds_bpermute so that every store instruction
+//   writes one contiguous run.
+// What bounds it (tools/ubench/write_patterns.hip): 69 % of the bytes are stores, a segment is ~26 records (208 B of
+// an 8-byte stream) starting on an arbitrary 8-byte boundary, and MI355X takes partially written 128-byte lines at 2.3 TB/s against 5.0
+// TB/s for aligned runs; neighbours arriving back to back from one wave are merged on the way (4.8 TB/s with one output stream), but with
+// the 8 interleaved streams of this product that drops to 3.6 TB/s -- which is where this kernel sits.  Taller tiles (TC = 32, 16, 8:
+// one half-wave writes 2, 4, 8 abutting segments of its column one after the other) measured the same or slower: the narrower rows
+// cost on the read side what the longer runs gain.
+#ifndef SLGC_SCATTER_TC
+#define SLGC_SCATTER_TC 64
+#endif
+constexpr int kScatterThreads = 512, kTilePixels = 2048, kSegRows = 32;
+constexpr unsigned kInvalidHV = 0xffffffffu;           // (pu, pv) = (-1, -1): pu = min(h, proj_w - 1) with h != -1 is never -1
 constexpr int kInvalid = (int)0x80000000;
+static_assert(kSegRows == kChunkRows, "segment bases come from the per-chunk column prefixes");
+
+// b / 255.0 exactly as the reference's float64 division rounds it (triangulate.py:64,:69), for b = 0..255: one refinement step on
+// b * (1 / 255) lands on the correctly rounded quotient for all 256 bytes (tests/test_abi_cpu.py checks the arithmetic exhaustively).
+__device__ __forceinline__ double unit_of_byte(unsigned b)
+{
+    constexpr double rcp = 1.0 / 255.0;
+    const double x = (double)b, q = x * rcp;
+    return __builtin_fma(__builtin_fma(-q, 255.0, x), rcp, q);
+}
 
 // XYZ = true (device-resident product, slgc_cloud_lists_dev): the dense float32 XYZ of the scan rides through the same transpose and
 // leaves as the reference's float64 (3,M) array (triangulate.py:95; M = *total, written by the column scan before this kernel runs).
-template <typename MapT, bool XYZ>
-__global__ void __launch_bounds__(256) k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H,
-                                                        int proj_w, int proj_h, const uint8_t *__restrict__ white,
-                                                        const unsigned *__restrict__ counts,
-                                                        const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
-                                                        float *__restrict__ proj, double *__restrict__ colors,
-                                                        const float *__restrict__ xyz, double *__restrict__ pts,
-                                                        const unsigned long long *__restrict__ total)
+template <typename MapT, bool XYZ, int TC>
+__global__ void __launch_bounds__(kScatterThreads, XYZ ? 6 : 4)
+k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H, int proj_w, int proj_h, const uint8_t *__restrict__ white,
+                 const unsigned *__restrict__ counts, const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
+                 float *__restrict__ proj, double *__restrict__ colors, const float *__restrict__ xyz, double *__restrict__ pts,
+                 const unsigned long long *__restrict__ total, int tiles_x, int abl)
 {
-    __shared__ int s_pu[kChunkRows][kTileCols + 1], s_pv[kChunkRows][kTileCols + 1];
-    __shared__ unsigned s_rgb[kChunkRows][kTileCols + 1];
-    __shared__ float s_xyz[XYZ ? 3 : 1][kChunkRows][kTileCols + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x_tile = blockIdx.x * kTileCols, chunk = blockIdx.y, y_tile = chunk * kChunkRows;
+    constexpr bool PACKED = sizeof(MapT) == 2;          // int16 maps: (pu, pv) share a dword; int64 maps (API parity) keep 32 bits each
+    constexpr int TR = kTilePixels / TC, NSEG = TR / kSegRows;
+    constexpr int CPH = TC >= 16 ? TC / 16 : 1;         // columns one half-wave writes
+    constexpr int SPLIT = TC >= 16 ? 1 : 16 / TC;       // half-waves that share a column (each a run of consecutive segments)
+    constexpr int SPH = NSEG / SPLIT;                   // segments of a column one half-wave writes
+    constexpr int WD = 3 * TC / 4;                      // dwords of white bytes per tile row
+    constexpr int NM = kTilePixels / kScatterThreads, NX = 3 * kTilePixels / kScatterThreads, NW = (TR * WD + kScatterThreads - 1) / kScatterThreads;
+    __shared__ unsigned s_hv[TR][TC + 1];
+    __shared__ int s_pv[PACKED ? 1 : TR][PACKED ? 1 : TC + 1];
+    __shared__ unsigned s_white[TR][WD + 1];            // +1: rows land in different banks
+    __shared__ float s_xyz[XYZ ? TR : 1][XYZ ? 3 * TC + 1 : 1];
+    __shared__ unsigned long long s_base[NSEG][TC];     // where each column segment's first record goes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int x_tile = (int)(blockIdx.x % (unsigned)tiles_x) * TC, y_tile = (int)(blockIdx.x / (unsigned)tiles_x) * TR;
+    const int cols = min(TC, W - x_tile);
+    const size_t npix = (size_t)W * H;
+    const bool white_dwords = colors && !LISTS_ABL(16) && (((uintptr_t)white | (unsigned)W) & 3u) == 0 && npix >= 2;   // row starts dword aligned
+    const bool white_bytes = colors && !LISTS_ABL(16) && !white_dwords;
+    unsigned long long M = 0;
+    if constexpr (XYZ) M = *total;
+
+    // Phase 1: unconditional loads on clamped addresses (rows past H re-read row H - 1, elements past the image its last one; phase 2
+    // never looks at those slots), all of a lane's loads in flight together.
+    MapT hq[NM], vq[NM];
+    float xq[XYZ ? NX : 1];
+    unsigned wq[NW];
+    unsigned long long bq = 0;
 #pragma unroll
-    for (int s = 0; s < kChunkRows / 4; ++s) {
-        const int r = s * 4 + wave, x = x_tile + lane, y = y_tile + r;
-        int pu = kInvalid, pv = 0;
-        unsigned rgb = 0;
-        if (x < W && y < H) {
-            const size_t p = (size_t)y * W + x;
-            const int64_t hv = h[p], vv = v[p];
-            if (decodable(hv, vv)) {
-                pu = (int)(hv < proj_w - 1 ? hv : proj_w - 1);                  // triangulate.py:60 (maps from this library fit 32 bits)
-                pv = (int)(vv < proj_h - 1 ? vv : proj_h - 1);                  // :61
-                if (pu == kInvalid) pu = kInvalid + 1;
-                if (colors) rgb = (unsigned)white[3 * p] | ((unsigned)white[3 * p + 1] << 8) | ((unsigned)white[3 * p + 2] << 16);
-                if constexpr (XYZ) {
-                    s_xyz[0][r][lane] = xyz[3 * p];
-                    s_xyz[1][r][lane] = xyz[3 * p + 1];
-                    s_xyz[2][r][lane] = xyz[3 * p + 2];
+    for (int q = 0; q < NM; ++q) {
+        const int i = q * kScatterThreads + tid, row = i / TC, col = i % TC;
+        const size_t p = min((size_t)min(y_tile + row, H - 1) * W + x_tile + col, npix - 1);
+        hq[q] = h[p];
+        vq[q] = v[p];
+    }
+    if constexpr (XYZ) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int i = q * kScatterThreads + tid, row = i / (3 * TC), k = i % (3 * TC);
+            xq[q] = LISTS_ABL(8) ? 0.0f : xyz[min(3 * ((size_t)min(y_tile + row, H - 1) * W + x_tile) + k, 3 * npix - 1)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) wq[q] = 0u;
+    if (white_dwords) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int i = min(q * kScatterThreads + tid, TR * WD - 1), row = i / WD, d = i % WD;
+            wq[q] = *reinterpret_cast<const unsigned *>(white + min(3 * ((size_t)min(y_tile + row, H - 1) * W + x_tile) + 4 * d, 3 * npix - 4));
+        }
+    } else if (white_bytes) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int i = min(q * kScatterThreads + tid, TR * WD - 1), row = i / WD, d = i % WD;
+            const size_t o = 3 * ((size_t)min(y_tile + row, H - 1) * W + x_tile) + 4 * d;
+            unsigned b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) b[k] = white[min(o + k, 3 * npix - 1)];
+            wq[q] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        }
+    }
+    if (tid < NSEG * TC) {
+        const int seg = tid / TC, xb = min(x_tile + tid % TC, W - 1), chunk = min(y_tile / kChunkRows + seg, (H - 1) / kChunkRows);
+        bq = colstart[xb] + counts[(size_t)chunk * W + xb];
+    }
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+        const int i = q * kScatterThreads + tid, row = i / TC, col = i % TC;
+        const int64_t hv = hq[q], vv = vq[q];
+        const bool ok = col < cols && y_tile + row < H && decodable(hv, vv);
+        const int pu = (int)(hv < proj_w - 1 ? hv : proj_w - 1);                    // triangulate.py:60 (maps from this library fit 32 bits)
+        const int pv = (int)(vv < proj_h - 1 ? vv : proj_h - 1);                    // :61
+        if constexpr (PACKED) {
+            s_hv[row][col] = ok ? ((unsigned)pu & 0xffffu) | ((unsigned)pv << 16) : kInvalidHV;
+        } else {
+            s_hv[row][col] = ok ? (unsigned)(pu == kInvalid ? kInvalid + 1 : pu) : (unsigned)kInvalid;
+            s_pv[row][col] = pv;
+        }
+    }
+    if constexpr (XYZ) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int i = q * kScatterThreads + tid;
+            s_xyz[i / (3 * TC)][i % (3 * TC)] = xq[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const int i = q * kScatterThreads + tid;
+        if (i < TR * WD) s_white[i / WD][i % WD] = wq[q];
+    }
+    if (tid < NSEG * TC) s_base[tid / TC][tid % TC] = bq;
+    __syncthreads();
+
+    // Phase 2
+    const int half = lane >> 5, r = lane & 31, hw = tid >> 5;
+    // colour doubles of a segment, re-spread: lane r of round k writes double j = 32 k + r = channel j % 3 of record j / 3
+    int rec_lane[3], ch_shift[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = k * 32 + r;
+        rec_lane[k] = (half * 32 + j / 3) * 4;
+        ch_shift[k] = 8 * (j % 3);
+    }
+#pragma unroll
+    for (int j = 0; j < CPH; ++j) {
+        const int c = SPLIT == 1 ? hw + 16 * j : hw % TC, x = x_tile + c;           // this half-wave's column
+#pragma unroll
+        for (int q = 0; q < SPH; ++q) {
+            const int seg = SPLIT == 1 ? q : (hw / TC) * SPH + q, row = seg * kSegRows + r;
+            const unsigned hv = s_hv[row][c];
+            const bool ok = PACKED ? hv != kInvalidHV : hv != (unsigned)kInvalid;
+            const unsigned long long m = __ballot(ok);
+            const unsigned mh = (unsigned)(half ? (m >> 32) : m);
+            const unsigned rank = (unsigned)__popc(mh & ((1u << r) - 1u)), n = (unsigned)__popc(mh);
+            const unsigned long long o0 = LISTS_ABL(32) ? ((unsigned long long)blockIdx.x * TC + c) * TR + seg * kSegRows : s_base[seg][c];
+            if (ok) {
+                const unsigned long long o = o0 + rank;
+                const int pu = PACKED ? (int)(short)(hv & 0xffffu) : (int)hv;
+                const int pv = PACKED ? (int)(short)(hv >> 16) : s_pv[PACKED ? 0 : row][PACKED ? 0 : c];
+                if (!LISTS_ABL(1)) {
+                    reinterpret_cast<float2 *>(cam)[o] = make_float2((float)x, (float)(y_tile + row));          // :59 [i, j] = (x, y)
+                    reinterpret_cast<float2 *>(proj)[o] = make_float2((float)pu, (float)pv);
+                }
+                if (XYZ && !LISTS_ABL(2)) {
+                    pts[o] = (double)s_xyz[row][3 * c];                              // Pts (3,M) float64, :95
+                    pts[M + o] = (double)s_xyz[row][3 * c + 1];
+                    pts[2 * M + o] = (double)s_xyz[row][3 * c + 2];
                 }
             }
-        }
-        s_pu[r][lane] = pu;
-        s_pv[r][lane] = pv;
-        s_rgb[r][lane] = rgb;
-    }
-    __syncthreads();
-    const int half = lane >> 5, r = lane & 31;
-#pragma unroll 2
-    for (int s = 0; s < kTileCols / 8; ++s) {
-        const int c = wave * (kTileCols / 4) + 2 * s + half, x = x_tile + c;    // this half-wave's column
-        const int pu = s_pu[r][c];
-        const bool ok = pu != kInvalid;
-        const unsigned long long m = __ballot(ok);
-        const unsigned mh = (unsigned)(half ? (m >> 32) : m);
-        if (ok && x < W) {
-            const unsigned long long o = colstart[x] + counts[(size_t)chunk * W + x] + (unsigned)__popc(mh & ((1u << r) - 1u));
-            reinterpret_cast<float2 *>(cam)[o] = make_float2((float)x, (float)(y_tile + r));                    // :59 [i, j] = (x, y)
-            reinterpret_cast<float2 *>(proj)[o] = make_float2((float)pu, (float)s_pv[r][c]);
-            if (colors) {
-                const unsigned rgb = s_rgb[r][c];
-                colors[3 * o] = (double)(rgb & 0xffu) / 255.0;                   // :64, :69
-                colors[3 * o + 1] = (double)((rgb >> 8) & 0xffu) / 255.0;
-                colors[3 * o + 2] = (double)((rgb >> 16) & 0xffu) / 255.0;
-            }
-            if constexpr (XYZ) {
-                const unsigned long long M = *total;
-                pts[o] = (double)s_xyz[0][r][c];                                 // Pts (3,M) float64, :95
-                pts[M + o] = (double)s_xyz[1][r][c];
-                pts[2 * M + o] = (double)s_xyz[2][r][c];
+            if (colors && !LISTS_ABL(4)) {
+                // compact the segment's colours over the lanes of the half-wave: valid pixels to lane `rank`, the others behind them
+                const uint8_t *wb = reinterpret_cast<const uint8_t *>(&s_white[row][0]) + 3 * c;
+                const unsigned rgb = (unsigned)wb[0] | ((unsigned)wb[1] << 8) | ((unsigned)wb[2] << 16);
+                const unsigned dst = ok ? rank : n + ((unsigned)r - rank);
+                const unsigned packed = (unsigned)__builtin_amdgcn_ds_permute((int)((half * 32 + dst) * 4), (int)rgb);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned px = (unsigned)__builtin_amdgcn_ds_bpermute(rec_lane[k], (int)packed);
+                    if ((unsigned)(k * 32 + r) < 3 * n) colors[3 * o0 + k * 32 + r] = unit_of_byte((px >> ch_shift[k]) & 0xffu);   // :64, :69
+                }
             }
         }
     }
@@ -330,6 +491,35 @@ int compact(slgc_ctx *ctx, Pred pred, Emit emit, size_t n, unsigned long long *d
     return SLGC_OK;
 }
 
+// The four passes of the x-major list build on ctx->stream (nothing synchronises with the host).
+template <typename MapT, bool XYZ>
+int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int cam_h, int proj_w, int proj_h, const uint8_t *d_white, float *d_cam,
+                 float *d_proj, double *d_colors, const float *d_xyz, double *d_pts, unsigned long long *d_total)
+{
+    constexpr int TC = SLGC_SCATTER_TC, TR = kTilePixels / TC;
+    const size_t npix = (size_t)cam_w * cam_h;
+    const int nchunks = (cam_h + kChunkRows - 1) / kChunkRows;
+    void *counts, *colstart;
+    int rc = slgc_ws(ctx, 4, ((size_t)nchunks * cam_w + 1) * sizeof(unsigned), &counts);
+    if (rc) return rc;
+    rc = slgc_ws(ctx, 5, ((size_t)cam_w + 1) * sizeof(unsigned long long), &colstart);
+    if (rc) return rc;
+    const int groups_x = (cam_w + 63) / 64;
+    if (npix) hipLaunchKernelGGL(k_xmajor_count<MapT>, dim3(groups_x, nchunks), dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
+    if (cam_w)
+        hipLaunchKernelGGL(k_xmajor_colprefix, dim3(groups_x), dim3(64 * kPrefixGroups), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
+                           (unsigned long long *)colstart);
+    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
+    if (npix) {
+        const int tiles_x = (cam_w + TC - 1) / TC, tiles_y = (cam_h + TR - 1) / TR;
+        hipLaunchKernelGGL((k_xmajor_scatter<MapT, XYZ, TC>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w,
+                           cam_h, proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_colors, d_xyz, d_pts,
+                           (const unsigned long long *)d_total, tiles_x, lists_abl());
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
 }  // namespace
 
 int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,
@@ -342,24 +532,8 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
         EmitCorr emit{d_h, d_v, d_white, cam_w, proj_w, proj_h, d_cam, d_proj, d_white ? d_colors : nullptr};
         return compact(ctx, pred, emit, npix, d_total);
     }
-    const int nchunks = (cam_h + kChunkRows - 1) / kChunkRows;
-    void *counts, *colstart;
-    int rc = slgc_ws(ctx, 4, ((size_t)nchunks * cam_w + 1) * sizeof(unsigned), &counts);
-    if (rc) return rc;
-    rc = slgc_ws(ctx, 5, ((size_t)cam_w + 1) * sizeof(unsigned long long), &colstart);
-    if (rc) return rc;
-    const dim3 grid((cam_w + 255) / 256, nchunks);
-    if (npix) hipLaunchKernelGGL(k_xmajor_count<int64_t>, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
-    if (cam_w)
-        hipLaunchKernelGGL(k_xmajor_colprefix, dim3((cam_w + 255) / 256), dim3(256), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
-                           (unsigned long long *)colstart);
-    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
-    if (npix)
-        hipLaunchKernelGGL((k_xmajor_scatter<int64_t, false>), dim3((cam_w + kTileCols - 1) / kTileCols, nchunks), dim3(256), 0, ctx->stream, d_h, d_v,
-                           cam_w, cam_h, proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj,
-                           d_white ? d_colors : nullptr, (const float *)nullptr, (double *)nullptr, (const unsigned long long *)nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-    return SLGC_OK;
+    return xmajor_lists<int64_t, false>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
+                                        d_total);
 }
 
 // Device-resident form of the reference-shaped product (slgc_cloud_lists_dev): int16 maps + dense float32 XYZ (+ white image) ->
@@ -367,32 +541,11 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
 int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white, int cam_w, int cam_h,
                        int proj_w, int proj_h, float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total)
 {
-    const size_t npix = (size_t)cam_w * cam_h;
-    const int nchunks = (cam_h + kChunkRows - 1) / kChunkRows;
-    void *counts, *colstart;
-    int rc = slgc_ws(ctx, 4, ((size_t)nchunks * cam_w + 1) * sizeof(unsigned), &counts);
-    if (rc) return rc;
-    rc = slgc_ws(ctx, 5, ((size_t)cam_w + 1) * sizeof(unsigned long long), &colstart);
-    if (rc) return rc;
-    const dim3 grid((cam_w + 255) / 256, nchunks);
-    if (npix) hipLaunchKernelGGL(k_xmajor_count<int16_t>, grid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
-    if (cam_w)
-        hipLaunchKernelGGL(k_xmajor_colprefix, dim3((cam_w + 255) / 256), dim3(256), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
-                           (unsigned long long *)colstart);
-    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
-    if (npix) {
-        const dim3 sgrid((cam_w + kTileCols - 1) / kTileCols, nchunks);
-        if (d_xyz && d_pts)
-            hipLaunchKernelGGL((k_xmajor_scatter<int16_t, true>), sgrid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white,
-                               (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_white ? d_colors : nullptr, d_xyz, d_pts,
-                               (const unsigned long long *)d_total);
-        else
-            hipLaunchKernelGGL((k_xmajor_scatter<int16_t, false>), sgrid, dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white,
-                               (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_white ? d_colors : nullptr,
-                               (const float *)nullptr, (double *)nullptr, (const unsigned long long *)nullptr);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return SLGC_OK;
+    if (d_xyz && d_pts)
+        return xmajor_lists<int16_t, true>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, d_xyz, d_pts,
+                                           d_total);
+    return xmajor_lists<int16_t, false>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
+                                        d_total);
 }
 
 // pass 0: count only (total -> *d_total); pass 1: count again + scatter (outputs sized from pass 0's total).

@@ -227,3 +227,20 @@ def test_read_images_order_shapes_and_types(tmp_path):
     empty = tmp_path / "none"
     empty.mkdir()
     assert read_images(str(empty))[0].shape[0] == 0
+
+
+def test_byte_over_255_by_one_refinement_step_is_the_correctly_rounded_quotient():
+    """correspond.hip: unit_of_byte(b) = fma(fma(-q, 255, b), 1/255, q) with q = b * (1/255) must equal the reference's float64 b / 255.0
+    (triangulate.py:64,:69) for every byte; the plain product b * (1/255) does not (that is what the negative control shows)."""
+    from fractions import Fraction
+    rcp = 1.0 / 255.0
+
+    def fma(a, b, c):                                        # exact product-sum, rounded once (Fraction -> float rounds to nearest even)
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    plain_wrong = 0
+    for b in range(256):
+        q = float(b) * rcp
+        plain_wrong += q != b / 255.0
+        assert fma(fma(-q, 255.0, float(b)), rcp, q) == b / 255.0
+    assert plain_wrong > 0

@@ -494,6 +494,40 @@ def test_cam_proj_pts_large_vs_oracle(ctx):
     assert full[0].shape == (H * W, 2) and np.array_equal(full[0][:3], [[0, 0], [0, 1], [0, 2]])   # x-major
 
 
+@pytest.mark.parametrize("W,H", [(517, 301), (64, 32), (65, 33), (3, 2), (1, 1), (200, 1)])
+def test_cloud_lists_dev_ragged_vs_oracle(ctx, W, H):
+    """slgc_cloud_lists_dev on maps / XYZ / white images of its own making: widths that are not a multiple of 4 (white image read byte by byte),
+    tiles cut by both edges, empty rows and columns, every byte value in the colours (b / 255.0 must be the reference's division)."""
+    rng = np.random.default_rng(W * 1000 + H)
+    px = W * H
+    h = rng.integers(-1, 1500, (H, W)).astype(np.int16)
+    v = rng.integers(-1, 900, (H, W)).astype(np.int16)
+    h[rng.random((H, W)) < 0.3] = -1
+    if W > 140:
+        h[:, 100:140] = -1
+    if H > 90:
+        v[50:90] = -1
+    dense = rng.standard_normal((H, W, 3)).astype(np.float32)
+    white_h = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    white_h.reshape(-1)[:min(256, px * 3)] = np.arange(min(256, px * 3), dtype=np.uint8)
+    maps = ctx.alloc(max(16, px * 4))
+    maps.upload(np.concatenate([h.reshape(-1), v.reshape(-1)]))
+    xyz = ctx.alloc(max(16, px * 12)).upload(dense)
+    raw = ctx.alloc(px * 3 + 16)
+    for shift in (0, 1):                                     # white image on a dword boundary and one byte off it
+        raw.upload(np.concatenate([np.zeros(shift, np.uint8), white_h.reshape(-1)]))
+        lists = ctx.alloc_cloud_lists(px, colors=True)
+        ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), xyz.ptr, raw.at(shift), W, H, (1280, 800), lists)
+        cam, proj, pts, col = lists.download()
+        rcam, rproj, rcol = oc.cam_proj_pts(h.astype(np.int64), v.astype(np.int64), (W, H), (1280, 800), white_h, order="x")
+        assert np.array_equal(cam, rcam) and np.array_equal(proj, rproj) and np.array_equal(col, rcol)
+        xs, ys = rcam[:, 0].astype(np.int64), rcam[:, 1].astype(np.int64)
+        assert pts.shape == (3, len(rcam)) and np.array_equal(pts, dense[ys, xs].astype(np.float64).T)
+        lists.free()
+    for b in (maps, xyz, raw):
+        b.free()
+
+
 def test_triangulate_random_vs_oracle(ctx, calib):
     rng = np.random.default_rng(13)
     M = 200_003
