@@ -7,14 +7,23 @@
 // K7  uniform-grid exact k-NN: points are binned into cubic cells of edge s (counting sort: atomics + the exclusive scan below), every
 //     query scans the 3x3x3 block around its cell keeping the K smallest squared distances in registers (static insertion
 //     network, no dynamic register indexing).  A result is exact when its k-th distance <= s (nothing outside the block can
-//     be closer); the others are retried with the cell edge doubled until all are exact.
+//     be closer); the others are retried with a larger cell edge until all are exact.  The first round takes its queries in cell
+//     order (see k_knn_mean).  The grid covers a ROBUST box (0.5 % .. 99.5 % quantiles of a sample per axis; points outside are
+//     clamped into its boundary cells, which keeps the "within s => inside the 3x3x3 block" argument intact), and the first cell edge
+//     is tuned on the cloud itself: a few counting passes steer the mean population of the non-empty cells to ~9 points (a surface
+//     sampled so that the disc holding k = 20 points has radius ~0.85 s).  A bounding-box estimate is off by an order of magnitude
+//     as soon as a scan has a few far outliers -- which is what this routine exists to remove.
 #include "slgc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
 
 namespace {
 
 // ---- exclusive prefix sum of uint32 (cell counts -> cell starts) -------------------------------------------------------------
 // Three-level reduce-then-scan: a 256-thread workgroup owns a tile of 2048 consecutive elements (8 per lane, two 16-byte loads);
-// pass 1 writes every tile's sum, the sums are scanned recursively (33.5 M cells -> 16 385 tile sums -> 9 -> 1), pass 2 rescans
+// pass 1 writes every tile's sum, the sums are scanned recursively (537 M cells -> 262 145 tile sums -> 129 -> 1), pass 2 rescans
 // each tile from its prefix.  Inside a tile: per-lane serial prefix, wave64 inclusive scan with __shfl_up, wave totals through LDS.
 constexpr int kScanTile = 2048;
 
@@ -127,7 +136,15 @@ __global__ void __launch_bounds__(256) k_cell_fill(const float *__restrict__ pts
     if (i >= M) return;
     const unsigned c = cell_of[i];
     const unsigned slot = cell_start[c] + atomicAdd(cursor + c, 1u);
-    sorted[slot] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 0.f);
+    sorted[slot] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float((unsigned)i));   // .w = where the point came from
+}
+
+__global__ void __launch_bounds__(256) k_count_nonzero(const unsigned *__restrict__ v, size_t n, unsigned *__restrict__ out)
+{
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += v[i] ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
 // queries: indices of the points still to be resolved (nullptr = all points 0..nq-1)
@@ -139,8 +156,18 @@ __global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts,
 {
     const size_t t = (size_t)blockIdx.x * 128 + threadIdx.x;
     if (t >= nq) return;
-    const unsigned i = queries ? queries[t] : (unsigned)t;
-    const double qx = pts[3 * (size_t)i], qy = pts[3 * (size_t)i + 1], qz = pts[3 * (size_t)i + 2];
+    // First round (queries == nullptr): the queries are the points in CELL order -- the lanes of a wave sit in the same or neighbouring
+    // cells, walk the same candidate runs (coalesced / broadcast loads, loops of equal length) and insert at similar times.
+    unsigned i;
+    double qx, qy, qz;
+    if (queries) {
+        i = queries[t];
+        qx = pts[3 * (size_t)i], qy = pts[3 * (size_t)i + 1], qz = pts[3 * (size_t)i + 2];
+    } else {
+        const float4 q = sorted[t];
+        i = __float_as_uint(q.w);
+        qx = q.x, qy = q.y, qz = q.z;
+    }
     const int cx = cell_coord((float)qx, g.ox, g.inv_s, g.nx), cy = cell_coord((float)qy, g.oy, g.inv_s, g.ny),
               cz = cell_coord((float)qz, g.oz, g.inv_s, g.nz);
     double best[K];
@@ -213,14 +240,33 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
             lo[c] = v < lo[c] ? v : lo[c];
             hi[c] = v > hi[c] ? v : hi[c];
         }
+    // robust box: per-axis 0.5 % / 99.5 % quantiles of a sample of <= 65 536 points, widened by 5 %, inside the true box
+    {
+        const int64_t stride = M > 65536 ? M / 65536 : 1;
+        std::vector<float> col;
+        col.reserve((size_t)(M / stride) + 1);
+        for (int c = 0; c < 3; ++c) {
+            col.clear();
+            for (int64_t i = 0; i < M; i += stride) col.push_back(pts[3 * i + c]);
+            const size_t n = col.size(), a = (size_t)(0.005 * (double)(n - 1)), b = (size_t)(0.995 * (double)(n - 1));
+            std::nth_element(col.begin(), col.begin() + a, col.end());
+            const float qa = col[a];
+            std::nth_element(col.begin(), col.begin() + b, col.end());
+            const float qb = col[b];
+            const float pad = 0.05f * (qb - qa);
+            lo[c] = std::max(lo[c], qa - pad);
+            hi[c] = std::min(hi[c], qb + pad);
+        }
+    }
     const double ext[3] = {(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2]};
     double e_sorted[3] = {ext[0], ext[1], ext[2]};
     for (int a = 0; a < 3; ++a)
         for (int b = a + 1; b < 3; ++b)
             if (e_sorted[b] > e_sorted[a]) { const double t = e_sorted[a]; e_sorted[a] = e_sorted[b]; e_sorted[b] = t; }
-    // scanner clouds are surfaces: estimate the 2-D density from the two largest extents; radius holding ~k points, x1.5
+    // scanner clouds are surfaces: first guess of the cell edge from the 2-D density over the two largest extents (radius holding ~k
+    // points, x1.25); tuned below on the cloud itself
     const double area = (e_sorted[0] > 0 ? e_sorted[0] : 1e-6) * (e_sorted[1] > 0 ? e_sorted[1] : 1e-6);
-    double s = 1.5 * sqrt((double)k / (3.141592653589793 * ((double)M / area)));
+    double s = 1.25 * sqrt((double)k / (3.141592653589793 * ((double)M / area)));
     if (!(s > 0)) s = 1e-6;
 
     void *d_pts, *d_mean, *d_sorted, *d_cellof, *d_unres[2], *d_nun;
@@ -237,23 +283,45 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     size_t nq = (size_t)M;
     const unsigned *d_q = nullptr;
     int cur = 0;
-    for (int round = 0; round < 40 && nq; ++round, s *= 2.0) {
+    const double occ_target = 0.45 * (double)k;                          // points per non-empty cell (k = 20 -> 9)
+    int tune_left = 3;
+    for (int round = 0; round < 40 && nq; ++round) {
         Grid g;
         g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
-        // keep the grid below 2^25 cells; growing s only makes the search more conservative
-        for (;;) {
-            const double nx = floor(ext[0] / s) + 1, ny = floor(ext[1] / s) + 1, nz = floor(ext[2] / s) + 1;
-            if (nx * ny * nz <= 33554432.0) { g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; break; }
-            s *= 1.26;
-        }
-        g.inv_s = (float)(1.0 / s);
-        const size_t ncell = (size_t)g.nx * g.ny * g.nz;
         void *d_counts, *d_start, *d_tmp;
-        if ((rc = slgc_ws(ctx, 4, (ncell + 1) * 4, &d_counts))) return rc;
-        if ((rc = slgc_ws(ctx, 5, (ncell + 1) * 4, &d_start))) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, g,
-                           (unsigned *)d_counts, (unsigned *)d_cellof);
+        size_t ncell;
+        for (;;) {
+            // keep the grid below 2^29 cells (2 x 2 GiB of counters, a 4 ms scan); growing s only makes the search more conservative
+            for (;;) {
+                const double nx = floor(ext[0] / s) + 1, ny = floor(ext[1] / s) + 1, nz = floor(ext[2] / s) + 1;
+                if (nx * ny * nz <= 536870912.0) { g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; break; }
+                s *= 1.26;
+                tune_left = 0;
+            }
+            g.inv_s = (float)(1.0 / s);
+            ncell = (size_t)g.nx * g.ny * g.nz;
+#ifdef SLGC_DIAG
+            fprintf(stderr, "slgc k-NN round %d: %zu queries, cell edge %.4g, grid %d x %d x %d, extents %.4g %.4g %.4g\n", round, nq, s, g.nx, g.ny, g.nz,
+                    ext[0], ext[1], ext[2]);
+#endif
+            if ((rc = slgc_ws(ctx, 4, (ncell + 1) * 4, &d_counts))) return rc;
+            if ((rc = slgc_ws(ctx, 5, (ncell + 1) * 4, &d_start))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));
+            hipLaunchKernelGGL(k_cell_count, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, g,
+                               (unsigned *)d_counts, (unsigned *)d_cellof);
+            if (round != 0 || tune_left <= 0 || ncell == 1) break;
+            // first round only: steer the population of the non-empty cells to the target (a surface: population ~ s^2)
+            --tune_left;
+            unsigned nonempty = 0;
+            HIP_TRY(ctx, hipMemsetAsync(d_nun, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)std::min<size_t>((ncell + 2047) / 2048, 4096)), dim3(256), 0, ctx->stream,
+                               (const unsigned *)d_counts, ncell, (unsigned *)d_nun);
+            HIP_TRY(ctx, hipMemcpyAsync(&nonempty, d_nun, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const double occ = (double)M / (double)(nonempty ? nonempty : 1);
+            if (occ > occ_target / 1.3 && occ < occ_target * 1.3) break;
+            s *= std::min(8.0, std::max(0.125, sqrt(occ_target / occ)));
+        }
         if ((rc = slgc_ws(ctx, 6, scan_scratch_elems(ncell + 1) * 4, &d_tmp))) return rc;
         if ((rc = exclusive_scan_u32(ctx, (const unsigned *)d_counts, (unsigned *)d_start, ncell + 1, (unsigned *)d_tmp))) return rc;
         HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (ncell + 1) * 4, ctx->stream));          // reused as the fill cursor
@@ -277,6 +345,7 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
         d_q = d_out;
         cur ^= 1;
         if (one_cell && nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN: %zu queries unresolved on a single-cell grid (internal error)", nq);
+        s *= round == 0 ? 2.0 : 4.0;                   // the stragglers are few: fewer rebuilds of the grid matter more than their candidate lists
     }
     if (nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN left %zu points unresolved", nq);
     HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));

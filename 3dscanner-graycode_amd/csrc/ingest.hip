@@ -5,31 +5,36 @@
 //                        the decode kernels read.  OpenCV's 8-bit path (third-party, 4.8.0.76 not installed -> PARITY
 //                        UNPINNED): Y = (B*BY + G*GY + R*RY + (1 << (shift-1))) >> shift with shift = 15,
 //                        (RY, GY, BY) = (9798, 19235, 3735) in 4.x; the older 14-bit set (4899, 9617, 1868) is selectable.
-// K6  k_frame_diff_count count(|frame[j+1] - frame[j]| > thresh) for consecutive frames -- the arithmetic of
-//                        remove_bad_images (decode_codes.py:34-68: cv2.absdiff + np.argwhere + len); wave64 reduce
-//                        (__shfl_down) then one atomic per workgroup.  The keep/drop state machine (:56-66) is host logic.
+// K6  k_frame_diff_*     count(|frame[j+1] - frame[j]| > thresh) for consecutive frames -- the arithmetic of
+//                        remove_bad_images (decode_codes.py:34-68: cv2.absdiff + np.argwhere + len).  uint8 frames: one lane
+//                        carries 16 pixels through ALL frames (every frame byte is read once: N B / pixel), two pixels per
+//                        32-bit operation; float64 frames and ragged sizes take the generic kernel.  The keep/drop state
+//                        machine (:56-66) is host logic.
 #include "slgc_internal.h"
 
 namespace {
 
+// 16 pixels = 48 input bytes = three 16-byte loads per lane, one 16-byte store
 __global__ void __launch_bounds__(256) k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t npix, int ry, int gy,
                                                      int by, int shift)
 {
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;   // 4 pixels = 12 input bytes = 3 dwords per lane
-    if (q * 4 >= npix) return;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q * 16 >= npix) return;
     const int rnd = 1 << (shift - 1);
-    if (q * 4 + 4 <= npix && ((uintptr_t)bgr & 3) == 0 && ((uintptr_t)gray & 3) == 0) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(bgr) + q * 3;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
-        const uint32_t b[4] = {w0 & 0xff, w0 >> 24, (w1 >> 16) & 0xff, (w2 >> 8) & 0xff};
-        const uint32_t g[4] = {(w0 >> 8) & 0xff, w1 & 0xff, w1 >> 24, (w2 >> 16) & 0xff};
-        const uint32_t r[4] = {(w0 >> 16) & 0xff, (w1 >> 8) & 0xff, w2 & 0xff, w2 >> 24};
-        uint32_t out = 0;
+    if (q * 16 + 16 <= npix && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)gray & 15) == 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bgr) + q * 3;
+        const uint4 a = src[0], b = src[1], c = src[2];
+        const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out |= (uint32_t)((int)(b[j] * by + g[j] * gy + r[j] * ry + rnd) >> shift) << (8 * j);
-        reinterpret_cast<uint32_t *>(gray)[q] = out;
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t B = (w[(3 * j) >> 2] >> (8 * ((3 * j) & 3))) & 0xffu, G = (w[(3 * j + 1) >> 2] >> (8 * ((3 * j + 1) & 3))) & 0xffu,
+                           R = (w[(3 * j + 2) >> 2] >> (8 * ((3 * j + 2) & 3))) & 0xffu;
+            out[j >> 2] |= (uint32_t)((int)(B * by + G * gy + R * ry + rnd) >> shift) << (8 * (j & 3));
+        }
+        reinterpret_cast<uint4 *>(gray)[q] = make_uint4(out[0], out[1], out[2], out[3]);
     } else {
-        for (size_t p = q * 4; p < npix && p < q * 4 + 4; ++p)
+        for (size_t p = q * 16; p < npix && p < q * 16 + 16; ++p)
             gray[p] = (uint8_t)(((int)bgr[3 * p] * by + (int)bgr[3 * p + 1] * gy + (int)bgr[3 * p + 2] * ry + rnd) >> shift);
     }
 }
@@ -42,8 +47,13 @@ __global__ void __launch_bounds__(256) k_frame_diff_count(const T *__restrict__ 
     const T *a = frames + (size_t)pair * elems, *b = a + elems;
     unsigned c = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < elems; i += (size_t)gridDim.x * 256) {
-        const double d = fabs((double)b[i] - (double)a[i]);   // cv2.absdiff; NaN compares false like NumPy's '>'
-        c += d > thresh ? 1u : 0u;
+        if constexpr (sizeof(T) == 1) {
+            const int d = (int)b[i] - (int)a[i];                  // cv2.absdiff on 8-bit frames
+            c += (double)(d < 0 ? -d : d) > thresh ? 1u : 0u;
+        } else {
+            const double d = fabs((double)b[i] - (double)a[i]);   // NaN compares false like NumPy's '>'
+            c += d > thresh ? 1u : 0u;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     __shared__ unsigned w[4];
@@ -55,13 +65,83 @@ __global__ void __launch_bounds__(256) k_frame_diff_count(const T *__restrict__ 
     }
 }
 
+// uint8 frames of a multiple of 16 pixels on a 16-byte boundary.  A lane keeps the previous frame's 16 pixels unpacked into 16-bit fields
+// (even bytes / odd bytes of each dword) and meets the next frame with two pixels per operation: with D = prev - next over both fields
+// at once (borrows between the fields cancel in the sums below) and C = (0x7fff - t) in both fields,
+//     C + D  has bit 15 / 31 set  <=>  prev - next >= t + 1          C - D  has it set  <=>  next - prev >= t + 1
+// for an integer threshold 0 <= t < 255 (|d| > thresh for integer d <=> |d| >= floor(thresh) + 1; the host deals with thresh < 0, >= 255
+// and NaN).  Every field stays inside its 16 bits: 0x7fff - t +- 255.
+constexpr unsigned kFieldMask = 0x00ff00ffu, kSignBits = 0x80008000u;
+
+// Sum of c over the 64 lanes of a fully active wave, as a wave-uniform value: a DPP butterfly inside each row of 16 lanes (vector ALU,
+// no LDS round trips), then the four row sums through v_readlane.
+__device__ __forceinline__ unsigned wave_sum(unsigned c)
+{
+    c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xf, 0xf, true);    // quad_perm:[1,0,3,2]
+    c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xf, 0xf, true);    // quad_perm:[2,3,0,1]
+    c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    c += (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x140, 0xf, 0xf, true);   // row_mirror
+    return (unsigned)(__builtin_amdgcn_readlane((int)c, 0) + __builtin_amdgcn_readlane((int)c, 16) + __builtin_amdgcn_readlane((int)c, 32) +
+                      __builtin_amdgcn_readlane((int)c, 48));
+}
+
+__global__ void __launch_bounds__(256) k_frame_diff_u8x16(const uint4 *__restrict__ frames, size_t chunks, int n_frames, unsigned c_fields,
+                                                          unsigned long long *__restrict__ counts)
+{
+    extern __shared__ unsigned s_cnt[];                                  // n_frames - 1 counters of this workgroup
+    for (int p = threadIdx.x; p < n_frames - 1; p += 256) s_cnt[p] = 0u;
+    __syncthreads();
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = q < chunks;
+    const size_t qc = active ? q : chunks - 1;
+    unsigned lo[4], hi[4];
+    {
+        const uint4 a = frames[qc];
+        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = w[k] & kFieldMask;
+            hi[k] = (w[k] >> 8) & kFieldMask;
+        }
+    }
+    const int last = n_frames - 1;                                       // loads run two frames ahead (the last frame is re-read at the end)
+    uint4 n1 = frames[(size_t)1 * chunks + qc], n2 = frames[(size_t)min(2, last) * chunks + qc];
+    for (int f = 1; f < n_frames; ++f) {
+        const uint4 b = n1;
+        n1 = n2;
+        n2 = frames[(size_t)min(f + 2, last) * chunks + qc];
+        const unsigned w[4] = {b.x, b.y, b.z, b.w};
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lb = w[k] & kFieldMask, hb = (w[k] >> 8) & kFieldMask;
+            const unsigned dl = lo[k] - lb, dh = hi[k] - hb;
+            c += __popc(((c_fields + dl) | (c_fields - dl)) & kSignBits) + __popc(((c_fields + dh) | (c_fields - dh)) & kSignBits);
+            lo[k] = lb;
+            hi[k] = hb;
+        }
+        if (!active) c = 0;
+        const unsigned total = wave_sum(c);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(&s_cnt[f - 1], total);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n_frames - 1; p += 256)
+        if (s_cnt[p]) atomicAdd(counts + p, (unsigned long long)s_cnt[p]);
+}
+
+__global__ void k_fill_u64(unsigned long long *__restrict__ out, int n, unsigned long long v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
 }  // namespace
 
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits)
 {
     if (npix == 0) return SLGC_OK;
     const int ry = coeff_bits == 14 ? 4899 : 9798, gy = coeff_bits == 14 ? 9617 : 19235, by = coeff_bits == 14 ? 1868 : 3735;
-    hipLaunchKernelGGL(k_bgr_to_gray, dim3((unsigned)(((npix + 3) / 4 + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, d_gray, npix, ry, gy, by,
+    hipLaunchKernelGGL(k_bgr_to_gray, dim3((unsigned)(((npix + 15) / 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, d_gray, npix, ry, gy, by,
                        coeff_bits);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
@@ -73,6 +153,22 @@ int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int
     if (n_frames < 2) return SLGC_OK;
     HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, 8 * (size_t)(n_frames - 1), ctx->stream));
     if (elems == 0) return SLGC_OK;
+    if (dtype == SLGC_U8 && thresh == thresh) {                      // integer differences: |d| > thresh <=> |d| >= floor(thresh) + 1
+        if (thresh < 0.0) {                                              // every pixel counts
+            hipLaunchKernelGGL(k_fill_u64, dim3((n_frames + 254) / 256), dim3(256), 0, ctx->stream, d_counts, n_frames - 1, (unsigned long long)elems);
+            HIP_TRY(ctx, hipGetLastError());
+            return SLGC_OK;
+        }
+        if (thresh >= 255.0) return SLGC_OK;                             // none can
+        const unsigned t = (unsigned)thresh;                             // floor, 0..254
+        if (elems % 16 == 0 && ((uintptr_t)d_frames & 15) == 0 && (size_t)(n_frames - 1) * 4 <= 48 * 1024) {
+            const size_t chunks = elems / 16;
+            hipLaunchKernelGGL(k_frame_diff_u8x16, dim3((unsigned)((chunks + 255) / 256)), dim3(256), (size_t)(n_frames - 1) * 4, ctx->stream,
+                               (const uint4 *)d_frames, chunks, n_frames, (0x7fffu - t) * 0x00010001u, d_counts);
+            HIP_TRY(ctx, hipGetLastError());
+            return SLGC_OK;
+        }
+    }
     const unsigned bx = (unsigned)((elems + 256 * 8 - 1) / (256 * 8) < 1024 ? (elems + 256 * 8 - 1) / (256 * 8) : 1024);
     const dim3 grid(bx ? bx : 1, n_frames - 1);
     if (dtype == SLGC_U8)

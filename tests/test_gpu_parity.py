@@ -1022,6 +1022,20 @@ def test_remove_bad_images_and_diff_counts(ctx):
     big = rng.integers(0, 256, (5, 301, 517, 3), dtype=np.uint8)
     assert np.array_equal(ctx.frame_diff_counts(big, 50), onp.frame_diff_counts(big, 50))
     assert ctx.frame_diff_counts(big[:1], 50).shape == (0,)
+    # the 16-pixels-per-lane kernel (uint8, a multiple of 16 pixels per frame) against the generic one and NumPy, every kind of threshold
+    fr = rng.integers(0, 256, (9, 64, 112), dtype=np.uint8)
+    fr[3], fr[4] = 0, 255                                                    # the extreme differences, both signs
+    fr[6] = fr[5]                                                            # and none at all
+    fr[7, :, ::2] = np.where(fr[6, :, ::2] > 128, fr[6, :, ::2] - 51, fr[6, :, ::2] + 51)   # exactly threshold + 1 / on odd and even bytes
+    fr[7, :, 1::2] = np.where(fr[6, :, 1::2] > 128, fr[6, :, 1::2] - 50, fr[6, :, 1::2] + 50)
+    for thresh in (-1.0, 0.0, 0.5, 1.0, 49.9, 50.0, 50.5, 127.0, 254.0, 254.5, 255.0, 300.0, float("nan")):
+        ref = onp.frame_diff_counts(fr, thresh)
+        assert np.array_equal(ctx.frame_diff_counts(fr, thresh), ref), thresh
+        assert np.array_equal(ctx.frame_diff_counts(fr[:, :, :111], thresh), onp.frame_diff_counts(fr[:, :, :111], thresh)), thresh   # generic kernel
+        assert np.array_equal(ctx.frame_diff_counts(fr.astype(np.float64), thresh), ref), thresh
+    assert np.array_equal(ctx.frame_diff_counts(fr[:2], 50), onp.frame_diff_counts(fr[:2], 50))
+    many = rng.integers(0, 256, (70, 16, 16), dtype=np.uint8)                # more pairs than lanes in a wave
+    assert np.array_equal(ctx.frame_diff_counts(many, 50), onp.frame_diff_counts(many, 50))
 
 
 def test_to_gray_fixed_point_luma(ctx):
