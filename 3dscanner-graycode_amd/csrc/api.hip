@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "slgc_internal.h"
+#include "tri_math.h"
 
 // ------------------------------------------------------------------------------------------ helpers
 int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...)
@@ -226,6 +227,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
+    ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;
@@ -248,6 +250,7 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     for (int i = 0; i < SLGC_WS_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
+    if (ctx->lut_nodes) (void)hipFree(ctx->lut_nodes);
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
     if (ctx->count_slots) (void)hipFree(ctx->count_slots);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -272,6 +275,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
+    else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG
     else if (!strcmp(name, "fuse_abl")) ctx->tune_fuse_abl = value;
@@ -993,6 +997,18 @@ extern "C" int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (rows < 0 || W < 0 || proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad band / projector size");
     return ensure_luts(ctx, rows, W, row0, proj_w, proj_h);
+}
+
+extern "C" int slgc_ray_table_info(slgc_ctx *ctx, int *in_use, double *max_err)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (in_use) {
+        const int w = ctx->lut_cam_W;
+        *in_use = SLGC_CAM_NODES_FOR(ctx, w, true).nodes ? 1 : 0;
+    }
+    if (max_err) *max_err = ctx->lut_cam ? (double)ctx->lut_nodes_err : -1.0;
+    return SLGC_OK;
 }
 
 extern "C" int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,

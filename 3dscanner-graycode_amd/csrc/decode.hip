@@ -237,6 +237,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 struct FuseArgs {            // triangulation appended to the decode kernel (slgc_scan_dev)
     const float2 *cam_lut;    // [npix] camera rays of this band
+    CamNodes cn;              // the same rays at every 4th column (cn.nodes == nullptr: read cam_lut)
     const float2 *proj_lut;   // 8x8-tiled projector rays
     float *xyz;               // [npix][3]
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
@@ -588,9 +589,16 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         uint32_t idx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         float4 c01 = make_float4(0.f, 0.f, 0.f, 0.f), c23 = c01;
         if (live) {
-            const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));     // requested now, lands during the exchange
-            c01 = cl[0];
-            c23 = cl[1];
+            if (a.f.cn.nodes) {                        // the four nodes around the lane's pixels: requested now, land during the exchange
+                const float2 *e = cam_node_ptr(a.f.cn, off >> 2);
+                const cam_v4f n01 = *reinterpret_cast<const cam_v4f *>(e), n23 = *reinterpret_cast<const cam_v4f *>(e + 2);
+                c01 = make_float4(n01.x, n01.y, n01.z, n01.w);
+                c23 = make_float4(n23.x, n23.y, n23.z, n23.w);
+            } else {
+                const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
+                c01 = cl[0];
+                c23 = cl[1];
+            }
             const uint32_t hw2[2] = {wh_[0], wh_[1]}, vw2[2] = {wv_[0], wv_[1]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -627,7 +635,11 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
-        const float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
+        float fx[4] = {c01.x, c01.z, c23.x, c23.z}, fy[4] = {c01.y, c01.w, c23.y, c23.w};
+        if (a.f.cn.nodes) {
+            cam_rays_from_nodes(cam_v4f{c01.x, c01.y, c01.z, c01.w}, cam_v4f{c23.x, c23.y, c23.z, c23.w}, fx, fy);
+            if (live) cam_rays_exact_where_tiny(fx, fy, a.f.cam_lut + off);
+        }
         triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
@@ -948,6 +960,8 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + npix4);
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
     b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
+    const int lut_w = ctx->lut_cam_W;
+    b.f.cn = SLGC_CAM_NODES_FOR(ctx, lut_w, cam_lut == ctx->lut_cam && npix4 / 4 < (1u << 24));
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
     b.f.nt_store = ctx->tune_fuse_nt;
     b.f.wave_tail = ctx->tune_fuse_tail;

@@ -56,6 +56,7 @@ struct slgc_ctx {
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
+    int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
     void *stage;            // pinned host staging (float64 stacks narrowed to uint8 before the upload)
@@ -67,6 +68,8 @@ struct slgc_ctx {
     unsigned calib_ver;
     // ray tables (triangulate.hip), rebuilt when the calibration or the geometry changes
     void *lut_cam, *lut_proj;
+    void *lut_nodes;        // camera rays at every 4th column (tri_math.h CamNodes), nullptr when not built / not accurate enough
+    float lut_nodes_err;    // max |interpolated - exact| / max(1, |exact|) over the band the table was built for
     void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
     unsigned lut_cam_ver, lut_proj_ver;
     int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h, lut_proj_tile;
@@ -189,6 +192,16 @@ inline int xcd_env(const char *name, int dflt)
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+struct CamNodes;
+// The node table of the band ensure_luts() last built (tri_math.h), or an empty one (kernels then read the per-pixel table).
+// tune_cam_nodes 1 (default) = when it pays: a per-pixel table of more than 64 MB streams from HBM on every scan, a smaller one stays in
+// the 256 MB Infinity Cache between scans and the node table only adds arithmetic (measured: 4096x3000 -1.3 % fused / -4.5 % two-kernel
+// step, 1920x1080 and 1280x720 +2 %); 2 = whenever it is accurate enough (tests); 0 = never.
+#define SLGC_CAM_NODES_FOR(ctx, W, allow)                                                                                                   \
+    (((allow) && (ctx)->lut_nodes && (ctx)->lut_cam_W == (W) &&                                                                            \
+      ((ctx)->tune_cam_nodes == 2 || ((ctx)->tune_cam_nodes == 1 && (size_t)(ctx)->lut_cam_rows * (size_t)(W) * 8u > (64u << 20))))        \
+         ? CamNodes{(const float2 *)(ctx)->lut_nodes, (uint32_t)((W) / 4), (uint32_t)((W) / 4 + 3), 1.0f / (float)((W) / 4)}              \
+         : CamNodes{nullptr, 1u, 1u, 1.0f})
 inline uint32_t xcd_chunk_for(const slgc_ctx *ctx, unsigned blocks)
 {
     return (ctx->tune_xcd && blocks >= 64) ? blocks / 8 : 0u;

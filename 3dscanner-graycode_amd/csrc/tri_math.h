@@ -147,6 +147,69 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
     }
 }
 
+// ---- camera rays from a table kept at every 4th column (CamNodes) ----
+// The camera ray table is the largest non-algorithmic stream of the scan kernels (8 B / pixel).  Along a row the ray is a smooth function of
+// x, so the kernels can read NODES at x = -4, 0, 4, ..., W + 4 of every row (2 B / pixel) and put the cubic through the four nodes around
+// a lane's 4-pixel group: pixel 4g + j, j = 1..3, = e0 + (Lm[j] dm + L1[j] d1 + L2[j] d2) with the differences dm = e(-1) - e0, d1 = e1 - e0,
+// d2 = e2 - e0 and the Lagrange weights at t = j / 4 (exact binary fractions); pixel 4g is the node itself.  Forming the small correction
+// first and adding it to e0 last keeps the float32 result within 1 ulp of the exactly evaluated float32 ray (ensure_luts measures the
+// difference over every pixel of the calibration and falls back to the full table when it is too large); the truncation error of the
+// cubic is < 2e-9 for the reference's lenses.  Flat pixels (triangulate4's rare path) and lanes whose rays cross zero
+// (cam_rays_exact_where_tiny) still read the exact per-pixel table.
+struct CamNodes {
+    const float2 *nodes;      // [rows][ne], ne = W / 4 + 3: node n of a row sits at x = 4 (n - 1);  nullptr = use the per-pixel table
+    uint32_t w4, ne;          // 4-pixel groups per row, nodes per row
+    float inv_w4;
+};
+
+__device__ __forceinline__ const float2 *cam_node_ptr(const CamNodes &cn, uint32_t g)      // g = linear 4-pixel group index in the band
+{
+    uint32_t row = (uint32_t)((float)g * cn.inv_w4);                                        // g < 2^24: exact in float32; fix the quotient
+    int32_t gx = (int32_t)(g - row * cn.w4);
+    if (gx < 0) {
+        --row;
+        gx += (int32_t)cn.w4;
+    } else if ((uint32_t)gx >= cn.w4) {
+        ++row;
+        gx -= (int32_t)cn.w4;
+    }
+    return cn.nodes + (size_t)row * cn.ne + (uint32_t)gx;
+}
+
+typedef float cam_v4f __attribute__((ext_vector_type(4), aligned(8)));                    // two nodes; a node pair starts on any 8-byte boundary
+
+// n01 = nodes (-1, 0), n23 = nodes (1, 2) around the group, as loaded from cam_node_ptr()[0..3]
+__device__ __forceinline__ void cam_rays_from_nodes(const cam_v4f &n01, const cam_v4f &n23, float (&cx)[4], float (&cy)[4])
+{
+    constexpr float Lm[3] = {-0.0546875f, -0.0625f, -0.0390625f}, L1[3] = {0.2734375f, 0.5625f, 0.8203125f}, L2[3] = {-0.0390625f, -0.0625f, -0.0546875f};
+    const float ex = n01.z, ey = n01.w;
+    const float dmx = n01.x - ex, dmy = n01.y - ey, d1x = n23.x - ex, d1y = n23.y - ey, d2x = n23.z - ex, d2y = n23.w - ey;
+    cx[0] = ex;
+    cy[0] = ey;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        cx[j] = ex + fmaf(L2[j - 1], d2x, fmaf(L1[j - 1], d1x, Lm[j - 1] * dmx));
+        cy[j] = ey + fmaf(L2[j - 1], d2y, fmaf(L1[j - 1], d1y, Lm[j - 1] * dmy));
+    }
+}
+
+// X = cx * s and Y = cy * s inherit the RELATIVE error of the ray component, and an interpolated component is only good to an absolute
+// ~1e-9 where the ray crosses zero (a handful of columns / rows of the image): a lane with a component below kCamNodeTiny takes its four
+// rays from the exact per-pixel table instead (cam4 = the lane's first pixel there).  ensure_luts checks both error measures.
+constexpr float kCamNodeTiny = 1e-3f;
+
+__device__ __forceinline__ void cam_rays_exact_where_tiny(float (&cx)[4], float (&cy)[4], const float2 *__restrict__ cam4)
+{
+    float m = fminf(fabsf(cx[0]), fabsf(cy[0]));
+#pragma unroll
+    for (int j = 1; j < 4; ++j) m = fminf(m, fminf(fabsf(cx[j]), fabsf(cy[j])));
+    if (m < kCamNodeTiny) {
+        const float4 c01 = reinterpret_cast<const float4 *>(cam4)[0], c23 = reinterpret_cast<const float4 *>(cam4)[1];
+        cx[0] = c01.x, cy[0] = c01.y, cx[1] = c01.z, cy[1] = c01.w;
+        cx[2] = c23.x, cy[2] = c23.y, cx[3] = c23.z, cy[3] = c23.w;
+    }
+}
+
 // The projector table is stored in tiles of 8 rows so that a wave's gather stays within a few cache lines whichever way the
 // decoded projector coordinates drift along a camera row.  wide = 0: 8x8-pixel tiles (512 B, a tile row is half a 128-byte line);
 // wide = 1: 16x8-pixel tiles (1 KB, a tile row is exactly one 128-byte line).  tiles_x counts tiles of the chosen width.

@@ -185,6 +185,42 @@ __global__ void __launch_bounds__(256) k_build_cam_lut(const Calib c, float2 *__
     lut[p] = make_float2(a.x, a.y);
 }
 
+// CamNodes table (tri_math.h): the exact rays at x = 4 (n - 1), n = 0 .. W / 4 + 2, of every row of the band
+__global__ void __launch_bounds__(256) k_build_cam_nodes(const Calib c, float2 *__restrict__ nodes, int ne, int row0, size_t total)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int n = (int)(p % (size_t)ne), row = (int)(p / (size_t)ne);
+    const Ray2 a = undistort_point((float)(4 * (n - 1)), (float)(row0 + row), c.cam_k, c.cam_d, c.R);
+    nodes[p] = make_float2(a.x, a.y);
+}
+
+// ... and how far the rays the kernels will interpolate from it are from the per-pixel table: max over the band of the error measure
+// below, as float bits through atomicMax (non-negative floats order like unsigned integers)
+__global__ void __launch_bounds__(256) k_check_cam_nodes(const float2 *__restrict__ lut, CamNodes cn, size_t ngroups, unsigned *__restrict__ worst)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float err = 0.0f;
+    if (g < ngroups) {
+        const float2 *e = cam_node_ptr(cn, (uint32_t)g);
+        const cam_v4f n01 = *reinterpret_cast<const cam_v4f *>(e), n23 = *reinterpret_cast<const cam_v4f *>(e + 2);
+        float cx[4], cy[4];
+        cam_rays_from_nodes(n01, n23, cx, cy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 t = lut[4 * g + j];
+            // two measures in one number (accepted when <= 2.4e-7): the direction error against 2 ulp of a float32 in [1, 2), and the
+            // relative error of a component the kernels will use (>= kCamNodeTiny, see cam_rays_exact_where_tiny) against 4e-6
+            const float ax = fabsf(cx[j] - t.x), ay = fabsf(cy[j] - t.y);
+            const float ex = fmaxf(ax / fmaxf(1.0f, fabsf(t.x)), (2.4e-7f / 4e-6f) * ax / fmaxf(kCamNodeTiny, fabsf(t.x)));
+            const float ey = fmaxf(ay / fmaxf(1.0f, fabsf(t.y)), (2.4e-7f / 4e-6f) * ay / fmaxf(kCamNodeTiny, fabsf(t.y)));
+            err = fmaxf(err, !(ex == ex) || !(ey == ey) ? __builtin_huge_valf() : fmaxf(ex, ey));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
+    if ((threadIdx.x & 63) == 0 && err > 0.0f) atomicMax(worst, __float_as_uint(err));
+}
+
 __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
                                                         size_t nslots, int wide)
 {
@@ -221,7 +257,8 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
                                                               const uint32_t *__restrict__ wire, const float2 *__restrict__ cam_lut,
                                                               const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
-                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store, int wide)
+                                                              unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store, int wide,
+                                                              const CamNodes cn)
 {
     __shared__ uint4 s_idx[256];
     __shared__ float4 s_buf[768];
@@ -241,8 +278,15 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             hw = reinterpret_cast<const uint2 *>(h)[g];
             vw = reinterpret_cast<const uint2 *>(v)[g];
         }
-        c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g];
-        c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
+        if (cn.nodes) {                                    // four nodes around the group instead of the group's four rays
+            const float2 *e = cam_node_ptr(cn, (uint32_t)g);
+            const cam_v4f n01 = *reinterpret_cast<const cam_v4f *>(e), n23 = *reinterpret_cast<const cam_v4f *>(e + 2);
+            c01 = make_float4(n01.x, n01.y, n01.z, n01.w);
+            c23 = make_float4(n23.x, n23.y, n23.z, n23.w);
+        } else {
+            c01 = reinterpret_cast<const float4 *>(cam_lut)[2 * g];
+            c23 = reinterpret_cast<const float4 *>(cam_lut)[2 * g + 1];
+        }
         const unsigned hq[2] = {hw.x, hw.y}, vq[2] = {vw.x, vw.y};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -271,7 +315,11 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                            (idx[3] != 0xffffffffu ? 8u : 0u);
     const unsigned nvalid = __builtin_popcount(valid);
-    const float cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+    float cx[4] = {c01.x, c01.z, c23.x, c23.z}, cy[4] = {c01.y, c01.w, c23.y, c23.w};
+    if (cn.nodes) {
+        cam_rays_from_nodes(cam_v4f{c01.x, c01.y, c01.z, c01.w}, cam_v4f{c23.x, c23.y, c23.z, c23.w}, cx, cy);
+        if (live) cam_rays_exact_where_tiny(cx, cy, cam_lut + 4 * g);
+    }
     if constexpr (MODE == SLGC_TRI_EXACT) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -397,6 +445,35 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
                            row0, npix);
         HIP_TRY(ctx, hipGetLastError());
         ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
+        // the every-4th-column table of the same band, kept only if the rays interpolated from it stay within 2 ulp of the exact ones
+        if (ctx->lut_nodes) {
+            HIP_TRY(ctx, hipFree(ctx->lut_nodes));
+            ctx->lut_nodes = nullptr;
+        }
+        ctx->lut_nodes_err = -1.0f;
+        if (W % 4 == 0 && W >= 4 && npix / 4 < (1u << 24)) {
+            const int ne = W / 4 + 3;
+            const size_t total = (size_t)rows * ne;
+            void *worst;
+            int rc = slgc_ws(ctx, 7, 64, &worst);
+            if (rc) return rc;
+            if (hipMalloc(&ctx->lut_nodes, total * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera node table");
+            HIP_TRY(ctx, hipMemsetAsync(worst, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_build_cam_nodes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)ctx->lut_nodes, ne,
+                               row0, total);
+            const CamNodes cn{(const float2 *)ctx->lut_nodes, (uint32_t)(W / 4), (uint32_t)ne, 1.0f / (float)(W / 4)};
+            hipLaunchKernelGGL(k_check_cam_nodes, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float2 *)ctx->lut_cam, cn,
+                               npix / 4, (unsigned *)worst);
+            HIP_TRY(ctx, hipGetLastError());
+            float err = 0.0f;
+            HIP_TRY(ctx, hipMemcpyAsync(&err, worst, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->lut_nodes_err = err;
+            if (!(err <= 2.4e-7f)) {                     // 2 ulp of a float32 in [1, 2): this lens is not smooth enough at 4-pixel nodes
+                HIP_TRY(ctx, hipFree(ctx->lut_nodes));
+                ctx->lut_nodes = nullptr;
+            }
+        }
     }
     if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h && ctx->lut_proj_tile == wide)) {
         if (ctx->lut_proj) {
@@ -461,17 +538,19 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")
+        // the exact float64 mode keeps the exact per-pixel rays; the fast form may interpolate them from the node table
+        const CamNodes cn = SLGC_CAM_NODES_FOR(ctx, W, mode != SLGC_TRI_EXACT);
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #ifdef SLGC_DIAG      // A/B of the guard's cost: only in the diagnostic build
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
             hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #endif
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;

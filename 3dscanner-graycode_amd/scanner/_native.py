@@ -81,6 +81,7 @@ SIGNATURES = {
     "slgc_prof_end": (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     "slgc_prof_samples": (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     "slgc_build_ray_tables_dev": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "slgc_ray_table_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_d)]),
     "slgc_guard_count_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "slgc_comm_unique_id": (_i, [_vp]),
     "slgc_comm_init": (_i, [_vp, _i, _i, _vp]),
@@ -539,6 +540,12 @@ class Context:
     def build_ray_tables_dev(self, rows, W, row0, proj_size):
         """Per-calibration ray tables of the dense path (asynchronous); built on first use otherwise."""
         self._ck(lib().slgc_build_ray_tables_dev(self._h, int(rows), int(W), int(row0), int(proj_size[0]), int(proj_size[1])))
+
+    def ray_table_info(self):
+        """-> (node table in use, max relative difference between the rays interpolated from it and the exact ones; -1.0 if none was built)."""
+        use, err = C.c_int(), C.c_double()
+        self._ck(lib().slgc_ray_table_info(self._h, C.byref(use), C.byref(err)))
+        return bool(use.value), err.value
 
     def guard_count_dev(self, d_h: int, d_v: int, rows, W, row0, proj_size, d_counts: int):
         """d_counts[0] += decodable pixels, d_counts[1] += pixels on the guarded (float32-mirror) triangulation path."""

@@ -499,6 +499,10 @@ def run_rank(args, rank, local_rank, world):
                        "luts_hoisted_us": round(luts_us, 1),
                        "luts_hoisted_note": "per-calibration ray tables (both cv2.undistortPoints calls on integer pixel coordinates) built once "
                                             "before the timed region, not per scan",
+                       "camera_rays": (lambda use, err: {"node_table_in_use": use, "node_table_error_vs_limit_2.4e-7": err,
+                                                         "note": "per-pixel table 8 B/pixel, or (bands above 64 MB of rays) the every-4th-column "
+                                                                 "table 2 B/pixel + a cubic through 4 nodes per 4-pixel group; flat triangles and "
+                                                                 "zero-crossing rays always read the exact per-pixel table"})(*ctx.ray_table_info()),
                        "guard_flagged_pixels": flagged,
                        "guard_note": "decodable pixels of one scan that triangulation redoes on the reference's float32 intermediates (flat triangles)"},
             "roofline": kernel_roofline(main_pipeline, dec_ms, dec_n, dec_samples),

@@ -62,13 +62,17 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
-/* Tuning knobs for same-process A/B timing; no setting changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
+/* Tuning knobs for same-process A/B timing; no setting but the last one named here changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
  * "park" 1 = at 42 / 44 / 46 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
  * 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte wire format / 0 = int16 (default;
  * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default 3);
- * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1).  Defaults can also be set with the environment
- * (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD), read when the context is created. */
+ * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1).  The one knob that is NOT bit-neutral: "cam_nodes"
+ * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
+ * to stay in the Infinity Cache between scans (> 64 MB; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
+ * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
+ * Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD,
+ * SLGC_CAM_NODES), read when the context is created. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
@@ -202,6 +206,13 @@ int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *
  * into two ray tables.  slgc_scan_dev / slgc_triangulate_maps_dev build them on first use; this entry point builds them
  * explicitly (asynchronous, on the context's stream) so that a caller -- and bench.py -- can place and time that one-off cost. */
 int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
+/* The camera table exists twice: per pixel (exact float32 rays, 8 B / pixel) and at every 4th column (2 B / pixel), from which the scan
+ * kernels' fast form interpolates each row's rays with a cubic through four nodes -- kept only when, over every pixel of the band, the
+ * interpolated ray stays within 2 float32 ulp (of a number in [1, 2)) of the exact one and every component of at least 1e-3 within 4e-6
+ * of itself (flat triangles, lanes whose rays cross zero, and the exact mode always read the per-pixel table).
+ * *in_use = 1 if the kernels will read the node table for the tables built last (0: W % 4 != 0, too rough a lens, a band of at
+ * most 64 MB of rays under slgc_tune "cam_nodes" 1, or "cam_nodes" 0); *max_err = the measured error, in units where 2.4e-7 is the acceptance limit (-1 if no node table was built). */
+int slgc_ray_table_info(slgc_ctx *ctx, int *in_use, double *max_err);
 
 /* Diagnostic: d_counts[0] += decodable pixels of the band, d_counts[1] += those among them that the dense triangulation redoes
  * on the reference's float32 intermediates because the triangle is flat (tri_is_flat, csrc/tri_math.h) -- the guarded slow path. */

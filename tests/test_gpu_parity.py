@@ -857,6 +857,7 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
         pd = calib["proj_dist"] * float(rng.uniform(0.0, 1.5))
         Rm, T = rot_y(float(rng.uniform(-30, -10))), np.array([[float(rng.uniform(0.15, 0.4))], [float(rng.uniform(-0.05, 0.05))], [float(rng.uniform(-0.05, 0.08))]])
         ctx.set_calibration(K, cd, pk, pd, Rm, T)
+        ctx.tune("cam_nodes", 2 if case % 4 == 1 else 1)         # every other 4-aligned case: camera rays from the node table whenever it is accepted
         hp, vp, ref = oc.scan_dense(st, psize, K, cd, pk, pd, Rm, T)
         want = np.moveaxis(ref, 0, -1)
         ok = (hp != -1) & (vp != -1)
@@ -880,6 +881,7 @@ def test_scan_dev_fuzz_vs_oracle(ctx, calib):
                 worst[0] = max(worst[0], float(err.max()))
         for b in (stack, xyz, maps):
             b.free()
+    ctx.tune("cam_nodes", 1)
     print(f"cancelled form, worst elementwise relative error over the fuzz scans: {worst[0]:.3e}")
 
 

@@ -99,7 +99,8 @@ for cfg in configs:
     med = float(np.median(s))
     print("  " + " ".join(f"{k}={v}" for k, v in zip(names, cfg)) + f":  kernel median {med:7.2f} us  min {s[0]:7.2f}  p95 {s[int(0.95 * (len(s) - 1))]:7.2f}"
           f"  | step median {float(np.median(st)):7.2f} us min {st[0]:7.2f} | frac {per_px * px / (med * 1e-6) / 8e12:.3f} | digest {digests[cfg]}")
-if len(set(digests.values())) != 1:
+print("ray tables: node table in use %s, max relative difference of the interpolated rays %.3g" % ctx.ray_table_info())
+if len(set(digests.values())) != 1 and "cam_nodes" not in names:      # cam_nodes is the one knob that is not bit-neutral (include/slgc.h)
     print("RESULTS DIFFER BETWEEN CONFIGURATIONS")
     sys.exit(1)
 ctx.close()

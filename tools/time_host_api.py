@@ -4,7 +4,8 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3dscanner-graycode_amd")); sys.path.insert(0, ROOT)
-from scanner import _native, scan_to_cloud
+from scanner import _native
+from scanner.pipeline import scan_to_cloud
 import bench
 for (W, H, PW, PH, N) in ((1920, 1080, 1920, 1080, 44), (4096, 3000, 1920, 1200, 44)):
     ctx = _native.Context(0)
