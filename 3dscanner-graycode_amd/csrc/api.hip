@@ -1,6 +1,8 @@
 // api.hip -- the C-ABI of libslgc.so (declared in include/slgc.h): context, device memory, and the host-buffer
 // entry points that mirror the reference's Python functions.  No CPU fallback anywhere: every entry point runs HIP
 // kernels on the context's device or returns an error.
+#include <sys/mman.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -141,6 +143,85 @@ int host_staging(slgc_ctx *ctx, size_t bytes, void **out)
     return SLGC_OK;
 }
 
+// ---- large results into memory nobody has touched yet ----
+// The reference-shaped entry points return fresh NumPy arrays.  A hipMemcpy into such memory runs at the page-fault rate of one thread
+// (measured on the MI355X host: 197 MB of int64 maps in 17.0 ms = 11.6 GB/s, the same as np.empty + fill; the link does 55 GB/s).  So
+// results of 8 MB and more land in a pinned ring of 4 x 16 MB instead, and host threads copy every landed chunk into its slice of the
+// destination -- the first touches spread over the threads, the next chunk already on the link.  Synchronous: returns with dst complete.
+constexpr size_t kDlChunk = 16u << 20;
+constexpr int kDlSlots = 4;
+
+int download_par(slgc_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (bytes == 0 || !dst) return SLGC_OK;
+    static const int par = xcd_env("SLGC_PAR_DOWNLOAD", 1);              // 0: plain hipMemcpy (A/B)
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthr = (int)(hw ? (hw > 16 ? 16 : hw) : 4);
+    bool pinned = false;                                                   // page-locked destination (slgc_host_alloc): the DMA engine writes it directly
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, dst) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                                      // ordinary memory is "invalid value" to the runtime: not an error here
+    }
+    if (pinned || !par || bytes < (8u << 20) || nthr < 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return SLGC_OK;
+    }
+    if (!ctx->dl_stage) {
+        if (hipHostMalloc(&ctx->dl_stage, kDlSlots * kDlChunk, hipHostMallocDefault) != hipSuccess)
+            return slgc_fail(ctx, SLGC_ENOMEM, "hipHostMalloc(%zu) failed", (size_t)kDlSlots * kDlChunk);
+        for (int i = 0; i < kDlSlots; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->dl_ev[i], hipEventDisableTiming));
+    }
+    const size_t nchunks = (bytes + kDlChunk - 1) / kDlChunk;
+    const int parts = 8;                                                   // 2 MB slices of a chunk: one transparent huge page each, where the kernel grants them
+    {
+        const uintptr_t lo = ((uintptr_t)dst + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), hi = ((uintptr_t)dst + bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);  // fewer, larger first-touch faults; a no-op where THP is off
+    }
+    std::vector<std::atomic<int>> done(nchunks);
+    for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<size_t> ready{0}, next{0};
+    std::atomic<bool> failed{false};
+    char *stage = (char *)ctx->dl_stage;
+    auto work = [&]() {
+        for (;;) {
+            const size_t task = next.fetch_add(1, std::memory_order_relaxed);
+            const size_t c = task / (size_t)parts, part = task % (size_t)parts;
+            if (c >= nchunks) return;
+            while (ready.load(std::memory_order_acquire) <= c) {
+                if (failed.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t n = c + 1 < nchunks ? kDlChunk : bytes - c * kDlChunk;
+            const size_t per = kDlChunk / parts;
+            const size_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n;
+            if (hi > lo && par != 2) memcpy((char *)dst + c * kDlChunk + lo, stage + (c % kDlSlots) * kDlChunk + lo, hi - lo);   // par == 2: transfers only (timing)
+            done[c].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
+    hipError_t err = hipSuccess;
+    for (size_t k = 0; k < nchunks && err == hipSuccess; ++k) {
+        if (k >= (size_t)kDlSlots)                                         // the slot's previous chunk must have left it
+            while (done[k - kDlSlots].load(std::memory_order_acquire) < parts) std::this_thread::yield();
+        const size_t n = k + 1 < nchunks ? kDlChunk : bytes - k * kDlChunk;
+        err = hipMemcpyAsync(stage + (k % kDlSlots) * kDlChunk, (const char *)d_src + k * kDlChunk, n, hipMemcpyDeviceToHost, ctx->stream);
+        if (err == hipSuccess) err = hipEventRecord(ctx->dl_ev[k % kDlSlots], ctx->stream);
+        if (err == hipSuccess && k >= 1) {
+            err = hipEventSynchronize(ctx->dl_ev[(k - 1) % kDlSlots]);
+            if (err == hipSuccess) ready.store(k, std::memory_order_release);
+        }
+    }
+    if (err == hipSuccess) err = hipEventSynchronize(ctx->dl_ev[(nchunks - 1) % kDlSlots]);
+    if (err == hipSuccess) ready.store(nchunks, std::memory_order_release);
+    else failed.store(true);
+    for (auto &t : pool) t.join();
+    if (err != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "download: %s", hipGetErrorString(err));
+    return SLGC_OK;
+}
+
 // Upload n_runs host stacks into workspace slot 0 back to back.  *dtype is in/out: a float64 stack that narrows to uint8 (above)
 // is uploaded as uint8 (1/8 of the bytes, from pinned memory) and *dtype becomes SLGC_U8 for the kernels that follow.
 int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs, int N, size_t npix, RunPtrs *out)
@@ -251,6 +332,10 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
     if (ctx->lut_nodes) (void)hipFree(ctx->lut_nodes);
+    if (ctx->dl_stage) {
+        (void)hipHostFree(ctx->dl_stage);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->dl_ev[i]);
+    }
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
     if (ctx->count_slots) (void)hipFree(ctx->count_slots);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
@@ -324,8 +409,8 @@ extern "C" int slgc_direct_indirect(slgc_ctx *ctx, const void *stack, int dtype,
                                nullptr, nullptr);
     if (rc) return rc;
     if (npix) {
-        HIP_TRY(ctx, hipMemcpyAsync(L_d, d_ld, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(L_g, d_lg, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = download_par(ctx, L_d, d_ld, npix * 8))) return rc;
+        if ((rc = download_par(ctx, L_g, d_lg, npix * 8))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -362,8 +447,8 @@ static int codes_common(slgc_ctx *ctx, const void *stack, int dtype, int N, int 
                                nullptr);
     if (rc) return rc;
     if (npix) {
-        HIP_TRY(ctx, hipMemcpyAsync(h_codes, d_hc, (size_t)g.L * npix, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v_codes, d_vc, (size_t)g.L * npix, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = download_par(ctx, h_codes, d_hc, (size_t)g.L * npix))) return rc;
+        if ((rc = download_par(ctx, v_codes, d_vc, (size_t)g.L * npix))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -403,8 +488,8 @@ extern "C" int slgc_codes_to_pixels(slgc_ctx *ctx, const int8_t *h_codes, const 
     }
     if ((rc = launch_codes_to_pixels(ctx, d_hc, d_vc, n_runs, L, npix, d_h, d_v))) return rc;
     if (npix) {
-        HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_v, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = download_par(ctx, h_pixels, d_h, npix * 8))) return rc;
+        if ((rc = download_par(ctx, v_pixels, d_v, npix * 8))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -441,8 +526,8 @@ extern "C" int slgc_decode(slgc_ctx *ctx, const void *const *stacks, int dtype, 
     }
     if (rc) return rc;
     if (npix) {
-        HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_v, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = download_par(ctx, h_pixels, d_h, npix * 8))) return rc;
+        if ((rc = download_par(ctx, v_pixels, d_v, npix * 8))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -527,9 +612,9 @@ extern "C" int slgc_cam_proj_pts_fetch(slgc_ctx *ctx, float *cam_pts, float *pro
     const double *d_colors = (const double *)d_out;
     const float *d_cam = (const float *)(d_out + (ctx->pend_colors ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
     if (M) {
-        if (cam_pts) HIP_TRY(ctx, hipMemcpyAsync(cam_pts, d_cam, M * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (proj_pts) HIP_TRY(ctx, hipMemcpyAsync(proj_pts, d_proj, M * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (colors && ctx->pend_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_colors, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+        if (cam_pts && (rc = download_par(ctx, cam_pts, d_cam, M * 8))) return rc;
+        if (proj_pts && (rc = download_par(ctx, proj_pts, d_proj, M * 8))) return rc;
+        if (colors && ctx->pend_colors && (rc = download_par(ctx, colors, d_colors, M * 24))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -550,7 +635,7 @@ extern "C" int slgc_triangulate(slgc_ctx *ctx, const float *cam_pts, const float
     HIP_TRY(ctx, hipMemcpyAsync(d_cam, cam_pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_proj, proj_pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_triangulate_list(ctx, d_cam, d_proj, M, mode, (double *)d_out))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(xyz, d_out, (size_t)M * 24, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download_par(ctx, xyz, d_out, (size_t)M * 24))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pend_M = -1;  // slot 6 was reused
     return SLGC_OK;
@@ -568,7 +653,7 @@ extern "C" int slgc_undistort_points(slgc_ctx *ctx, int which, const float *pts,
     if ((rc = slgc_ws(ctx, 6, (size_t)M * 8, &d_out))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_in, pts, (size_t)M * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_undistort_list(ctx, which, (const float *)d_in, M, (float *)d_out))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download_par(ctx, out, d_out, (size_t)M * 8))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }
@@ -616,8 +701,8 @@ extern "C" int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_
     const size_t K = (size_t)ctx->filt_M;
     const double *d_xo = (const double *)ctx->ws[6], *d_co = d_xo + 3 * K;
     if (K) {
-        if (xyz_out) HIP_TRY(ctx, hipMemcpyAsync(xyz_out, d_xo, K * 24, hipMemcpyDeviceToHost, ctx->stream));
-        if (colors_out && ctx->filt_colors) HIP_TRY(ctx, hipMemcpyAsync(colors_out, d_co, K * 24, hipMemcpyDeviceToHost, ctx->stream));
+        if (xyz_out && (rc = download_par(ctx, xyz_out, d_xo, K * 24))) return rc;
+        if (colors_out && ctx->filt_colors && (rc = download_par(ctx, colors_out, d_co, K * 24))) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
@@ -636,7 +721,7 @@ extern "C" int slgc_to_gray(slgc_ctx *ctx, const uint8_t *bgr, int n_frames, int
     if ((rc = slgc_ws(ctx, 2, npix, &d_out))) return rc;
     if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_in, bgr, npix * 3, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)d_in, (uint8_t *)d_out, npix, coeff_bits))) return rc;
-    if (npix) HIP_TRY(ctx, hipMemcpyAsync(gray, d_out, npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (npix && (rc = download_par(ctx, gray, d_out, npix))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }
@@ -771,24 +856,24 @@ extern "C" int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_
     const size_t npix = ctx->pipe_npix, M = (size_t)ctx->pipe_M, Mr = (size_t)ctx->pipe_M_raw;
     const int64_t *d_h = (const int64_t *)ctx->ws[3];
     if (npix) {
-        if (h_pixels) HIP_TRY(ctx, hipMemcpyAsync(h_pixels, d_h, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (v_pixels) HIP_TRY(ctx, hipMemcpyAsync(v_pixels, d_h + npix, npix * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (h_pixels && (rc = download_par(ctx, h_pixels, d_h, npix * 8))) return rc;
+        if (v_pixels && (rc = download_par(ctx, v_pixels, d_h + npix, npix * 8))) return rc;
     }
     const char *d_corr = (const char *)ctx->ws[8];
     const double *d_colors = (const double *)d_corr;
     const float *d_cam = (const float *)(d_corr + (ctx->pipe_colors ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
     if (Mr) {
-        if (cam_pts) HIP_TRY(ctx, hipMemcpyAsync(cam_pts, d_cam, Mr * 8, hipMemcpyDeviceToHost, ctx->stream));      // unfiltered lists
-        if (proj_pts) HIP_TRY(ctx, hipMemcpyAsync(proj_pts, d_proj, Mr * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (cam_pts && (rc = download_par(ctx, cam_pts, d_cam, Mr * 8))) return rc;      // unfiltered lists
+        if (proj_pts && (rc = download_par(ctx, proj_pts, d_proj, Mr * 8))) return rc;
     }
     if (M) {
         if (ctx->pipe_filtered) {
             const double *d_fx = (const double *)ctx->ws[10];
-            if (xyz) HIP_TRY(ctx, hipMemcpyAsync(xyz, d_fx, M * 24, hipMemcpyDeviceToHost, ctx->stream));
-            if (colors && ctx->pipe_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_fx + 3 * M, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+            if (xyz && (rc = download_par(ctx, xyz, d_fx, M * 24))) return rc;
+            if (colors && ctx->pipe_colors && (rc = download_par(ctx, colors, d_fx + 3 * M, M * 24))) return rc;
         } else {
-            if (xyz) HIP_TRY(ctx, hipMemcpyAsync(xyz, ctx->ws[9], M * 24, hipMemcpyDeviceToHost, ctx->stream));
-            if (colors && ctx->pipe_colors) HIP_TRY(ctx, hipMemcpyAsync(colors, d_colors, M * 24, hipMemcpyDeviceToHost, ctx->stream));
+            if (xyz && (rc = download_par(ctx, xyz, ctx->ws[9], M * 24))) return rc;
+            if (colors && ctx->pipe_colors && (rc = download_par(ctx, colors, d_colors, M * 24))) return rc;
         }
     }
     if (M_unfiltered) *M_unfiltered = ctx->pipe_M_raw;
@@ -824,11 +909,32 @@ extern "C" int slgc_h2d(slgc_ctx *ctx, void *dst_dev, const void *src_host, size
     return SLGC_OK;
 }
 
+extern "C" int slgc_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return SLGC_EINVAL;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return SLGC_ENOMEM;
+    }
+    return SLGC_OK;
+}
+
+extern "C" int slgc_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return SLGC_EHIP;
+    }
+    return SLGC_OK;
+}
+
 extern "C" int slgc_d2h(slgc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bytes && (rc = download_par(ctx, dst_host, src_dev, bytes))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }
@@ -960,7 +1066,7 @@ extern "C" int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, in
     if ((rc = slgc_ws(ctx, 7, 64, &d_bad))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     if ((rc = launch_selftest_thresholds(ctx, eps, black_lo, black_hi - black_lo, (unsigned long long *)d_bad, skew))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download_par(ctx, mismatches, d_bad, 8))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }
@@ -974,7 +1080,7 @@ extern "C" int slgc_selftest_classify(slgc_ctx *ctx, int negative_control, unsig
     if ((rc = slgc_ws(ctx, 7, 64, &d_bad))) return rc;
     HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, 8, ctx->stream));
     if ((rc = launch_selftest_classify(ctx, (unsigned long long *)d_bad, negative_control ? 1 : 0))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(mismatches, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = download_par(ctx, mismatches, d_bad, 8))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SLGC_OK;
 }

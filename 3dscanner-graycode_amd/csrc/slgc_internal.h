@@ -59,6 +59,8 @@ struct slgc_ctx {
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
+    void *dl_stage;         // pinned ring the large device-to-host results land in (api.hip: download_par)
+    hipEvent_t dl_ev[4];
     void *stage;            // pinned host staging (float64 stacks narrowed to uint8 before the upload)
     size_t stage_bytes;
     int last_input_path;    // slgc_last_input_path

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "slgc_dev_free": (_i, [_vp, _vp]),
+    "slgc_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "slgc_host_free": (_i, [_vp]),
     "slgc_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "slgc_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "slgc_dev_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -133,6 +136,62 @@ def device_count() -> int:
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _PinnedPool:
+    """Page-locked blocks behind the large arrays the host-buffer API returns (slgc_host_alloc).  A result array is an ordinary
+    writable NumPy array over such a block; when the array and every view of it are gone the block goes back to the pool, so a
+    caller that processes scan after scan gets its results at the rate of the PCIe link instead of the page-fault rate of fresh
+    memory.  Blocks are cached up to SLGC_PINNED_POOL_MB (default 4096); SLGC_PINNED_OUTPUTS=0 returns plain np.empty arrays."""
+
+    MIN_BYTES = 8 << 20
+    GRANULE = 2 << 20
+
+    def __init__(self):
+        self.free = {}                      # rounded size -> [address, ...]
+        self.cached = 0
+        self.lock = threading.Lock()
+        self.enabled = os.environ.get("SLGC_PINNED_OUTPUTS", "1") != "0"
+        self.limit = int(os.environ.get("SLGC_PINNED_POOL_MB", "4096")) << 20
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if not self.enabled or nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        size = -(-nbytes // self.GRANULE) * self.GRANULE
+        with self.lock:
+            blocks = self.free.get(size)
+            addr = blocks.pop() if blocks else None
+            if addr is not None:
+                self.cached -= size
+        if addr is None:
+            p = C.c_void_p()
+            if lib().slgc_host_alloc(size, C.byref(p)) or not p.value:
+                return np.empty(shape, dtype)                     # no page-locked memory to be had: an ordinary array does the job
+            addr = p.value
+        raw = (C.c_char * nbytes).from_address(addr)
+        weakref.finalize(raw, self._release, addr, size)          # fires when the array and all its views are gone
+        return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def _release(self, addr, size):
+        with self.lock:
+            if self.cached + size <= self.limit:
+                self.free.setdefault(size, []).append(addr)
+                self.cached += size
+                return
+        try:
+            lib().slgc_host_free(addr)
+        except Exception:                                         # interpreter shutdown
+            pass
+
+
+_pool = _PinnedPool()
+
+
+def _out(shape, dtype=np.float64):
+    """A result array of the host-buffer API (see _PinnedPool)."""
+    return _pool.empty(shape, dtype)
 
 
 class DeviceBuffer:
@@ -285,7 +344,7 @@ class Context:
     def direct_indirect(self, images):
         st, dt = self._stack(images)
         N, H, W = st.shape
-        ld, lg = np.empty((H, W)), np.empty((H, W))
+        ld, lg = _out((H, W)), _out((H, W))
         self._ck(lib().slgc_direct_indirect(self._h, _ptr(st), dt, N, H, W, _ptr(ld), _ptr(lg)))
         return ld, lg
 
@@ -297,7 +356,7 @@ class Context:
         lg = np.ascontiguousarray(L_g, dtype=np.float64)
         if ld.shape != (H, W) or lg.shape != (H, W):
             raise ValueError("L_d / L_g must be [H,W]")
-        hc, vc = np.empty((L, H, W), np.int8), np.empty((L, H, W), np.int8)
+        hc, vc = _out((L, H, W), np.int8), _out((L, H, W), np.int8)
         self._ck(lib().slgc_is_lit(self._h, _ptr(st), dt, N, H, W, _ptr(ld), _ptr(lg), float(eps), float(m), _ptr(hc), _ptr(vc)))
         return hc, vc
 
@@ -305,7 +364,7 @@ class Context:
         st, dt = self._stack(images)
         N, H, W = st.shape
         L = int((N - 2) / 4)
-        hc, vc = np.empty((max(L, 0), H, W), np.int8), np.empty((max(L, 0), H, W), np.int8)
+        hc, vc = _out((max(L, 0), H, W), np.int8), _out((max(L, 0), H, W), np.int8)
         self._ck(lib().slgc_codes(self._h, _ptr(st), dt, N, H, W, float(eps), float(m), _ptr(hc), _ptr(vc)))
         return hc, vc
 
@@ -317,7 +376,7 @@ class Context:
         if hc.shape != vc.shape or hc.ndim != 4:
             raise ValueError("codes must be [L,H,W] or [R,L,H,W], same shape for h and v")
         R, L, H, W = hc.shape
-        hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+        hp, vp = _out((H, W), np.int64), _out((H, W), np.int64)
         self._ck(lib().slgc_codes_to_pixels(self._h, _ptr(hc), _ptr(vc), R, L, H, W, _ptr(hp), _ptr(vp)))
         return hp, vp
 
@@ -335,7 +394,7 @@ class Context:
         dt = dts.pop()
         N, H, W = prepared[0][0].shape
         ptrs = (C.c_void_p * len(prepared))(*[s.ctypes.data for s, _ in prepared])
-        hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+        hp, vp = _out((H, W), np.int64), _out((H, W), np.int64)
         self._ck(lib().slgc_decode(self._h, ptrs, dt, len(prepared), N, H, W, float(eps), float(m), _ptr(hp), _ptr(vp)))
         return hp, vp
 
@@ -365,8 +424,8 @@ class Context:
         self._ck(lib().slgc_cam_proj_pts_count(self._h, _ptr(h), _ptr(v), cw, ch, int(proj_size[0]), int(proj_size[1]),
                                                _ptr(wh), int(order), C.byref(M)))
         n = M.value
-        cam, proj = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32)
-        col = np.empty((n, 3), np.float64) if wh is not None else None
+        cam, proj = _out((n, 2), np.float32), _out((n, 2), np.float32)
+        col = _out((n, 3), np.float64) if wh is not None else None
         self._ck(lib().slgc_cam_proj_pts_fetch(self._h, _ptr(cam), _ptr(proj), _ptr(col)))
         return cam, proj, col
 
@@ -375,7 +434,7 @@ class Context:
         b = np.ascontiguousarray(np.asarray(proj_pts, dtype=np.float32).reshape(-1, 2))
         if a.shape != b.shape:
             raise ValueError("cam_pts and proj_pts must have the same length")
-        xyz = np.empty((3, len(a)), np.float64)
+        xyz = _out((3, len(a)), np.float64)
         self._ck(lib().slgc_triangulate(self._h, _ptr(a), _ptr(b), len(a), int(mode), _ptr(xyz)))
         return xyz
 
@@ -396,8 +455,8 @@ class Context:
             raise ValueError("colors must be (M,3)")
         kept = C.c_int64()
         self._ck(lib().slgc_filter_count(self._h, _ptr(x), _ptr(c), M, float(threshold), C.byref(kept)))
-        xo = np.empty((3, kept.value), np.float64)
-        co = None if c is None else np.empty((kept.value, 3), np.float64)
+        xo = _out((3, kept.value), np.float64)
+        co = None if c is None else _out((kept.value, 3), np.float64)
         self._ck(lib().slgc_filter_fetch(self._h, _ptr(xo), _ptr(co)))
         return xo, co
 
@@ -406,7 +465,7 @@ class Context:
         if im.ndim != 4 or im.shape[3] != 3:
             raise ValueError("images must be [n,H,W,3]")
         n, H, W, _ = im.shape
-        out = np.empty((n, H, W), np.uint8)
+        out = _out((n, H, W), np.uint8)
         self._ck(lib().slgc_to_gray(self._h, _ptr(im), n, H, W, int(coeff_bits), _ptr(out)))
         return out
 
@@ -421,7 +480,7 @@ class Context:
 
     def knn_mean_distance(self, pts, k=20):
         p = np.ascontiguousarray(np.asarray(pts, dtype=np.float32).reshape(-1, 3))
-        out = np.empty(len(p), np.float64)
+        out = _out(len(p), np.float64)
         self._ck(lib().slgc_knn_mean_distance(self._h, _ptr(p), len(p), int(k), _ptr(out)))
         return out
 
@@ -447,15 +506,15 @@ class Context:
         self._ck(lib().slgc_pipeline_count(self._h, ptrs, dt, len(prepared), N, H, W, float(eps), float(m), int(proj_size[0]),
                                            int(proj_size[1]), _ptr(wh), int(order), int(mode), thr, C.byref(M)))
         n = M.value
-        out = {"pts": np.empty((3, n), np.float64), "colors": np.empty((n, 3), np.float64) if wh is not None else None}
+        out = {"pts": _out((3, n), np.float64), "colors": _out((n, 3), np.float64) if wh is not None else None}
         hp = vp = cam = proj = None
         if want_maps:
-            hp, vp = np.empty((H, W), np.int64), np.empty((H, W), np.int64)
+            hp, vp = _out((H, W), np.int64), _out((H, W), np.int64)
         raw = C.c_int64()
         # first fetch learns the unfiltered length when the lists are wanted
         self._ck(lib().slgc_pipeline_fetch(self._h, _ptr(hp), _ptr(vp), _ptr(out["pts"]), _ptr(out["colors"]), C.byref(raw), None, None))
         if want_lists:
-            cam, proj = np.empty((raw.value, 2), np.float32), np.empty((raw.value, 2), np.float32)
+            cam, proj = _out((raw.value, 2), np.float32), _out((raw.value, 2), np.float32)
             self._ck(lib().slgc_pipeline_fetch(self._h, None, None, None, None, None, _ptr(cam), _ptr(proj)))
         out.update(h_pixels=hp, v_pixels=vp, cam_pts=cam, proj_pts=proj, n_unfiltered=int(raw.value))
         return out
