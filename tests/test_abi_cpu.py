@@ -244,3 +244,13 @@ def test_byte_over_255_by_one_refinement_step_is_the_correctly_rounded_quotient(
         plain_wrong += q != b / 255.0
         assert fma(fma(-q, 255.0, float(b)), rcp, q) == b / 255.0
     assert plain_wrong > 0
+
+
+def test_result_arrays_fall_back_to_plain_numpy_without_page_locked_memory():
+    """scanner/_native.py: _out() asks slgc_host_alloc for a page-locked block; without a HIP device there is none and an ordinary array
+    is returned (the compute call that follows still fails loudly)."""
+    from scanner import _native
+    a = _native._out((1100, 1024), np.int64)                                 # 9 MB: above the pool's floor
+    assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable
+    small = _native._out((4, 4), np.float32)
+    assert small.flags.owndata
