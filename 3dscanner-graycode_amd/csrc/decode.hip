@@ -218,8 +218,8 @@ __global__ void __launch_bounds__(BLOCK) k_decode_fast(const FastArgs a)
 // A dword of a frame holds pixels p0..p3.  It is split into the pairs E = [p0, p2] and O = [p1, p3] (one v_perm /
 // v_and each), so every later instruction handles two pixels.  For a pair register X (values 0..255 per 16-bit half):
 //     X + (0x8000 - t)             has bit 15 of a half set  <=>  x >= t         (threshold tests, t in 0..256)
-//     D' = N + (0x0100 - I)        = n - i + 256 in 1..511 per half
-//     D' + (0x8000 - 256 - c)      has bit 15 set  <=>  n - i >= c  (r1) ;    D' + (0x8000 - 257 + c)  has bit 15 clear  <=>  i - n >= c  (r2)
+//     D = N - I (one 32-bit subtraction over both halves; the borrow a negative low half takes is given back by the next addition)
+//     D + (0x8000 - c)             has bit 15 set  <=>  n - i >= c  (r1) ;    D + (0x8000 - 1 + c)  has bit 15 clear  <=>  i - n >= c  (r2)
 // Every one of these sums stays inside its 16-bit half (no carry, no borrow: ranges in pack_pair_consts), so they are plain 32-bit
 // v_add_u32 / v_sub_u32 -- full rate on gfx950, where the packed v_pk_add_u16 / v_pk_sub_i16 / v_pk_lshrrev_b16 / v_and_or_b32 this
 // kernel first used issue at HALF rate (tools/ubench/valu_rates.hip: 2.5 vs 4.5 cycles per wave instruction).  The rule table is
@@ -294,17 +294,19 @@ __device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, u
 // Thresholds of the two pixels of a pair register -> the four packed constants classify_pk adds
 // (tt = tnd | tg << 16 and cc = cA from pixel_thresholds; lo / hi = the register's low / high half).  Ranges, per half, with
 // n, i in 0..255, tnd, tg in 0..256, cA in 1..256 or kUnreachable = 0x4000:
-//   x + KA,  x + KB   in 0x7f00 .. 0x80ff          D' = n - i + 256 in 1 .. 511
-//   D' + K1 (K1 = 0x8000 - 256 - cA in 0x3f00 .. 0x7eff)   in 0x3f01 .. 0x80fe
-//   D' + K2 (K2 = 0x8000 - 257 + cA in 0x7f00 .. 0xbeff)   in 0x7f01 .. 0xc0fe          -- all inside 16 bits: no carry between the halves.
+//   x + KA,  x + KB   in 0x7f00 .. 0x80ff          d = n - i in -255 .. 255
+//   d + K1 (K1 = 0x8000 - cA     in 0x4000 .. 0x7fff)   in 0x3f01 .. 0x80fe
+//   d + K2 (K2 = 0x8000 - 1 + cA in 0x8000 .. 0xbfff)   in 0x7f01 .. 0xc0fe          -- all inside 16 bits: no carry between the halves.
+// d is formed over both halves at once as the 32-bit N - I: a negative low half borrows from the high half, and the addition of K1 / K2
+// gives the borrow back -- the sum of the per-half values d + K (each inside its 16 bits) is the same integer either way.
 __device__ __forceinline__ void pack_pair_consts(int tt_lo, int cc_lo, int tt_hi, int cc_hi, uint32_t &KA, uint32_t &KB, uint32_t &K1, uint32_t &K2)
 {
     const uint32_t a_lo = (uint32_t)tt_lo & 0xffffu, a_hi = (uint32_t)tt_hi & 0xffffu;
     const uint32_t b_lo = (uint32_t)tt_lo >> 16, b_hi = (uint32_t)tt_hi >> 16;
     KA = (0x8000u - a_lo) | ((0x8000u - a_hi) << 16);
     KB = (0x8000u - b_lo) | ((0x8000u - b_hi) << 16);
-    K1 = (0x8000u - 256u - (uint32_t)cc_lo) | ((0x8000u - 256u - (uint32_t)cc_hi) << 16);
-    K2 = (0x8000u - 257u + (uint32_t)cc_lo) | ((0x8000u - 257u + (uint32_t)cc_hi) << 16);
+    K1 = (0x8000u - (uint32_t)cc_lo) | ((0x8000u - (uint32_t)cc_hi) << 16);
+    K2 = (0x8000u - 1u + (uint32_t)cc_lo) | ((0x8000u - 1u + (uint32_t)cc_hi) << 16);
 }
 
 // (a & b) | c as ONE full-rate v_bitop3_b32 (the compiler's own choice for this shape, v_and_or_b32, issues at half rate on gfx950)
@@ -317,8 +319,8 @@ __device__ __forceinline__ uint32_t and_or_full_rate(uint32_t a, uint32_t b, uin
 __device__ __forceinline__ void classify_bits(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t K1, uint32_t K2, uint32_t &bit, uint32_t &ok)
 {
     const uint32_t Na = N + KA, Nb = N + KB, Ia = I + KA, Ib = I + KB;
-    const uint32_t Dp = N + (0x01000100u - I);
-    const uint32_t R1 = Dp + K1, R2 = Dp + K2;
+    const uint32_t D = N - I;
+    const uint32_t R1 = D + K1, R2 = D + K2;
     // five v_bitop3_b32 (truth-table index = a << 2 | b << 1 | c), spelled out: left to itself the compiler closes these expressions
     // with v_and_or_b32 / v_or3_b32, which issue at half rate
     const uint32_t r4 = __builtin_amdgcn_bitop3_b32(Nb, Ia, Nb, 0x30);         // Nb & ~Ia
