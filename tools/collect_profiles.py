@@ -77,3 +77,14 @@ for name, j in (("plain", b), ("under rocprof", p)):
           f"{j['decode_kernel_alone']['roofline']['frac']:.3f} | throughput {j.get('throughput_mode', {}).get('value')}")
 alg = {"split": 48 * 4096 * 3000, "fused": 56 * 4096 * 3000}
 print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / alg[k.rsplit("/", 1)[1]], 3)) for k, v in t.items()}, "fingerprint", fp)
+
+# the "next" rows, the list stage, the host API and the store-pattern microbenchmark of the same box
+for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_stats_list_stage")):
+    try:
+        shutil.copy(newest(sub + "/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}.csv"))
+    except ValueError:
+        print("no", sub)
+for f, name in (("next_rows.log", "next_rows.txt"), ("lists_plain.log", "list_stage.txt"), ("host_api.log", "host_api.txt"), ("write_patterns.txt", "write_patterns.txt")):
+    if os.path.exists(os.path.join(src, f)):
+        keep = [ln for ln in open(os.path.join(src, f), errors="replace") if not re.match(r"^(RCCL|HIP|ROCm|Hostname|Librccl|[WEI]\d{8}) ", ln)]
+        open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)

@@ -20,6 +20,12 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$out
 python3 bench.py --force-sharded --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
 python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_xyz.json"
 python3 bench.py --force-sharded --exchange records --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
+# the "next" rows and the list stage under the kernel trace, the store-pattern microbenchmark
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_next" -- python3 tools/time_next_rows.py > "$out/next_rows.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs xcd=1 > "$out/lists.log" 2>&1
+python3 tools/time_lists.py --knobs xcd=1 2>/dev/null | grep "list stage" > "$out/lists_plain.log"
+python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
+[ -x tools/ubench/write_patterns ] && tools/ubench/write_patterns > "$out/write_patterns.txt" 2>&1
 python3 - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$out/bench_*.json")):
