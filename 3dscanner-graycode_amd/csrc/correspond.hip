@@ -353,29 +353,34 @@ __global__ void __launch_bounds__(256) k_tile_count(Pred pred, size_t n, unsigne
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
 }
 
-// exclusive scan of tile counts by one workgroup (ntiles <= a few 10^4)
+// exclusive scan of tile counts by one workgroup (ntiles <= a few 10^4): every thread owns a contiguous slab (the scan stays ordered),
+// the slab sums are scanned with wave shuffles + one LDS hop -- no serial loop over the 1024 partial sums
 __global__ void __launch_bounds__(1024) k_tile_scan(const unsigned *__restrict__ tile_counts, size_t ntiles,
                                                     unsigned long long *__restrict__ tile_off, unsigned long long *__restrict__ total)
 {
-    __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t per = (ntiles + 1023) / 1024;
     const size_t i0 = min(ntiles, (size_t)t * per), i1 = min(ntiles, i0 + per);
     unsigned long long mine = 0;
     for (size_t i = i0; i < i1; ++i) mine += tile_counts[i];
-    part[t] = mine;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long acc = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const unsigned long long n = part[i];
-            part[i] = acc;
-            acc += n;
-        }
-        *total = acc;
+    unsigned long long inc = mine;                     // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    unsigned long long acc = part[t];
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned long long n = wsum[w];
+        before += w < wave ? n : 0ull;
+        all += n;
+    }
+    if (t == 0) *total = all;
+    unsigned long long acc = before + inc - mine;
     for (size_t i = i0; i < i1; ++i) {
         tile_off[i] = acc;
         acc += tile_counts[i];

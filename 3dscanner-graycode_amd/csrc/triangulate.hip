@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(256) k_check_cam_nodes(const float2 *__restric
         }
     }
     for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
-    if ((threadIdx.x & 63) == 0 && err > 0.0f) atomicMax(worst, __float_as_uint(err));
+    // one atomic per wave at most, and none once the running maximum (a plain read: it only ever grows) already covers this wave
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(err) > *reinterpret_cast<volatile unsigned *>(worst)) atomicMax(worst, __float_as_uint(err));
 }
 
 __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
