@@ -754,6 +754,16 @@ extern "C" int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dty
     return SLGC_OK;
 }
 
+extern "C" int slgc_frame_diff_counts_dev(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
+                                          unsigned long long *d_counts)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (dtype != SLGC_U8 && dtype != SLGC_F64) return slgc_fail(ctx, SLGC_EINVAL, "dtype must be SLGC_U8 or SLGC_F64");
+    if (n_frames < 0 || (n_frames > 1 && (!d_frames || !d_counts))) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative size");
+    return launch_frame_diff_counts(ctx, d_frames, dtype, n_frames, elems_per_frame, thresh, d_counts);
+}
+
 // ------------------------------------------------------------------------------------------ whole pipeline, one upload
 // Driver glue of the reference in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, merge,
 // gray_to_decimal) followed by src/4-triangulate.py:50-71 (get_cam_proj_pts, triangulate, filter_3d_pts).

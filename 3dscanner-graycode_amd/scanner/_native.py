@@ -56,6 +56,7 @@ SIGNATURES = {
     "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slgc_to_gray_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "slgc_frame_diff_counts": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
+    "slgc_frame_diff_counts_dev": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
     "slgc_knn_mean_distance": (_i, [_vp, _vp, _i64, _i, _vp]),
     "slgc_pipeline_count": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64)]),
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
@@ -477,6 +478,10 @@ class Context:
         out = np.zeros(max(n - 1, 0), np.int64)
         self._ck(lib().slgc_frame_diff_counts(self._h, _ptr(fr), U8 if fr.dtype == np.uint8 else F64, n, elems, float(thresh), _ptr(out)))
         return out
+
+    def frame_diff_counts_dev(self, d_frames: int, n_frames, elems_per_frame, thresh, d_counts: int, dtype=U8):
+        """remove_bad_images' counts for frames already in HBM (asynchronous; d_counts = n_frames - 1 uint64 in device memory)."""
+        self._ck(lib().slgc_frame_diff_counts_dev(self._h, d_frames, int(dtype), int(n_frames), int(elems_per_frame), float(thresh), d_counts))
 
     def knn_mean_distance(self, pts, k=20):
         p = np.ascontiguousarray(np.asarray(pts, dtype=np.float32).reshape(-1, 3))

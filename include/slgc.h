@@ -146,6 +146,10 @@ int slgc_to_gray_dev(slgc_ctx *ctx, const uint8_t *d_bgr, size_t npix, int coeff
  * |frames[j+1] - frames[j]| > thresh, j = 0 .. n_frames-2 (cv2.absdiff + np.argwhere + len).  frames: [n][elems]. */
 int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
                            int64_t *counts);
+/* The same counts for frames that already sit in HBM (the stack a capture pipeline uploaded for slgc_decode_dev): asynchronous on the
+ * context's stream, d_counts = n_frames - 1 uint64 in device memory. */
+int slgc_frame_diff_counts_dev(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
+                               unsigned long long *d_counts);
 
 /* Point-cloud post-processing: mean distance of every point to its k nearest points, itself
  * included -- the arithmetic of Open3D's remove_statistical_outlier as called at scanner/utils/visualize.py:104 (exact k-NN on

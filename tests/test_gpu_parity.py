@@ -1063,6 +1063,13 @@ def test_remove_bad_images_and_diff_counts(ctx):
     assert np.array_equal(ctx.frame_diff_counts(fr[:2], 50), onp.frame_diff_counts(fr[:2], 50))
     many = rng.integers(0, 256, (70, 16, 16), dtype=np.uint8)                # more pairs than lanes in a wave
     assert np.array_equal(ctx.frame_diff_counts(many, 50), onp.frame_diff_counts(many, 50))
+    # frames that already sit in HBM
+    d_fr, d_cnt = ctx.alloc(fr.nbytes).upload(fr), ctx.alloc(8 * 16)
+    ctx.frame_diff_counts_dev(d_fr.ptr, len(fr), fr[0].size, 50, d_cnt.ptr)
+    ctx.synchronize()
+    assert np.array_equal(d_cnt.download((len(fr) - 1,), np.uint64).astype(np.int64), onp.frame_diff_counts(fr, 50))
+    d_fr.free()
+    d_cnt.free()
 
 
 def test_to_gray_fixed_point_luma(ctx):
