@@ -308,6 +308,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
+    ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -360,6 +361,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
+    else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value != 0;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG

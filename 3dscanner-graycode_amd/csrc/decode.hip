@@ -243,6 +243,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
+    uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
     TriF32 kf;                // T and |T|^2 in float32 for the fast form
     double T[3], t_len;
 };
@@ -387,7 +388,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
-    const uint32_t off = (blockIdx.x * BLOCK + threadIdx.x) * PX;
+    const uint32_t bid = FUSE != 0 ? xcd_block(blockIdx.x, a.f.xcd_chunk) : blockIdx.x;    // fused scan: one XCD = one band of rows (projector-table lines shared inside its L2)
+    const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t ps = a.plane_stride;
     const int L = SPEC ? FS::L : a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
@@ -647,7 +649,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
         sync();
-        const uint32_t first = blockIdx.x * BLOCK + grp * SPAN, ngroups = a.npix / 4;           // in 4-pixel groups
+        const uint32_t first = bid * BLOCK + grp * SPAN, ngroups = a.npix / 4;                  // in 4-pixel groups
         const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)SPAN ? ngroups - first : (uint32_t)SPAN) * 3u) : 0u;
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
 #pragma unroll
@@ -973,6 +975,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + 127) / 128;
+    b.f.xcd_chunk = ctx->tune_fuse_xcd ? xcd_chunk_for(ctx, blocks) : 0u;
     const bool wave = b.f.wave_tail != 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;

@@ -55,6 +55,7 @@ struct slgc_ctx {
     int tune_fuse_nt;       // fused scan: bit 0 XYZ, bit 1 maps leave with non-temporal stores
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
+    int tune_fuse_xcd;      // the same map for the fused scan kernel
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
