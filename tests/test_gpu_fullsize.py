@@ -129,6 +129,44 @@ def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
         b.free()
 
 
+@pytest.mark.parametrize("cam", ["cam_1080", "cam_1440"])
+def test_node_table_on_the_reference_lenses(ctx, cam):
+    """The two camera models the reference ships (calibration_results/cam_1080, cam_1440 -- the second one strongly distorted, k1 = -0.51), at
+    their native sizes, with the scan kernels forced onto the every-4th-column node table: every pixel against the oracle like the bench
+    configurations, and the table's measured error inside its acceptance limit (or the table dropped, which the test reports)."""
+    from scanner import _native
+    from scanner import reference_calibration as rc
+    K, cd, (W, H) = {"cam_1080": (rc.CAM_MTX, rc.CAM_DIST, (1920, 1080)), "cam_1440": (rc.CAM1440_MTX, rc.CAM1440_DIST, (2560, 1440))}[cam]
+    pw, ph, N = 1920, 1080, 44
+    _, _, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
+    calib = (K, cd, pk, pd, R, T)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, row0=0, rows=H, seed=2, noise=3, shadow=True)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.synchronize()
+    ref_h, ref_v, ref_xyz = oc.scan_dense(stack.download((N, H, W), np.uint8), (pw, ph), *calib)
+    worst = {}
+    for nodes in (2, 0):
+        ctx.tune("cam_nodes", nodes)
+        for name, mode in (("fused", _native.TRI_ALGEBRAIC), ("split", _native.TRI_ALGEBRAIC | _native.TRI_SPLIT)):
+            maps.zero()
+            xyz.zero()
+            ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+            ctx.synchronize()
+            got = (maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32))
+            _, worst[(nodes, name)] = compare_scan(*got, ref_h, ref_v, ref_xyz, f"{cam} {name} cam_nodes={nodes}")
+        if nodes == 2:
+            in_use, err = ctx.ray_table_info()
+            assert (in_use and 0.0 <= err <= 2.4e-7) or (not in_use and err > 2.4e-7)
+            print(f"\n{cam} {W}x{H}: node table {'in use' if in_use else 'dropped'}, error measure {err:.3g} (limit 2.4e-7)")
+    ctx.tune("cam_nodes", 1)
+    print({k: f"{v:.2e}" for k, v in worst.items()})
+    for b in (stack, maps, xyz):
+        b.free()
+
+
 def test_bench_configuration_two_runs_every_pixel(ctx):
     """src/3-capture_decode.py:95-96 (MAX_NB_RUNS = 2) at 4096x3000x44: two captures max-merged per code bit inside the fused kernel."""
     from scanner import _native
