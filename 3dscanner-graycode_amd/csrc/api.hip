@@ -1186,6 +1186,37 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 
+// Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry, their stacks scan_stride bytes apart, in ONE
+// launch of the fused kernel when every scan is a whole number of its 512-pixel workgroups -- a 1920x1080 scan alone is one round of
+// resident waves (all of them in the same phase of the kernel at the same time); sixteen of them overlap like a large image does.
+extern "C" int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n_scans, size_t scan_stride, size_t plane_stride, int N, int rows,
+                                   int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_scans < 0 || !d_stacks || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative count");
+    const size_t npix = (size_t)rows * W;
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    const int tri = mode & 3;
+    if (n_scans > 1 && tri == SLGC_TRI_ALGEBRAIC && !(mode & SLGC_TRI_SPLIT) && ctx->have_calib && npix % 512 == 0 && npix &&
+        (uint64_t)(npix / 512) * (uint64_t)n_scans * (uint64_t)(npix / 512) < 0x100000000ull && proj_w >= 1 && proj_h >= 1 &&
+        (size_t)proj_w * proj_h < (1u << 28) && scan_stride % 4 == 0 && !dev_geom(ctx, d_stacks, 1, 0, plane_stride, N, rows, W, eps, &g, &runs, &e) &&
+        scan_fused_eligible(g, runs, plane_stride, npix, d_h, d_v, d_xyz)) {
+        if ((rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h))) return rc;
+        if ((rc = prof_mark(ctx, 0))) return rc;
+        if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h, n_scans, scan_stride)))
+            return rc;
+        return prof_mark(ctx, 1);
+    }
+    for (int s = 0; s < n_scans; ++s)                                     // any other shape / mode: scan after scan
+        if ((rc = slgc_scan_dev(ctx, d_stacks + (size_t)s * scan_stride, 1, 0, plane_stride, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h + s * npix,
+                                d_v + s * npix, d_xyz + 3 * s * npix, nullptr)))
+            return rc;
+    return SLGC_OK;
+}
+
 extern "C" int slgc_pack_hv24_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, size_t npix, int code_bits, uint8_t *d_wire)
 {
     int rc = check_ctx(ctx);

@@ -244,6 +244,8 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
+    uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
+    uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
     TriF32 kf;                // T and |T|^2 in float32 for the fast form
     double T[3], t_len;
 };
@@ -388,7 +390,14 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
-    const uint32_t bid = FUSE != 0 ? xcd_block(blockIdx.x, a.f.xcd_chunk) : blockIdx.x;    // fused scan: one XCD = one band of rows (projector-table lines shared inside its L2)
+    uint32_t bid = FUSE != 0 ? xcd_block(blockIdx.x, a.f.xcd_chunk) : blockIdx.x;          // fused scan: one XCD = one band of rows (projector-table lines shared inside its L2)
+    uint32_t scan = 0u;                                                                      // batched launch: which of the independent scans this workgroup belongs to
+    if constexpr (FUSE != 0) {
+        if (a.f.batch_bps) {
+            scan = __umulhi(bid, a.f.batch_magic);                                           // bid / batch_bps, exact for bid * batch_bps < 2^32 (checked by the launcher)
+            bid -= scan * a.f.batch_bps;
+        }
+    }
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t ps = a.plane_stride;
     const int L = SPEC ? FS::L : a.g.L;
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     for (int p = 0; p < NP; ++p) { mB_h[p] = mB_v[p] = 0u; mV_h[p] = mV_v[p] = MULTI ? 0u : 0xffffffffu; }
 
     for (int r = 0; r < a.g.n_runs; ++r) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.run[r], 0, a.run_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.run[r] + (FUSE != 0 ? scan * a.f.batch_stride : 0ull)), 0, a.run_bytes, 0x00020000);
         uint32_t KA[NP], KB[NP], C1[NP], C2[NP];      // C1 / C2 hold K1 / K2 of pack_pair_consts
         // specialised kernels: DEPTH steps of frame loads stay in flight ahead of the step being classified
         constexpr int DEPTH = SLGC_PARK_DEPTH;
@@ -542,8 +551,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         ov[p] = gray_to_binary_2x16(gv) | ~okv;
     }
     // pairs back to pixel order: E = [p0, p2], O = [p1, p3]  ->  dwords [p0, p1], [p2, p3]
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)a.h, 0, a.npix * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)a.v, 0, a.npix * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *)(a.h + (size_t)scan * a.npix), 0, a.npix * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(a.v + (size_t)scan * a.npix), 0, a.npix * 2u, 0x00020000);
     uint32_t wh_[2 * NW], wv_[2 * NW];
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
@@ -651,7 +660,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         sync();
         const uint32_t first = bid * BLOCK + grp * SPAN, ngroups = a.npix / 4;                  // in 4-pixel groups
         const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)SPAN ? ngroups - first : (uint32_t)SPAN) * 3u) : 0u;
-        float4 *dst = reinterpret_cast<float4 *>(a.f.xyz) + (size_t)first * 3;
+        float4 *dst = reinterpret_cast<float4 *>(a.f.xyz + (size_t)scan * a.npix * 3) + (size_t)first * 3;
 #pragma unroll
         for (int it = 0; it < 3; ++it)
             if ((uint32_t)(it * SPAN + t) < nvec && (ABL != 5 || s_buf[it * SPAN + t].x == 12345.678f)) {
@@ -955,7 +964,7 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
 
 // Fused decode + triangulate (K1a-pk + K3 tail), 4 px/lane, 128-thread workgroups, NT loads.  Preconditions are checked by the caller.
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
-                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h)
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch, size_t batch_stride)
 {
     PkArgs b{};
     for (int r = 0; r < g.n_runs; ++r) b.run[r] = (const uint8_t *)runs.p[r];
@@ -974,8 +983,14 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
-    const unsigned blocks = (groups + 127) / 128;
-    b.f.xcd_chunk = ctx->tune_fuse_xcd ? xcd_chunk_for(ctx, blocks) : 0u;
+    unsigned blocks = (groups + 127) / 128;
+    b.f.xcd_chunk = (ctx->tune_fuse_xcd && n_batch <= 1) ? xcd_chunk_for(ctx, blocks) : 0u;
+    if (n_batch > 1) {          // the caller has checked: every scan is a whole number of workgroups, blocks * n_batch * blocks < 2^32
+        b.f.batch_bps = blocks;
+        b.f.batch_magic = (uint32_t)((0x100000000ull + blocks - 1) / blocks);
+        b.f.batch_stride = batch_stride;
+        blocks *= (unsigned)n_batch;
+    }
     const bool wave = b.f.wave_tail != 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;

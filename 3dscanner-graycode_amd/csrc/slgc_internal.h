@@ -130,7 +130,7 @@ bool decode_fast_eligible(double eps, int *e_out);
 int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, unsigned long long *d_bad, int skew);
 int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew);
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
-                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h);
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch = 1, size_t batch_stride = 0);
 inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj_tile ? (proj_w + 15) / 16 : (proj_w + 7) / 8; }
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz);

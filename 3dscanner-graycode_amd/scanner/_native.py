@@ -98,6 +98,7 @@ SIGNATURES = {
     "slgc_comm_allgatherv_pair_begin": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_wait": (_i, [_vp, _i]),
     "slgc_shard_band": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "slgc_scan_batch_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
     "slgc_scan_sharded_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
 }
 
@@ -600,6 +601,12 @@ class Context:
         if n.value:
             self._ck(lib().slgc_prof_samples(self._h, _ptr(out), n.value, C.byref(n)))
         return out
+
+    def scan_batch_dev(self, d_stacks: int, n_scans, scan_stride, plane_stride, N, rows, W, row0, proj_size, d_xyz: int, d_h: int, d_v: int,
+                       eps=1.0, m=10.0, mode=TRI_ALGEBRAIC):
+        """n_scans independent single-run scans of one geometry in one launch (throughput mode); outputs back to back per scan."""
+        self._ck(lib().slgc_scan_batch_dev(self._h, d_stacks, int(n_scans), int(scan_stride), int(plane_stride), int(N), int(rows), int(W), int(row0),
+                                           int(proj_size[0]), int(proj_size[1]), float(eps), float(m), int(mode), d_h, d_v, d_xyz))
 
     def build_ray_tables_dev(self, rows, W, row0, proj_size):
         """Per-calibration ray tables of the dense path (asynchronous); built on first use otherwise."""

@@ -178,6 +178,43 @@ def throughput_step(lanes, per_rank, i, mode):
     return plan
 
 
+def throughput_batched(ctx, _native, G, steps, mode, device):
+    """configs[4] through slgc_scan_batch_dev: the GPU's share of the 16 scans in ONE launch per step (3 rotated sets of stacks: > Infinity
+    Cache), no collective.  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
+    cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
+    px = cw * ch
+    per_rank = max(1, 16 // G)
+    c = _native.Context(device)
+    c.set_calibration(*calibration(cw, ch, pw, ph))
+    sets = []
+    for b in range(3):
+        st = c.alloc(per_rank * n * px)
+        for s in range(per_rank):
+            c.synth_scene_dev(st.at(s * n * px), px, n, ch, cw, seed=11 + 16 * b + s)
+        sets.append(st)
+    maps_h, maps_v, xyz = c.alloc(per_rank * px * 2), c.alloc(per_rank * px * 2), c.alloc(per_rank * px * 12)
+
+    def step(i):
+        c.scan_batch_dev(sets[i % 3].ptr, per_rank, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, maps_h.ptr, maps_v.ptr, mode=mode)
+
+    for i in range(3):
+        step(i)
+    c.synchronize()
+    if G > 1:
+        ctx.comm_barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    c.synchronize()
+    if G > 1:
+        ctx.comm_barrier()
+    el = time.perf_counter() - t0
+    if G > 1:
+        el = ctx.comm_allreduce_max(el)
+    c.close()
+    return el, per_rank * G, cw * ch / 1e6
+
+
 def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
     """16 independent 1920x1080x44 scans per step spread over the G GPUs, no collective (replicas only -- SURVEY.md 8(e)).  Each GPU
     streams its scans back to back over `n_streams` HIP streams so the tail of one scan's kernel overlaps the head of the next.
@@ -424,9 +461,10 @@ def run_rank(args, rank, local_rank, world):
     if extras and hasattr(ctx, "cloud_lists_dev"):
         ref_product = reference_product(ctx, _native, stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
 
-    thr = None
+    thr = thr_batched = None
     if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
         thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams)
+        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device)
 
     # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
     count.zero()
@@ -534,6 +572,11 @@ def run_rank(args, rank, local_rank, world):
                                                 "(BASELINE.json configs[4], replicas only)",
                                       "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "streams_per_gpu": args.streams,
                                       "scaling": "weak"}
+            if thr_batched is not None:
+                b_el, b_scans, b_mpix = thr_batched
+                out["throughput_mode"]["batched"] = {"value": round(b_scans * b_mpix * t_steps / b_el, 1), "unit": "Mpixels/s",
+                                                     "scans_per_s": round(b_scans * t_steps / b_el, 1),
+                                                     "note": "the same scans through slgc_scan_batch_dev: each GPU's share in one launch per step"}
         if single and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline()
         if use_comm:

@@ -194,6 +194,11 @@ int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t ru
 int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
                   int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
                   int16_t *d_v, float *d_xyz, unsigned long long *d_count);
+/* Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry in one launch -- stacks scan_stride bytes
+ * apart, d_h / d_v [n_scans][rows * W] int16 and d_xyz [n_scans][rows * W][3] float32 back to back.  Same results as n_scans calls of
+ * slgc_scan_dev (which is what shapes that are not a whole number of 512-pixel workgroups, and the other modes, fall back to). */
+int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n_scans, size_t scan_stride, size_t plane_stride, int N, int rows, int W,
+                        int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz);
 
 /* Diagnostic.  The device-resident decode kernels fold the per-pixel fp64 quantities of decode_codes.py:113-120 into integer
  * thresholds; this checks, for every (black, white, L_max, L_min) with black in [black_lo, black_hi) and the other three over

@@ -220,6 +220,42 @@ def test_throughput_mode_scans_match_oracle(ctx):
             c.close()
 
 
+@pytest.mark.parametrize("shape", [(1920, 1080, 44, 5), (1024, 96, 26, 3), (130, 33, 26, 3)])
+def test_batched_scans_equal_single_scans(ctx, shape):
+    """slgc_scan_batch_dev (BASELINE configs[4] in one launch): every scan of the batch bit-identical to slgc_scan_dev on the same stack, for a
+    shape that batches (a whole number of 512-pixel workgroups per scan), one with a single workgroup row ... and one that falls back."""
+    from scanner import _native
+    W, H, N, B = shape
+    pw, ph = 1920, 1080
+    ctx.set_calibration(*bench.calibration(1920, 1080, pw, ph))
+    px = W * H
+    stacks = ctx.alloc(B * N * px)
+    for s in range(B):
+        ctx.synth_scene_dev(stacks.at(s * N * px), px, N, H + 13 * B, W, row0=13 * s, rows=H, seed=40 + s, noise=3, shadow=True)   # a different window of one tall scene per scan
+    bh, bv, bx = ctx.alloc(B * px * 2), ctx.alloc(B * px * 2), ctx.alloc(B * px * 12)
+    ctx.scan_batch_dev(stacks.ptr, B, N * px, px, N, H, W, 0, (pw, ph), bx.ptr, bh.ptr, bv.ptr)
+    ctx.synchronize()
+    got_h, got_v, got_x = bh.download((B, H, W), np.int16), bv.download((B, H, W), np.int16), bx.download((B, H, W, 3), np.float32)
+    maps, xyz = ctx.alloc(px * 4 + 64), ctx.alloc(px * 12)
+    voff = (px * 2 + 31) // 32 * 32
+    for s in range(B):
+        ctx.scan_dev(stacks.at(s * N * px), 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(voff), mode=_native.TRI_ALGEBRAIC)
+        ctx.synchronize()
+        assert np.array_equal(got_h[s], maps.download((H, W), np.int16)) and np.array_equal(got_v[s], maps.download((H, W), np.int16, voff)), s
+        one = xyz.download((H, W, 3), np.float32)
+        if px % 512 == 0:                                                    # one launch: the same kernel on the same bytes
+            assert np.array_equal(got_x[s].view(np.uint32), one.view(np.uint32)), s
+        else:                                                                # scan after scan at other buffer alignments: the ragged-shape kernels
+            assert np.array_equal(np.isnan(got_x[s]), np.isnan(one)), s
+            np.testing.assert_allclose(got_x[s], one, rtol=1e-5, atol=0, equal_nan=True)
+    assert len({got_h[s].tobytes() for s in range(B)}) == B                  # the scans differ from each other
+    if (W, H) == (1920, 1080):                                               # and one of them against the oracle
+        st = stacks.download((N, H, W), np.uint8, 2 * N * px)
+        compare_scan(got_h[2], got_v[2], got_x[2], *oc.scan_dense(st, (pw, ph), *bench.calibration(1920, 1080, pw, ph)), "batched scan 2")
+    for b in (stacks, bh, bv, bx, maps, xyz):
+        b.free()
+
+
 @pytest.mark.parametrize("workload", ["c3_4096x3000x44", None])
 def test_device_resident_reference_product(ctx, workload):
     """slgc_cloud_lists_dev: the x-major lists of get_cam_proj_pts (triangulate.py:52-71), the colour gather from a device-resident
