@@ -178,7 +178,7 @@ def throughput_step(lanes, per_rank, i, mode):
     return plan
 
 
-def throughput_batched(ctx, _native, G, steps, mode, device):
+def throughput_batched(ctx, _native, G, steps, mode, device, collective=False):
     """configs[4] through slgc_scan_batch_dev: the GPU's share of the 16 scans in ONE launch per step (3 rotated sets of stacks: > Infinity
     Cache), no collective.  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
     cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
@@ -200,22 +200,22 @@ def throughput_batched(ctx, _native, G, steps, mode, device):
     for i in range(3):
         step(i)
     c.synchronize()
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         ctx.comm_barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
     c.synchronize()
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         ctx.comm_barrier()
     el = time.perf_counter() - t0
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         el = ctx.comm_allreduce_max(el)
     c.close()
     return el, per_rank * G, cw * ch / 1e6
 
 
-def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
+def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2, collective=False):
     """16 independent 1920x1080x44 scans per step spread over the G GPUs, no collective (replicas only -- SURVEY.md 8(e)).  Each GPU
     streams its scans back to back over `n_streams` HIP streams so the tail of one scan's kernel overlaps the head of the next.
     Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
@@ -230,16 +230,16 @@ def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2):
     for i in range(3):
         throughput_step(lanes, per_rank, i, mode)
     sync_all()
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         ctx.comm_barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         throughput_step(lanes, per_rank, i, mode)
     sync_all()
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         ctx.comm_barrier()
     el = time.perf_counter() - t0
-    if G > 1:
+    if G > 1 or collective:                             # --force-sharded at one rank walks through every collective call too
         el = ctx.comm_allreduce_max(el)
     for c, _, _, _ in lanes:
         c.close()
@@ -418,7 +418,7 @@ def run_rank(args, rank, local_rank, world):
         for i in range(W_):
             step(i, **kw)
         drain()
-        if G > 1:
+        if use_comm:
             ctx.comm_barrier()
         ctx.prof_begin(K + 8, stride or args.event_stride)   # HIP-event pair bound to every stride-th kernel dispatch of the region
         t0 = time.perf_counter()
@@ -426,12 +426,12 @@ def run_rank(args, rank, local_rank, world):
         for i in range(K):
             tot = step(i, **kw)
         drain()                                              # the K-th scan's exchange + triangulation are inside the timed region
-        if G > 1:
+        if use_comm:
             ctx.comm_barrier()
         el = time.perf_counter() - t0
         kms, kn = ctx.prof_end()
         samples = ctx.prof_samples()
-        if G > 1:
+        if use_comm:
             el = ctx.comm_allreduce_max(el)
             kms = ctx.comm_allreduce_max(kms)
         return el, kms, kn, tot, samples
@@ -463,8 +463,8 @@ def run_rank(args, rank, local_rank, world):
 
     thr = thr_batched = None
     if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
-        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams)
-        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device)
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm)
+        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm)
 
     # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
     count.zero()
@@ -583,7 +583,7 @@ def run_rank(args, rank, local_rank, world):
             import ctypes
             ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
-    if G > 1:
+    if use_comm:
         ctx.comm_barrier()
     ctx.close()
     if verify is not None and not verify.get("ok", False):
@@ -637,15 +637,13 @@ def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, c
     if args.exchange in ("maps", "xyz"):
         for rep in range(2):                                   # first pass warms up
             ctx.synchronize()
-            if G > 1:
-                ctx.comm_barrier()
+            ctx.comm_barrier()
             t0 = time.perf_counter()
             for i in range(K):
                 scanner.compute_only(stacks[i % len(stacks)].ptr, plane)
             ctx.synchronize()
             t_compute = time.perf_counter() - t0
-        if G > 1:
-            t_compute = ctx.comm_allreduce_max(t_compute)
+        t_compute = ctx.comm_allreduce_max(t_compute)
     px = cam_w * cam_h
     per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
     info = {"rccl_nranks": G, "exchange": args.exchange, "wire": scanner.wire if args.exchange == "maps" else None,
@@ -668,9 +666,8 @@ def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plan
     sample = xyz.reshape(-1, 3)[::97]
     mine = digest64(h, v, np.nan_to_num(sample, nan=-1.0))
     ranks_equal = True
-    if G > 1:
-        allh = ctx.comm_allgather_i64(mine)
-        ranks_equal = all(x == allh[0] for x in allh)
+    allh = ctx.comm_allgather_i64(mine)                      # nranks = 1 (--force-sharded) included: the same calls as on a node
+    ranks_equal = len(allh) == G and all(x == allh[0] for x in allh)
     full = ctx.alloc(N * px)
     ctx.synth_scene_dev(full.ptr, px, N, cam_h, cam_w, row0=0, rows=cam_h, seed=seed, noise=3, shadow=True)
     m1, x1 = ctx.alloc(px * 4), ctx.alloc(px * 12)
@@ -681,17 +678,16 @@ def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plan
     maps_equal = bool(np.array_equal(h, h1) and np.array_equal(v, v1))
     fin = np.isfinite(s1).all(axis=1)
     xyz_equal = bool(np.array_equal(np.isfinite(sample).all(axis=1), fin) and
-                     np.allclose(sample[fin], s1[fin], rtol=2e-6, atol=0))
+                     np.allclose(sample[fin], s1[fin], rtol=2e-5, atol=0))      # a band below 64 MB of rays reads the exact camera table, the full image the node table
     for b in (full, m1, x1):
         b.free()
     ok_local = maps_equal and xyz_equal
     ok_all = ok_local
-    if G > 1:
-        oks = ctx.comm_allgather_i64(1 if ok_local else 0)
-        ok_all = all(oks)
+    oks = ctx.comm_allgather_i64(1 if ok_local else 0)
+    ok_all = len(oks) == G and all(oks)
     return {"ok": bool(ranks_equal and ok_all), "ranks_hold_identical_results": bool(ranks_equal), "maps_equal_single_gpu_scan": maps_equal,
             "xyz_sample_equal_single_gpu_scan": xyz_equal, "valid_pixels": int(((h != -1) & (v != -1)).sum()), "digest": f"{mine:016x}",
-            "note": "every rank compared its reassembled maps (bit-exact) and a 1/97 XYZ sample (2e-6) with a single-GPU fused scan of the same "
+            "note": "every rank compared its reassembled maps (bit-exact) and a 1/97 XYZ sample (2e-5) with a single-GPU fused scan of the same "
                     "stack, and its digest with every other rank's"}
 
 
