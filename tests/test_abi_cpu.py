@@ -254,3 +254,15 @@ def test_result_arrays_fall_back_to_plain_numpy_without_page_locked_memory():
     assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable
     small = _native._out((4, 4), np.float32)
     assert small.flags.owndata
+
+
+def test_tools_and_bench_compile():
+    """The measurement scripts are part of the evidence: at least they must parse (they need the GPU box to run)."""
+    import glob
+    import py_compile
+    files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(files) >= 15
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh")) + glob.glob(os.path.join(ROOT, "tools", "jobs", "*.sh"))):
+        assert subprocess.run(["bash", "-n", f]).returncode == 0, f
