@@ -259,10 +259,9 @@ def test_result_arrays_fall_back_to_plain_numpy_without_page_locked_memory():
 def test_tools_and_bench_compile():
     """The measurement scripts are part of the evidence: at least they must parse (they need the GPU box to run)."""
     import glob
-    import py_compile
     files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
     assert len(files) >= 15
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        ast.parse(open(f).read(), filename=f)
     for f in sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh")) + glob.glob(os.path.join(ROOT, "tools", "jobs", "*.sh"))):
         assert subprocess.run(["bash", "-n", f]).returncode == 0, f
