@@ -44,6 +44,10 @@ WORKLOADS = {
     # small test workloads (tests/test_gpu_rccl_multi.py): an odd height (ragged bands at any G) and an even one
     "t_516x1031x44": (516, 1031, 300, 200, 44),
     "t_512x1024x44": (512, 1024, 300, 200, 44),
+    # one rank's band of the headline image at 2 / 4 / 8 ranks (timing the band kernels on one GPU: tools/ab_fused.py --workload ...)
+    "b2_4096x1500x44": (4096, 1500, 1920, 1200, 44),
+    "b4_4096x750x44": (4096, 750, 1920, 1200, 44),
+    "b8_4096x375x44": (4096, 375, 1920, 1200, 44),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PREHEAT_S = 0.15       # untimed back-to-back scans before the counted warm-up: the clocks of a fresh box ramp for ~100 ms
