@@ -491,44 +491,7 @@ def run_rank(args, rank, local_rank, world):
         if not args.no_verify and args.exchange in ("maps", "xyz"):
             verify = verify_sharded(ctx, sharded_scanner, G, rank, N, cam_w, cam_h, (proj_w, proj_h), 1 + last_stack, args.plane_pad)
 
-    alternatives = None
-    if use_comm and args.exchange == "maps" and not args.no_extras and pipelined:
-        # The first run on real xGMI is rare: time the other exchange forms too (same stacks, same pipelining, each verified against the maps
-        # the main strategy left) -- extras after the counted region, a failure here is reported and changes nothing above.
-        sharded_scanner.submit(stacks[last_stack].ptr, plane)
-        sharded_scanner.flush()
-        h_main, v_main, _ = sharded_scanner.fetch_dense()
-        main_digest = digest64(h_main, v_main)
-        alternatives = {}
-        for label, kind, wire in (("maps_hv24", "maps", "hv24"), ("xyz", "xyz", "int16")):
-            if label == "maps_hv24" and (args.wire == "hv24" or int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS):
-                continue
-            try:
-                alt = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
-                K = max(5, args.steps // 2)
-                for i in range(3):
-                    alt.submit(stacks[i % len(stacks)].ptr, plane)
-                alt.flush()
-                ctx.synchronize()
-                ctx.comm_barrier()
-                t0 = time.perf_counter()
-                for i in range(K):
-                    alt.submit(stacks[i % len(stacks)].ptr, plane)
-                alt.flush()
-                ctx.synchronize()
-                ctx.comm_barrier()
-                el_alt = ctx.comm_allreduce_max(time.perf_counter() - t0)
-                alt.submit(stacks[last_stack].ptr, plane)                 # the stack the main strategy finished on
-                alt.flush()
-                ha, va, _ = alt.fetch_dense()
-                same = ctx.comm_allgather_i64(1 if digest64(ha, va) == main_digest else 0)
-                alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K,
-                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "xyz": 16}[label],
-                                       "maps_equal_main_strategy_on_every_rank": bool(all(same))}
-                del alt
-            except Exception as e:  # noqa: BLE001
-                alternatives[label] = {"error": f"{type(e).__name__}: {e}"}
-
+    out = None
     if rank == 0:
         mpix_per_step = cam_w * cam_h / 1e6
         ms_per_step = elapsed / args.steps * 1e3
@@ -591,8 +554,6 @@ def run_rank(args, rank, local_rank, world):
         }
         if shard_info:
             out["sharded"] = shard_info
-        if alternatives:
-            out["sharded_alternatives"] = alternatives
         if verify is not None:
             out["verify"] = verify
         if other is not None:
@@ -623,10 +584,68 @@ def run_rank(args, rank, local_rank, world):
                                                      "note": "the same scans through slgc_scan_batch_dev: each GPU's share in one launch per step"}
         if single and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline()
-        if use_comm:
+
+    def emit():
+        if rank == 0:
             import ctypes
             ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+            print(json.dumps(out), flush=True)
+
+    # Extras of the multi-rank run, AFTER everything above is measured and assembled: a watchdog prints the line as it stands and ends
+    # the process if they do not come back (a hang in a collective that has never run on more than one GPU must not cost the run).
+    import threading
+
+    def bail():
+        if rank == 0:
+            out["sharded_alternatives"] = {"error": "timed out: the line above was printed without them"}
+        emit()
+        os._exit(3 if (verify is not None and not verify.get("ok", False)) else 0)
+
+    watchdog = threading.Timer(float(os.environ.get("SLGC_BENCH_ALT_TIMEOUT_S", "120")), bail)
+    watchdog.daemon = True
+    watchdog.start()
+    alternatives = None
+    if use_comm and args.exchange == "maps" and not args.no_extras and pipelined:
+        # The first run on real xGMI is rare: time the other exchange forms too (same stacks, same pipelining, each verified against the maps
+        # the main strategy left) -- extras after the counted region, a failure here is reported and changes nothing above.
+        sharded_scanner.submit(stacks[last_stack].ptr, plane)
+        sharded_scanner.flush()
+        h_main, v_main, _ = sharded_scanner.fetch_dense()
+        main_digest = digest64(h_main, v_main)
+        alternatives = {}
+        for label, kind, wire in (("maps_hv24", "maps", "hv24"), ("xyz", "xyz", "int16")):
+            if label == "maps_hv24" and (args.wire == "hv24" or int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS):
+                continue
+            try:
+                alt = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
+                K = max(5, args.steps // 2)
+                for i in range(3):
+                    alt.submit(stacks[i % len(stacks)].ptr, plane)
+                alt.flush()
+                ctx.synchronize()
+                ctx.comm_barrier()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    alt.submit(stacks[i % len(stacks)].ptr, plane)
+                alt.flush()
+                ctx.synchronize()
+                ctx.comm_barrier()
+                el_alt = ctx.comm_allreduce_max(time.perf_counter() - t0)
+                alt.submit(stacks[last_stack].ptr, plane)                 # the stack the main strategy finished on
+                alt.flush()
+                ha, va, _ = alt.fetch_dense()
+                same = ctx.comm_allgather_i64(1 if digest64(ha, va) == main_digest else 0)
+                alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K,
+                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "xyz": 16}[label],
+                                       "maps_equal_main_strategy_on_every_rank": bool(all(same))}
+                del alt
+            except Exception as e:  # noqa: BLE001
+                alternatives[label] = {"error": f"{type(e).__name__}: {e}"}
+
+    watchdog.cancel()
+    if rank == 0 and alternatives:
+        out["sharded_alternatives"] = alternatives
+    emit()
     if use_comm:
         ctx.comm_barrier()
     ctx.close()
