@@ -344,6 +344,20 @@ def run_rank(args, rank, local_rank, world):
     if args.event_stride <= 0:
         args.event_stride = 1 if args.steps < 16 else 2 if args.steps < 64 else 4
 
+    if G > 1:
+        # a rank that waits for ever in a collective (a peer died, the fabric is unhappy) must not leave the driver without a line
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "Mpixels/s decode+triangulate", "value": None, "unit": "Mpixels/s", "n_gpus": G, "steps": args.steps,
+                                  "warmup": args.warmup, "error": "timed out after SLGC_BENCH_TIMEOUT_S in the multi-rank run"}), flush=True)
+            os._exit(4)
+
+        killer = threading.Timer(float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900")), give_up)
+        killer.daemon = True
+        killer.start()
+
     n_dev = max(1, _native.device_count())
     device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
     ctx = _native.Context(device)
