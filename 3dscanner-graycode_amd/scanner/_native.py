@@ -144,17 +144,23 @@ class _PinnedPool:
     """Page-locked blocks behind the large arrays the host-buffer API returns (slgc_host_alloc).  A result array is an ordinary
     writable NumPy array over such a block; when the array and every view of it are gone the block goes back to the pool, so a
     caller that processes scan after scan gets its results at the rate of the PCIe link instead of the page-fault rate of fresh
-    memory.  Blocks are cached up to SLGC_PINNED_POOL_MB (default 4096); SLGC_PINNED_OUTPUTS=0 returns plain np.empty arrays."""
+    memory.  Page-locking is itself expensive (~0.2 ms per MB: three times what the page faults of one download cost), so a size
+    is only page-locked once it has been asked for LOCK_AFTER times without the pool being able to serve it -- a script that handles
+    one scan (the reference's own two scripts) never pays and gets plain np.empty arrays, a loop is served from the pool after its
+    first few passes.  Blocks are cached up to SLGC_PINNED_POOL_MB (default 4096); SLGC_PINNED_OUTPUTS=0 always returns plain arrays."""
 
     MIN_BYTES = 8 << 20
     GRANULE = 2 << 20
+    LOCK_AFTER = int(os.environ.get("SLGC_PINNED_AFTER", "4"))
 
     def __init__(self):
         self.free = {}                      # rounded size -> [address, ...]
-        self.cached = 0
+        self.misses = {}                    # rounded size -> requests the pool could not serve
+        self.cached = 0                     # bytes in self.free
         self.lock = threading.Lock()
         self.enabled = os.environ.get("SLGC_PINNED_OUTPUTS", "1") != "0"
         self.limit = int(os.environ.get("SLGC_PINNED_POOL_MB", "4096")) << 20
+        self.owned = 0                      # bytes page-locked so far (in the pool or behind live arrays)
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -167,14 +173,24 @@ class _PinnedPool:
             addr = blocks.pop() if blocks else None
             if addr is not None:
                 self.cached -= size
+            else:
+                self.misses[size] = self.misses.get(size, 0) + 1
+                want = self.misses[size] >= self.LOCK_AFTER and self.owned + size <= self.limit
         if addr is None:
+            if not want:
+                return np.empty(shape, dtype)
             p = C.c_void_p()
             if lib().slgc_host_alloc(size, C.byref(p)) or not p.value:
                 return np.empty(shape, dtype)                     # no page-locked memory to be had: an ordinary array does the job
             addr = p.value
+            with self.lock:
+                self.owned += size
         raw = (C.c_char * nbytes).from_address(addr)
         weakref.finalize(raw, self._release, addr, size)          # fires when the array and all its views are gone
         return np.frombuffer(raw, dtype=dtype).reshape(shape)
+
+    def wait_idle(self):
+        """Nothing runs in the background (kept for the tests' sake)."""
 
     def _release(self, addr, size):
         with self.lock:
@@ -182,6 +198,7 @@ class _PinnedPool:
                 self.free.setdefault(size, []).append(addr)
                 self.cached += size
                 return
+            self.owned -= size
         try:
             lib().slgc_host_free(addr)
         except Exception:                                         # interpreter shutdown

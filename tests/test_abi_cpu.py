@@ -251,7 +251,13 @@ def test_result_arrays_fall_back_to_plain_numpy_without_page_locked_memory():
     is returned (the compute call that follows still fails loudly)."""
     from scanner import _native
     a = _native._out((1100, 1024), np.int64)                                 # 9 MB: above the pool's floor
-    assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable
+    assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable and a.flags.owndata   # first request of a size: never page-locked
+    lock_after, _native._pool.LOCK_AFTER = _native._pool.LOCK_AFTER, 1
+    try:
+        b = _native._out((1100, 1024), np.int64)                             # would page-lock now: no device, so a plain array again
+        assert b.flags.writeable and b.shape == (1100, 1024)
+    finally:
+        _native._pool.LOCK_AFTER = lock_after
     small = _native._out((4, 4), np.float32)
     assert small.flags.owndata
 

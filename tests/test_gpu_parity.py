@@ -1014,7 +1014,11 @@ def test_results_live_in_recycled_page_locked_blocks(ctx):
     """scanner/_native.py: large results are ordinary writable arrays over page-locked blocks (slgc_host_alloc) that go back to a pool
     when the array and all its views are gone -- and not before."""
     import gc
+    from scanner import _native
     st = onp.synth_scene_int(26, 1024, 1100, seed=5)[0]                    # 9 MB per int64 map: above the pool's 8 MB floor
+    h, v = ctx.decode(st)                                                  # a size is page-locked only once it keeps coming back (plain arrays until then)
+    del h, v
+    lock_after, _native._pool.LOCK_AFTER = _native._pool.LOCK_AFTER, 1     # from here on: every miss page-locks (deterministic test)
     h, v = ctx.decode(st)
     assert h.dtype == np.int64 and h.flags.writeable and h.flags.c_contiguous and not h.flags.owndata
     ref_h, ref_v = oc.decode(st)
@@ -1031,6 +1035,7 @@ def test_results_live_in_recycled_page_locked_blocks(ctx):
     del keep, h2, v2
     gc.collect()
     h3, v3 = ctx.decode(st)
+    _native._pool.LOCK_AFTER = lock_after
     assert {h3.ctypes.data, v3.ctypes.data} <= (first | second)           # recycled blocks
     assert np.array_equal(h3, ref_h) and np.array_equal(v3, ref_v)
 
