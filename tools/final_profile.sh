@@ -25,6 +25,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_next" -- python
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs xcd=1 > "$out/lists.log" 2>&1
 python3 tools/time_lists.py --knobs xcd=1 2>/dev/null | grep "list stage" > "$out/lists_plain.log"
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
+python3 tools/time_dropin.py 2>/dev/null | grep -E "^pass|^c3|^  " > "$out/dropin.log"
 [ -x tools/ubench/write_patterns ] && tools/ubench/write_patterns > "$out/write_patterns.txt" 2>&1
 python3 - <<PY
 import json, glob, os
