@@ -144,10 +144,12 @@ int host_staging(slgc_ctx *ctx, size_t bytes, void **out)
 }
 
 // ---- large results into memory nobody has touched yet ----
-// The reference-shaped entry points return fresh NumPy arrays.  A hipMemcpy into such memory runs at the page-fault rate of one thread
-// (measured on the MI355X host: 197 MB of int64 maps in 17.0 ms = 11.6 GB/s, the same as np.empty + fill; the link does 55 GB/s).  So
-// results of 8 MB and more land in a pinned ring of 4 x 16 MB instead, and host threads copy every landed chunk into its slice of the
-// destination -- the first touches spread over the threads, the next chunk already on the link.  Synchronous: returns with dst complete.
+// The reference-shaped entry points return NumPy arrays.  A hipMemcpy into memory nobody has touched yet runs at the page-fault rate of one
+// thread (measured on the MI355X host: 197 MB of int64 maps in 17.0 ms = 11.6 GB/s, the same as np.empty + fill; the link does 56 GB/s);
+// into pages that exist already -- page-locked or not -- it runs at the rate of the link (tools/ubench/host_alloc.hip), which is why
+// scanner/_native.py recycles its result buffers.  For the untouched case, results of 8 MB and more land in a pinned ring of 4 x 16 MB
+// and host threads copy every landed chunk into its slice of the destination -- the first touches spread over the threads, the next chunk
+// already on the link.  Synchronous: returns with dst complete.
 constexpr size_t kDlChunk = 16u << 20;
 constexpr int kDlSlots = 4;
 
@@ -157,13 +159,26 @@ int download_par(slgc_ctx *ctx, void *dst, const void *d_src, size_t bytes)
     static const int par = xcd_env("SLGC_PAR_DOWNLOAD", 1);              // 0: plain hipMemcpy (A/B)
     unsigned hw = std::thread::hardware_concurrency();
     const int nthr = (int)(hw ? (hw > 16 ? 16 : hw) : 4);
-    bool pinned = false;                                                   // page-locked destination (slgc_host_alloc): the DMA engine writes it directly
+    bool pinned = false;                                                   // page-locked destination (the caller's own hipHostMalloc / hipHostRegister): the DMA engine writes it directly
     {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, dst) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
         else (void)hipGetLastError();                                      // ordinary memory is "invalid value" to the runtime: not an error here
     }
-    if (pinned || !par || bytes < (8u << 20) || nthr < 2) {
+    // Pages that exist already (a recycled result buffer, an array the caller has used before) take the copy at the rate of the link, page-
+    // locked or not; only memory nobody has touched is worth the ring.  mincore() on every 16th page tells the two apart in microseconds.
+    bool resident = false;
+    if (!pinned && par && bytes >= (8u << 20)) {
+        const uintptr_t lo = (uintptr_t)dst & ~(uintptr_t)4095, hi = ((uintptr_t)dst + bytes + 4095) & ~(uintptr_t)4095;
+        const size_t pages = (hi - lo) >> 12;
+        std::vector<unsigned char> vec(pages);
+        if (mincore((void *)lo, hi - lo, vec.data()) == 0) {
+            size_t seen = 0, in = 0;
+            for (size_t i = 0; i < pages; i += 16, ++seen) in += vec[i] & 1u;
+            resident = in * 10 >= seen * 9;
+        }
+    }
+    if (pinned || resident || !par || bytes < (8u << 20) || nthr < 2) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return SLGC_OK;
@@ -918,27 +933,6 @@ extern "C" int slgc_h2d(slgc_ctx *ctx, void *dst_dev, const void *src_host, size
     if (rc) return rc;
     if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SLGC_OK;
-}
-
-extern "C" int slgc_host_alloc(size_t bytes, void **out)
-{
-    if (!out) return SLGC_EINVAL;
-    *out = nullptr;
-    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        *out = nullptr;
-        return SLGC_ENOMEM;
-    }
-    return SLGC_OK;
-}
-
-extern "C" int slgc_host_free(void *p)
-{
-    if (p && hipHostFree(p) != hipSuccess) {
-        (void)hipGetLastError();
-        return SLGC_EHIP;
-    }
     return SLGC_OK;
 }
 

@@ -62,8 +62,6 @@ SIGNATURES = {
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "slgc_dev_free": (_i, [_vp, _vp]),
-    "slgc_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
-    "slgc_host_free": (_i, [_vp]),
     "slgc_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "slgc_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "slgc_dev_memset": (_i, [_vp, _vp, _i, _sz]),
@@ -140,27 +138,24 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-class _PinnedPool:
-    """Page-locked blocks behind the large arrays the host-buffer API returns (slgc_host_alloc).  A result array is an ordinary
-    writable NumPy array over such a block; when the array and every view of it are gone the block goes back to the pool, so a
-    caller that processes scan after scan gets its results at the rate of the PCIe link instead of the page-fault rate of fresh
-    memory.  Page-locking is itself expensive (~0.2 ms per MB: three times what the page faults of one download cost), so a size
-    is only page-locked once it has been asked for LOCK_AFTER times without the pool being able to serve it -- a script that handles
-    one scan (the reference's own two scripts) never pays and gets plain np.empty arrays, a loop is served from the pool after its
-    first few passes.  Blocks are cached up to SLGC_PINNED_POOL_MB (default 4096); SLGC_PINNED_OUTPUTS=0 always returns plain arrays."""
+class _ResultPool:
+    """Recycled memory behind the large arrays the host-buffer API returns.  A device-to-host copy into memory nobody has touched runs
+    at the page-fault rate of the host (11-15 GB/s measured; the link does 56), into pages that exist already at the rate of the link --
+    page-locked or not (tools/ubench/host_alloc.hip).  So the binding keeps the buffers of results the caller has let go of and hands
+    them out again: a result array is an ordinary writable NumPy array over such a buffer, and when the array and every view of it are
+    gone the buffer returns to the pool instead of to the operating system.  A script that handles one scan sees exactly np.empty's cost;
+    a loop gets its results at the rate of the link from its second or third pass on, with nothing page-locked and no warm-up to pay.
+    Buffers are cached up to SLGC_RESULT_POOL_MB (default 4096); SLGC_RESULT_POOL=0 returns plain np.empty arrays."""
 
     MIN_BYTES = 8 << 20
     GRANULE = 2 << 20
-    LOCK_AFTER = int(os.environ.get("SLGC_PINNED_AFTER", "4"))
 
     def __init__(self):
-        self.free = {}                      # rounded size -> [address, ...]
-        self.misses = {}                    # rounded size -> requests the pool could not serve
-        self.cached = 0                     # bytes in self.free
+        self.free = {}                      # rounded size -> [uint8 buffer, ...]
+        self.cached = 0
         self.lock = threading.Lock()
-        self.enabled = os.environ.get("SLGC_PINNED_OUTPUTS", "1") != "0"
-        self.limit = int(os.environ.get("SLGC_PINNED_POOL_MB", "4096")) << 20
-        self.owned = 0                      # bytes page-locked so far (in the pool or behind live arrays)
+        self.enabled = os.environ.get("SLGC_RESULT_POOL", "1") != "0"
+        self.limit = int(os.environ.get("SLGC_RESULT_POOL_MB", "4096")) << 20
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -169,47 +164,28 @@ class _PinnedPool:
             return np.empty(shape, dtype)
         size = -(-nbytes // self.GRANULE) * self.GRANULE
         with self.lock:
-            blocks = self.free.get(size)
-            addr = blocks.pop() if blocks else None
-            if addr is not None:
+            bufs = self.free.get(size)
+            base = bufs.pop() if bufs else None
+            if base is not None:
                 self.cached -= size
-            else:
-                self.misses[size] = self.misses.get(size, 0) + 1
-                want = self.misses[size] >= self.LOCK_AFTER and self.owned + size <= self.limit
-        if addr is None:
-            if not want:
-                return np.empty(shape, dtype)
-            p = C.c_void_p()
-            if lib().slgc_host_alloc(size, C.byref(p)) or not p.value:
-                return np.empty(shape, dtype)                     # no page-locked memory to be had: an ordinary array does the job
-            addr = p.value
-            with self.lock:
-                self.owned += size
-        raw = (C.c_char * nbytes).from_address(addr)
-        weakref.finalize(raw, self._release, addr, size)          # fires when the array and all its views are gone
+        if base is None:
+            base = np.empty(size, np.uint8)
+        raw = (C.c_char * nbytes).from_address(base.ctypes.data)
+        weakref.finalize(raw, self._release, base, size)          # fires when the array and all its views are gone; holds `base` until then
         return np.frombuffer(raw, dtype=dtype).reshape(shape)
 
-    def wait_idle(self):
-        """Nothing runs in the background (kept for the tests' sake)."""
-
-    def _release(self, addr, size):
+    def _release(self, base, size):
         with self.lock:
             if self.cached + size <= self.limit:
-                self.free.setdefault(size, []).append(addr)
+                self.free.setdefault(size, []).append(base)
                 self.cached += size
-                return
-            self.owned -= size
-        try:
-            lib().slgc_host_free(addr)
-        except Exception:                                         # interpreter shutdown
-            pass
 
 
-_pool = _PinnedPool()
+_pool = _ResultPool()
 
 
 def _out(shape, dtype=np.float64):
-    """A result array of the host-buffer API (see _PinnedPool)."""
+    """A result array of the host-buffer API (see _ResultPool)."""
     return _pool.empty(shape, dtype)
 
 

@@ -171,12 +171,6 @@ int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_pixels, dou
 /* ------------------------------------------------------------------ device-resident path (what bench.py times) */
 int slgc_dev_alloc(slgc_ctx *ctx, size_t bytes, void **dptr);
 int slgc_dev_free(slgc_ctx *ctx, void *dptr);
-/* Page-locked host memory for results (optional).  The host-buffer entry points write into whatever memory the caller passes; into
- * memory that has never been touched -- a fresh NumPy array -- a device-to-host copy runs at the page-fault rate of the host (11-15 GB/s
- * measured, the link does 50), into a block from slgc_host_alloc at the rate of the link.  scanner/_native.py keeps a pool of such
- * blocks behind the arrays it returns (SLGC_PINNED_OUTPUTS=0 turns that off). */
-int slgc_host_alloc(size_t bytes, void **out);
-int slgc_host_free(void *p);
 int slgc_h2d(slgc_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int slgc_d2h(slgc_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t bytes);

@@ -246,18 +246,25 @@ def test_byte_over_255_by_one_refinement_step_is_the_correctly_rounded_quotient(
     assert plain_wrong > 0
 
 
-def test_result_arrays_fall_back_to_plain_numpy_without_page_locked_memory():
-    """scanner/_native.py: _out() asks slgc_host_alloc for a page-locked block; without a HIP device there is none and an ordinary array
-    is returned (the compute call that follows still fails loudly)."""
+def test_result_arrays_come_from_recycled_buffers():
+    """scanner/_native.py: large results are ordinary writable arrays over buffers that return to a pool when the array and all its views
+    are gone (a device-to-host copy into pages that exist already runs at the rate of the link); small ones are plain np.empty arrays."""
+    import gc
     from scanner import _native
     a = _native._out((1100, 1024), np.int64)                                 # 9 MB: above the pool's floor
-    assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable and a.flags.owndata   # first request of a size: never page-locked
-    lock_after, _native._pool.LOCK_AFTER = _native._pool.LOCK_AFTER, 1
-    try:
-        b = _native._out((1100, 1024), np.int64)                             # would page-lock now: no device, so a plain array again
-        assert b.flags.writeable and b.shape == (1100, 1024)
-    finally:
-        _native._pool.LOCK_AFTER = lock_after
+    assert a.shape == (1100, 1024) and a.dtype == np.int64 and a.flags.writeable and a.flags.c_contiguous
+    a[3, 4] = 7
+    addr = a.ctypes.data
+    view = a[10:20]
+    del a
+    gc.collect()
+    b = _native._out((1100, 1024), np.int64)                                 # the view keeps the first buffer out of the pool
+    assert b.ctypes.data != addr
+    del view, b
+    gc.collect()
+    c = _native._out((1024, 1100), np.int64)                                 # same size class: one of the two buffers comes back
+    d = _native._out((1100, 1024), np.int64)
+    assert addr in (c.ctypes.data, d.ctypes.data)
     small = _native._out((4, 4), np.float32)
     assert small.flags.owndata
 

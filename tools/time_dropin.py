@@ -51,7 +51,7 @@ for rep in range(8):
     pts = clock("triangulate(cam_pts, proj_pts)          4:63", lambda: tri.triangulate(cam, proj), times)
     fp, fc = clock("filter_3d_pts(pts, colors, 0.5)         4:71", lambda: tri.filter_3d_pts(pts, col, threshold=0.5), times)
     del hc, vc, hp, vp, cam, proj, col, pts
-    print(f"pass {rep + 1}: {sum(t for _, t in times):.1f} ms" + ("   (one scan, as the reference's scripts run: results in plain arrays, nothing page-locked yet)" if rep == 0 else ""))
+    print(f"pass {rep + 1}: {sum(t for _, t in times):.1f} ms" + ("   (one scan in a fresh process, as the reference's scripts run)" if rep == 0 else ""))
 total = sum(t for _, t in times)
 print(f"{args.workload}, {'float64' if args.float64 else 'uint8'} stack, last pass ({fp.shape[1]} points kept):")
 for label, t in times:

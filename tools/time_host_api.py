@@ -15,7 +15,7 @@ for (W, H, PW, PH, N) in ((1920, 1080, 1920, 1080, 44), (4096, 3000, 1920, 1200,
     for name, fn in (("decode(uint8)", lambda: ctx.decode(st)),
                      ("get_codes(uint8)", lambda: ctx.codes(st)),):
         for _ in range(5):
-            fn()                                          # steady state: the result sizes are page-locked after a few passes (_native._PinnedPool)
+            fn()                                          # steady state of a loop: result buffers recycled (_native._ResultPool)
         t = time.perf_counter(); fn(); dt = time.perf_counter() - t
         print(f"{W}x{H}x{N} {name:18s} {dt*1e3:8.1f} ms  {mp/dt:8.1f} Mpix/s", flush=True)
     if W <= 1920:
