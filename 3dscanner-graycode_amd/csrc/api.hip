@@ -376,7 +376,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
-    else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value != 0;
+    else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG

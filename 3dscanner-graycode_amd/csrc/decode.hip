@@ -244,6 +244,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
+    uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
     uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
     uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
     TriF32 kf;                // T and |T|^2 in float32 for the fast form
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
-    uint32_t bid = FUSE != 0 ? xcd_block(blockIdx.x, a.f.xcd_chunk) : blockIdx.x;          // fused scan: one XCD = one band of rows (projector-table lines shared inside its L2)
+    uint32_t bid = FUSE != 0 ? (a.f.xcd_run ? xcd_block_fine(blockIdx.x, a.f.xcd_run, gridDim.x) : xcd_block(blockIdx.x, a.f.xcd_chunk)) : blockIdx.x;   // fused scan: optional XCD-aware tile maps (A/B)
     uint32_t scan = 0u;                                                                      // batched launch: which of the independent scans this workgroup belongs to
     if constexpr (FUSE != 0) {
         if (a.f.batch_bps) {
@@ -984,7 +985,8 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const uint32_t groups = b.npix / 4;
     if (groups == 0) return SLGC_OK;
     unsigned blocks = (groups + 127) / 128;
-    b.f.xcd_chunk = (ctx->tune_fuse_xcd && n_batch <= 1) ? xcd_chunk_for(ctx, blocks) : 0u;
+    b.f.xcd_chunk = (ctx->tune_fuse_xcd == 1 && n_batch <= 1) ? xcd_chunk_for(ctx, blocks) : 0u;
+    b.f.xcd_run = (ctx->tune_fuse_xcd >= 2 && n_batch <= 1 && blocks >= 64) ? (uint32_t)ctx->tune_fuse_xcd : 0u;       // fuse_xcd = n >= 2: fine map, n tiles per XCD
     if (n_batch > 1) {          // the caller has checked: every scan is a whole number of workgroups, blocks * n_batch * blocks < 2^32
         b.f.batch_bps = blocks;
         b.f.batch_magic = (uint32_t)((0x100000000ull + blocks - 1) / blocks);

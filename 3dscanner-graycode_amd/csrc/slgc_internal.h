@@ -189,6 +189,15 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t chunk)
 {
     return (chunk != 0u && bid < chunk * 8u) ? (bid & 7u) * chunk + (bid >> 3) : bid;
 }
+// The same idea in small: groups of 8 * run workgroups, inside a group XCD x owns `run` consecutive tiles -- every XCD works on whole rows
+// while all eight stay inside the same few dozen rows of the image (the banded map above sends them 1/8 of the image apart).
+__device__ __forceinline__ uint32_t xcd_block_fine(uint32_t bid, uint32_t run, uint32_t nblocks)
+{
+    const uint32_t span = 8u * run, group = bid / span;
+    if ((group + 1u) * span > nblocks) return bid;                      // the ragged last group keeps its order
+    const uint32_t in = bid - group * span;
+    return group * span + (in & 7u) * run + (in >> 3);
+}
 // Integer environment knob (A/B switches: SLGC_XCD, SLGC_TRI_NT, SLGC_FUSE_NT).
 inline int xcd_env(const char *name, int dflt)
 {
