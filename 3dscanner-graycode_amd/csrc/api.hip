@@ -325,6 +325,9 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
     ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
+    ctx->lut_nodes_err = -1.0f;
+    ctx->tune_stagger = xcd_env("SLGC_STAGGER", 0);
+    ctx->tune_stagger_max = xcd_env("SLGC_STAGGER_MAX", 8192);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;
@@ -348,6 +351,7 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
     if (ctx->lut_nodes) (void)hipFree(ctx->lut_nodes);
+    if (ctx->lut_check_word) (void)hipFree(ctx->lut_check_word);
     if (ctx->dl_stage) {
         (void)hipHostFree(ctx->dl_stage);
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->dl_ev[i]);
@@ -378,6 +382,9 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "stagger")) ctx->tune_stagger = value < 0 ? 0 : value;
+    else if (!strcmp(name, "stagger_max")) ctx->tune_stagger_max = value < 0 ? 0 : value;
+    else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG
     else if (!strcmp(name, "fuse_abl")) ctx->tune_fuse_abl = value;
@@ -387,6 +394,15 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
 }
 
 extern "C" int slgc_last_input_path(slgc_ctx *ctx) { return ctx ? ctx->last_input_path : SLGC_EINVAL; }
+
+extern "C" int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (ns_frames) *ns_frames = ctx->last_ns;
+    if (node_table) *node_table = ctx->last_nodes;
+    if (guard) *guard = ctx->last_guard;
+    return ctx->last_scan_path;
+}
 
 extern "C" int slgc_synchronize(slgc_ctx *ctx)
 {
@@ -1174,10 +1190,15 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
         if ((rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h))) return rc;
         if ((rc = prof_mark(ctx, 0))) return rc;
         if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h))) return rc;
+        ctx->last_scan_path = SLGC_PATH_FUSED;
         return prof_mark(ctx, 1);
     }
+    ctx->last_scan_path = SLGC_PATH_NONE;
+    ctx->last_ragged = 0;
     if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, 0))) return rc;
-    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
+    if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
+    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    return SLGC_OK;
 }
 
 // Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry, their stacks scan_stride bytes apart, in ONE
@@ -1202,6 +1223,7 @@ extern "C" int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n
         if ((rc = prof_mark(ctx, 0))) return rc;
         if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h, n_scans, scan_stride)))
             return rc;
+        ctx->last_scan_path = SLGC_PATH_BATCH_FUSED;
         return prof_mark(ctx, 1);
     }
     for (int s = 0; s < n_scans; ++s)                                     // any other shape / mode: scan after scan
@@ -1269,6 +1291,25 @@ extern "C" int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plan
     if (!d_stack || N < 14 || N > 65 || rows < 0 || row0 < 0 || row0 + rows > H || plane_stride < (size_t)rows * W)
         return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments");
     return launch_synth(ctx, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, shadow);
+}
+
+extern "C" int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
+                                       int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (N < 14 || N > 65 || rows < 0 || W < 0 || row0 < 0 || row0 + rows > H || (d_stack && plane_stride < (size_t)rows * W) || proj_w < 1 || proj_h < 1 ||
+        proj_w > 32767 || proj_h > 32767 || (d_h_true == nullptr) != (d_v_true == nullptr))
+        return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments");
+    if (!d_h_true) {
+        void *codes;
+        const size_t npix = (size_t)rows * W;
+        if ((rc = slgc_ws(ctx, 2, npix * 4 + 128, &codes))) return rc;
+        d_h_true = (int16_t *)codes;
+        d_v_true = d_h_true + ((npix + 31) & ~(size_t)31);
+    }
+    return launch_synth_physical(ctx, d_stack, plane_stride, N, H, W, row0, rows, proj_w, proj_h, seed, noise, d_h_true, d_v_true, d_truth_xyz);
 }
 
 extern "C" int slgc_event_record(slgc_ctx *ctx, int id)

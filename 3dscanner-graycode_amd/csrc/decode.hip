@@ -245,6 +245,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
     uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
+    uint32_t stagger;         // small launches (one residency round): start-up phase shift between groups of workgroups, see k_decode_pk (0 = off)
     uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
     uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
     TriF32 kf;                // T and |T|^2 in float32 for the fast form
@@ -392,6 +393,20 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
     uint32_t bid = FUSE != 0 ? (a.f.xcd_run ? xcd_block_fine(blockIdx.x, a.f.xcd_run, gridDim.x) : xcd_block(blockIdx.x, a.f.xcd_chunk)) : blockIdx.x;   // fused scan: optional XCD-aware tile maps (A/B)
+    if constexpr (FUSE != 0) {
+        // A scan that fits one round of resident workgroups (1920x1080: 4 050 of 4 096 slots) runs in lock step: every wave is in the same phase
+        // -- threshold loads, float64 block, bit loop, tail -- at the same time, and nothing overlaps.  stagger shifts groups of workgroups
+        // against each other: bits 0..4 = which bit of the dispatch order picks the group, bits 5..6 = log2(groups), bits 8..15 = sleep units
+        // (s_sleep 32 = 2 048 cycles) per group step; bit 16 = no sleeping, the groups get different issue priorities instead.
+        if (a.f.stagger) {
+            const uint32_t grp = (blockIdx.x >> (a.f.stagger & 31u)) & ((1u << ((a.f.stagger >> 5) & 3u)) - 1u);
+            if (a.f.stagger & 0x10000u) {
+                if (grp & 1u) __builtin_amdgcn_s_setprio(2);
+            } else {
+                for (uint32_t i = 0; i < grp * ((a.f.stagger >> 8) & 255u); ++i) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     uint32_t scan = 0u;                                                                      // batched launch: which of the independent scans this workgroup belongs to
     if constexpr (FUSE != 0) {
         if (a.f.batch_bps) {
@@ -931,6 +946,7 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
     if (groups == 0) return SLGC_OK;
     const unsigned blocks = (groups + BLOCK - 1) / BLOCK;
     const int ns = (abl == 0 && PX == 4 && BLOCK == 128 && NT == 1) ? spec_frames(ctx, a.g) : 0;
+    ctx->last_ns = ns;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     if (abl == 1)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), a);
@@ -987,6 +1003,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     unsigned blocks = (groups + 127) / 128;
     b.f.xcd_chunk = (ctx->tune_fuse_xcd == 1 && n_batch <= 1) ? xcd_chunk_for(ctx, blocks) : 0u;
     b.f.xcd_run = (ctx->tune_fuse_xcd >= 2 && n_batch <= 1 && blocks >= 64) ? (uint32_t)ctx->tune_fuse_xcd : 0u;       // fuse_xcd = n >= 2: fine map, n tiles per XCD
+    b.f.stagger = (n_batch <= 1 && blocks <= (unsigned)ctx->tune_stagger_max) ? (uint32_t)ctx->tune_stagger : 0u;
     if (n_batch > 1) {          // the caller has checked: every scan is a whole number of workgroups, blocks * n_batch * blocks < 2^32
         b.f.batch_bps = blocks;
         b.f.batch_magic = (uint32_t)((0x100000000ull + blocks - 1) / blocks);
@@ -1005,6 +1022,10 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
 #endif
     {
         const int ns = wave ? spec_frames(ctx, g) : 0;
+        ctx->last_ns = ns;
+        ctx->last_nodes = b.f.cn.nodes ? 1 : 0;
+        ctx->last_guard = 1;
+        ctx->last_ragged = 0;
 #define SLGC_SPEC(NSV)                                                                                             \
         if (ns == NSV) {                                                                                           \
             if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2, NSV>), dim3(blocks), dim3(128), b);    \
@@ -1085,6 +1106,8 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
 #undef SLGC_PK
     } else {
         if (nt) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: NT only with the packed kernel", variant);
+        ctx->last_ns = 0;
+        ctx->last_ragged = 1;             // the lane-mask kernel: what misaligned bands fall back to
 #define SLGC_CASE(P, B) if (px == P && block == B) rc = launch_fast_t<P, B>(ctx, a, main_pix);
         SLGC_CASE(16, 256) SLGC_CASE(16, 128) SLGC_CASE(16, 64) SLGC_CASE(8, 256) SLGC_CASE(8, 128) SLGC_CASE(8, 64)
         SLGC_CASE(4, 256) SLGC_CASE(4, 128) SLGC_CASE(4, 64) SLGC_CASE(1, 256)
@@ -1092,6 +1115,7 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
     }
     if (rc) return rc == SLGC_EINVAL ? slgc_fail(ctx, SLGC_EINVAL, "variant %d not built", variant) : rc;
     if (main_pix < npix) {  // ragged tail (< px pixels): byte-wide groups
+        ctx->last_ragged = 1;
         FastArgs t = a;
         for (int r = 0; r < g.n_runs; ++r) t.run[r] = a.run[r] + main_pix;
         t.h = d_h + main_pix;

@@ -56,8 +56,18 @@ struct slgc_ctx {
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel
+    int tune_stagger;       // fused scan kernel, launches of at most tune_stagger_max workgroups: start-up phase shift between workgroup groups (decode.hip)
+    int tune_stagger_max;
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
+    int tune_image_rows;    // height of the whole image a band belongs to (0 = the band IS the image): the node-table decision (size and accuracy) is taken
+                            // for the whole image, so a pixel gets the same rays -- and bit-identical XYZ -- whether one GPU scans the image or N GPUs its bands
+    // slgc_last_scan_path: what the last slgc_scan_dev / slgc_scan_batch_dev / slgc_decode_dev / slgc_triangulate_maps_dev call launched (written by the launchers)
+    int last_scan_path;     // SLGC_PATH_*
+    int last_ns;            // frames-per-run specialisation of the decode / fused kernel (42 / 44 / 46), 0 = generic kernel
+    int last_nodes;         // 1 = the triangulation read the camera node table, 0 = the per-pixel table (or evaluated the rays per pixel)
+    int last_guard;         // 1 = float32 fast form with the flat-triangle guard, 0 = exact (acos / sin) mode, -1 = unguarded (diagnostic build only)
+    int last_ragged;        // 1 = a byte-wide / per-pixel fallback kernel took part (misaligned buffers, ragged tails)
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
     void *dl_stage;         // pinned ring the large device-to-host results land in (api.hip: download_par)
@@ -72,7 +82,12 @@ struct slgc_ctx {
     // ray tables (triangulate.hip), rebuilt when the calibration or the geometry changes
     void *lut_cam, *lut_proj;
     void *lut_nodes;        // camera rays at every 4th column (tri_math.h CamNodes), nullptr when not built / not accurate enough
-    float lut_nodes_err;    // max |interpolated - exact| / max(1, |exact|) over the band the table was built for
+    float lut_nodes_err;    // error measure of k_check_cam_nodes over the band -- or, with tune_image_rows, over the whole image (-1: not measured)
+    int lut_image_rows;     // tune_image_rows the tables were built under
+    void *lut_check_word;   // 4-byte device word the node-table check reduces into
+    float img_err;          // whole-image error measure, cached per (calibration, W, image_rows): every band of one image reuses it
+    unsigned img_err_ver;
+    int img_err_W, img_err_rows;
     void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
     unsigned lut_cam_ver, lut_proj_ver;
     int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h, lut_proj_tile;
@@ -157,6 +172,8 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
 // synth.hip
 int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
                  int noise, int shadow);
+int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
+                          uint32_t seed, int noise, int16_t *d_h, int16_t *d_v, float *d_truth);
 // ingest.hip
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
@@ -208,10 +225,12 @@ struct CamNodes;
 // The node table of the band ensure_luts() last built (tri_math.h), or an empty one (kernels then read the per-pixel table).
 // tune_cam_nodes 1 (default) = when it pays: a per-pixel table of more than 64 MB streams from HBM on every scan, a smaller one stays in
 // the 256 MB Infinity Cache between scans and the node table only adds arithmetic (measured: 4096x3000 -1.3 % fused / -4.5 % two-kernel
-// step, 1920x1080 and 1280x720 +2 %); 2 = whenever it is accurate enough (tests); 0 = never.
+// step, 1920x1080 and 1280x720 +2 %); 2 = whenever it is accurate enough (tests); 0 = never.  The size that decides is the WHOLE image's
+// (tune_image_rows when the context scans a band of a taller image): the choice must not depend on how many GPUs share the image.
 #define SLGC_CAM_NODES_FOR(ctx, W, allow)                                                                                                   \
     (((allow) && (ctx)->lut_nodes && (ctx)->lut_cam_W == (W) &&                                                                            \
-      ((ctx)->tune_cam_nodes == 2 || ((ctx)->tune_cam_nodes == 1 && (size_t)(ctx)->lut_cam_rows * (size_t)(W) * 8u > (64u << 20))))        \
+      ((ctx)->tune_cam_nodes == 2 ||                                                                                                       \
+       ((ctx)->tune_cam_nodes == 1 && (size_t)((ctx)->lut_image_rows > 0 ? (ctx)->lut_image_rows : (ctx)->lut_cam_rows) * (size_t)(W) * 8u > (64u << 20)))) \
          ? CamNodes{(const float2 *)(ctx)->lut_nodes, (uint32_t)((W) / 4), (uint32_t)((W) / 4 + 3), 1.0f / (float)((W) / 4)}              \
          : CamNodes{nullptr, 1u, 1u, 1.0f})
 inline uint32_t xcd_chunk_for(const slgc_ctx *ctx, unsigned blocks)

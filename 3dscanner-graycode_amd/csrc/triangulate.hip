@@ -222,6 +222,38 @@ __global__ void __launch_bounds__(256) k_check_cam_nodes(const float2 *__restric
     if ((threadIdx.x & 63) == 0 && __float_as_uint(err) > *reinterpret_cast<volatile unsigned *>(worst)) atomicMax(worst, __float_as_uint(err));
 }
 
+// The same measure over a WHOLE image without its tables (slgc_tune "image_rows": the context holds one band of a taller image, the
+// decision must be the one a single GPU scanning the whole image takes): nodes and exact rays are evaluated on the spot with the routine
+// that fills the tables, so the number is the one k_check_cam_nodes reports on the whole image's tables.  g = linear 4-pixel group of the image.
+__global__ void __launch_bounds__(256) k_check_cam_nodes_direct(const Calib c, int w4, size_t ngroups, unsigned *__restrict__ worst)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float err = 0.0f;
+    if (g < ngroups) {
+        const int row = (int)(g / (size_t)w4), gx = (int)(g % (size_t)w4);
+        float2 n[4];
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const Ray2 a = undistort_point((float)(4 * (gx + k - 1)), (float)row, c.cam_k, c.cam_d, c.R);
+            n[k] = make_float2(a.x, a.y);
+        }
+        float cx[4], cy[4];
+        cam_rays_from_nodes(cam_v4f{n[0].x, n[0].y, n[1].x, n[1].y}, cam_v4f{n[2].x, n[2].y, n[3].x, n[3].y}, cx, cy);
+#pragma unroll 1
+        for (int j = 1; j < 4; ++j) {                    // pixel 4 gx is node 1 itself
+            const Ray2 a = undistort_point((float)(4 * gx + j), (float)row, c.cam_k, c.cam_d, c.R);
+            const float ix = j == 1 ? cx[1] : j == 2 ? cx[2] : cx[3], iy = j == 1 ? cy[1] : j == 2 ? cy[2] : cy[3];
+            const float ax = fabsf(ix - a.x), ay = fabsf(iy - a.y);
+            const float ex = fmaxf(ax / fmaxf(1.0f, fabsf(a.x)), (2.4e-7f / 4e-6f) * ax / fmaxf(kCamNodeTiny, fabsf(a.x)));
+            const float ey = fmaxf(ay / fmaxf(1.0f, fabsf(a.y)), (2.4e-7f / 4e-6f) * ay / fmaxf(kCamNodeTiny, fabsf(a.y)));
+            err = fmaxf(err, !(ex == ex) || !(ey == ey) ? __builtin_huge_valf() : fmaxf(ex, ey));
+        }
+        if (!(n[1].x == n[1].x) || !(n[1].y == n[1].y)) err = __builtin_huge_valf();      // k_check_cam_nodes sees a NaN node through pixel 4 gx
+    }
+    for (int o = 32; o > 0; o >>= 1) err = fmaxf(err, __shfl_down(err, o, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(err) > *reinterpret_cast<volatile unsigned *>(worst)) atomicMax(worst, __float_as_uint(err));
+}
+
 __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
                                                         size_t nslots, int wide)
 {
@@ -430,62 +462,96 @@ int launch_triangulate_list(slgc_ctx *ctx, const float *d_cam, const float *d_pr
 }
 
 // Build (or reuse) the ray tables for this calibration / geometry.
+// Asynchronous on the context's stream EXCEPT when a node table is (re)built: its accuracy check reads one word back (a stream
+// synchronisation, once per calibration / geometry).  A node table that cannot be allocated or does not pass the check simply is not
+// there (the kernels read the per-pixel table); the state describing a table is written only after its build has been enqueued.
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
 {
     const int wide = ctx->tune_proj_tile ? 1 : 0;
     const int tiles_x = proj_tiles_x(ctx, proj_w), tiles_y = (proj_h + 7) / 8;
     const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * (wide ? 128 : 64);
-    if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows)) {
-        if (ctx->lut_cam) {
+    // the whole image this band belongs to (slgc_tune "image_rows"); a band that is the image itself needs no separate treatment
+    const int img_rows = (ctx->tune_image_rows > 0 && !(row0 == 0 && rows == ctx->tune_image_rows)) ? ctx->tune_image_rows : 0;
+    if (img_rows && (row0 < 0 || row0 + rows > img_rows))
+        return slgc_fail(ctx, SLGC_EINVAL, "band rows %d..%d outside the image of %d rows set with slgc_tune(\"image_rows\")", row0, row0 + rows, img_rows);
+    if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows &&
+          ctx->lut_image_rows == img_rows)) {
+        if (ctx->lut_cam || ctx->lut_nodes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipFree(ctx->lut_cam));
-            ctx->lut_cam = nullptr;
-        }
-        if (hipMalloc(&ctx->lut_cam, npix * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera ray table");
-        hipLaunchKernelGGL(k_build_cam_lut, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)ctx->lut_cam, W,
-                           row0, npix);
-        HIP_TRY(ctx, hipGetLastError());
-        ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows;
-        // the every-4th-column table of the same band, kept only if the rays interpolated from it stay within 2 ulp of the exact ones
-        if (ctx->lut_nodes) {
-            HIP_TRY(ctx, hipFree(ctx->lut_nodes));
-            ctx->lut_nodes = nullptr;
+            if (ctx->lut_cam) (void)hipFree(ctx->lut_cam);
+            if (ctx->lut_nodes) (void)hipFree(ctx->lut_nodes);
+            ctx->lut_cam = ctx->lut_nodes = nullptr;
         }
         ctx->lut_nodes_err = -1.0f;
-        if (W % 4 == 0 && W >= 4 && npix / 4 < (1u << 24)) {
+        void *cam = nullptr;
+        if (hipMalloc(&cam, npix * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera ray table");
+        if (npix) hipLaunchKernelGGL(k_build_cam_lut, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)cam, W, row0, npix);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(cam);
+            return slgc_fail(ctx, SLGC_EHIP, "camera ray table build failed to launch");
+        }
+        ctx->lut_cam = cam;
+        ctx->lut_cam_ver = ctx->calib_ver; ctx->lut_cam_W = W; ctx->lut_cam_row0 = row0; ctx->lut_cam_rows = rows; ctx->lut_image_rows = img_rows;
+        // the every-4th-column table of the same band, kept only if the rays interpolated from it stay within 2 ulp of the exact ones --
+        // over the band, or (image_rows) over the whole image the band belongs to, so that every band of one image decides alike
+        const size_t img_groups = (size_t)(img_rows ? img_rows : rows) * (size_t)(W / 4);
+        if (W % 4 == 0 && W >= 4 && npix >= 4 && img_groups < (1u << 24)) {
             const int ne = W / 4 + 3;
             const size_t total = (size_t)rows * ne;
-            void *worst;
-            int rc = slgc_ws(ctx, 7, 64, &worst);
-            if (rc) return rc;
-            if (hipMalloc(&ctx->lut_nodes, total * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "camera node table");
-            HIP_TRY(ctx, hipMemsetAsync(worst, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_build_cam_nodes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)ctx->lut_nodes, ne,
-                               row0, total);
-            const CamNodes cn{(const float2 *)ctx->lut_nodes, (uint32_t)(W / 4), (uint32_t)ne, 1.0f / (float)(W / 4)};
-            hipLaunchKernelGGL(k_check_cam_nodes, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float2 *)ctx->lut_cam, cn,
-                               npix / 4, (unsigned *)worst);
-            HIP_TRY(ctx, hipGetLastError());
-            float err = 0.0f;
-            HIP_TRY(ctx, hipMemcpyAsync(&err, worst, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->lut_nodes_err = err;
-            if (!(err <= 2.4e-7f)) {                     // 2 ulp of a float32 in [1, 2): this lens is not smooth enough at 4-pixel nodes
-                HIP_TRY(ctx, hipFree(ctx->lut_nodes));
-                ctx->lut_nodes = nullptr;
+            void *nodes = nullptr;
+            if (!ctx->lut_check_word && hipMalloc(&ctx->lut_check_word, 64) != hipSuccess) ctx->lut_check_word = nullptr;
+            if (ctx->lut_check_word && hipMalloc(&nodes, total * sizeof(float2) + 64) == hipSuccess) {
+                unsigned *worst = (unsigned *)ctx->lut_check_word;
+                hipLaunchKernelGGL(k_build_cam_nodes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)nodes, ne, row0, total);
+                float err = __builtin_huge_valf();
+                bool measured = false;
+                if (img_rows && ctx->img_err_ver == ctx->calib_ver && ctx->img_err_W == W && ctx->img_err_rows == img_rows) {
+                    err = ctx->img_err;                  // another band of the same image measured it already
+                    measured = true;
+                } else {
+                    bool ok = hipMemsetAsync(worst, 0, 4, ctx->stream) == hipSuccess;
+                    if (ok && img_rows) {
+                        hipLaunchKernelGGL(k_check_cam_nodes_direct, dim3((unsigned)((img_groups + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, W / 4, img_groups, worst);
+                    } else if (ok) {
+                        const CamNodes cn{(const float2 *)nodes, (uint32_t)(W / 4), (uint32_t)ne, 1.0f / (float)(W / 4)};
+                        hipLaunchKernelGGL(k_check_cam_nodes, dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float2 *)ctx->lut_cam, cn, npix / 4, worst);
+                    }
+                    ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(&err, worst, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                         hipStreamSynchronize(ctx->stream) == hipSuccess;
+                    if (!ok) {
+                        (void)hipGetLastError();
+                        err = __builtin_huge_valf();
+                    } else {
+                        measured = true;
+                        if (img_rows) { ctx->img_err = err; ctx->img_err_ver = ctx->calib_ver; ctx->img_err_W = W; ctx->img_err_rows = img_rows; }
+                    }
+                }
+                if (measured) ctx->lut_nodes_err = err;
+                if (err <= 2.4e-7f) {                     // 2 ulp of a float32 in [1, 2); otherwise this lens is not smooth enough at 4-pixel nodes
+                    ctx->lut_nodes = nodes;
+                } else {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    (void)hipFree(nodes);
+                }
+            } else {
+                (void)hipGetLastError();                  // no memory for the node table: the kernels read the per-pixel one
             }
         }
     }
     if (!(ctx->lut_proj && ctx->lut_proj_ver == ctx->calib_ver && ctx->lut_proj_w == proj_w && ctx->lut_proj_h == proj_h && ctx->lut_proj_tile == wide)) {
         if (ctx->lut_proj) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipFree(ctx->lut_proj));
+            (void)hipFree(ctx->lut_proj);
             ctx->lut_proj = nullptr;
         }
-        if (hipMalloc(&ctx->lut_proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
-        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib,
-                           (float2 *)ctx->lut_proj, proj_w, proj_h, tiles_x, nproj, wide);
-        HIP_TRY(ctx, hipGetLastError());
+        void *proj = nullptr;
+        if (hipMalloc(&proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
+        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)proj, proj_w, proj_h, tiles_x, nproj, wide);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(proj);
+            return slgc_fail(ctx, SLGC_EHIP, "projector ray table build failed to launch");
+        }
+        ctx->lut_proj = proj;
         ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h; ctx->lut_proj_tile = wide;
     }
     return SLGC_OK;
@@ -541,6 +607,8 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")
         // the exact float64 mode keeps the exact per-pixel rays; the fast form may interpolate them from the node table
         const CamNodes cn = SLGC_CAM_NODES_FOR(ctx, W, mode != SLGC_TRI_EXACT);
+        ctx->last_nodes = cn.nodes ? 1 : 0;
+        ctx->last_guard = mode == SLGC_TRI_EXACT ? 0 : 1;
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
                                (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
@@ -555,11 +623,15 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;
+        ctx->last_ragged = 1;
         // ragged tail (< 4 pixels): direct-evaluation kernel on the remainder
         const int x0 = (int)(done % (size_t)W);
         (void)x0;
         return launch_triangulate_maps_direct(ctx, d_h + done, d_v + done, npix - done, done, W, row0, proj_w, proj_h, mode, d_xyz + 3 * done, d_count);
     }
+    ctx->last_nodes = 0;
+    ctx->last_guard = mode == SLGC_TRI_EXACT ? 0 : 1;
+    ctx->last_ragged = 1;
     return launch_triangulate_maps_direct(ctx, d_h, d_v, npix, 0, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 

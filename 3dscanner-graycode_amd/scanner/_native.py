@@ -39,6 +39,7 @@ SIGNATURES = {
     "slgc_last_error": (C.c_char_p, [_vp]),
     "slgc_synchronize": (_i, [_vp]),
     "slgc_last_input_path": (_i, [_vp]),
+    "slgc_last_scan_path": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "slgc_tune": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
     "slgc_direct_indirect": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "slgc_unpack_hv24_dev": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "slgc_triangulate_wire_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
+    "slgc_synth_physical_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.c_uint32, _i, _vp, _vp, _vp]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "slgc_prof_begin": (_i, [_vp, _i, _i]),
@@ -309,6 +311,17 @@ class Context:
     def last_input_path(self) -> int:
         """0 = uint8 stack as given, 1 = float64 stack narrowed to uint8 on the host, 2 = float64 kernel (slgc_last_input_path)."""
         return int(lib().slgc_last_input_path(self._h))
+
+    SCAN_PATHS = {0: "none", 1: "fused", 2: "split", 3: "split-ragged", 4: "batch-fused"}
+
+    def last_scan_path(self) -> dict:
+        """Which kernels the last scan_dev / scan_batch_dev call launched (slgc_last_scan_path): {"path": "fused" | "split" |
+        "split-ragged" | "batch-fused" | "none", "ns_frames": 42 | 44 | 46 | 0 (generic kernel), "node_table": bool, "guard": bool}."""
+        ns, nodes, guard = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().slgc_last_scan_path(self._h, C.byref(ns), C.byref(nodes), C.byref(guard))
+        if rc < 0:
+            self._ck(rc)
+        return {"path": self.SCAN_PATHS.get(rc, str(rc)), "ns_frames": int(ns.value), "node_table": bool(nodes.value), "guard": guard.value == 1}
 
     def dev_memset(self, dptr: int, value: int, nbytes: int):
         self._ck(lib().slgc_dev_memset(self._h, dptr, int(value), int(nbytes)))
@@ -576,6 +589,14 @@ class Context:
     def synth_scene_dev(self, d_stack: int, plane_stride, N, H, W, row0=0, rows=None, seed=1, noise=3, shadow=True):
         rows = H if rows is None else rows
         self._ck(lib().slgc_synth_scene_dev(self._h, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, int(bool(shadow))))
+
+    def synth_physical_dev(self, d_stack, plane_stride, N, H, W, proj_size, row0=0, rows=None, seed=1, noise=3, d_h_true=None, d_v_true=None,
+                           d_truth_xyz=None):
+        """Physically consistent synthetic capture (set_calibration first): frames encode the projector pixel that really lights each
+        camera pixel of a plane + sphere scene; optional device outputs: the encoded codes (int16, -1 = unlit) and the true surface points."""
+        rows = H if rows is None else rows
+        self._ck(lib().slgc_synth_physical_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(proj_size[0]),
+                                               int(proj_size[1]), int(seed), int(noise), d_h_true, d_v_true, d_truth_xyz))
 
     def prof_begin(self, max_launches: int = 4096, stride: int = 1):
         self._ck(lib().slgc_prof_begin(self._h, int(max_launches), int(stride)))

@@ -216,6 +216,9 @@ class ShardedScanner:
         self.wire = wire
         self.ctx, self.exchange, self.plan = ctx, exchange, plan
         self.proj_size, self.N, self.mode, self.kind = proj_size, n_frames, mode, exchange_kind
+        # the camera-ray table decision (per-pixel or node table) is taken for the whole image, not for this rank's band: a pixel's XYZ is
+        # then bit-identical for any number of ranks (and equal to a single-GPU scan of the image)
+        ctx.tune("image_rows", plan.H)
         self.rank = exchange.rank
         self.row0, self.rows = plan.band(self.rank)
         band_px, full_px = self.rows * plan.W, plan.H * plan.W

@@ -73,6 +73,9 @@ int slgc_synchronize(slgc_ctx *ctx);
  * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
  * to stay in the Infinity Cache between scans (> 64 MB; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
+ * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
+ * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
+ * scan its bands (0, the default: the band is the image).
  * Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD,
  * SLGC_FUSE_XCD, SLGC_CAM_NODES), read when the context is created. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
@@ -82,6 +85,20 @@ int slgc_tune(slgc_ctx *ctx, const char *name, int value);
  * uploaded as 1 byte per sample; 2 = float64 shipped as it is (a fraction / negative / NaN was found) and decoded by the float64
  * kernel.  Results are identical on all three. */
 int slgc_last_input_path(slgc_ctx *ctx);
+
+/* Which kernels the last slgc_scan_dev / slgc_scan_batch_dev call on this context launched (slgc_scan_dev silently takes the two-kernel
+ * path when a buffer is misaligned, the band is ragged, a count is requested or the mode asks for it): returns one of SLGC_PATH_* (or a
+ * negative status).  Optional outputs: *ns_frames = the frames-per-run specialisation the decode / fused kernel was compiled for (42, 44,
+ * 46; 0 = the generic kernel); *node_table = 1 if the triangulation read the every-4th-column camera table; *guard = 1 float32 fast form
+ * with the flat-triangle guard, 0 exact (acos / sin) mode.  bench.py reports its pipeline from this, not from its own arguments. */
+enum {
+    SLGC_PATH_NONE = 0,
+    SLGC_PATH_FUSED = 1,        /* one kernel: decode with the triangulation tail */
+    SLGC_PATH_SPLIT = 2,        /* decode kernel + dense triangulation kernel, both on their vector paths */
+    SLGC_PATH_SPLIT_RAGGED = 3, /* two kernels and a byte-wide / per-pixel fallback kernel took part (misaligned or ragged band) */
+    SLGC_PATH_BATCH_FUSED = 4   /* slgc_scan_batch_dev: all scans in one launch of the fused kernel */
+};
+int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
 
 /* ------------------------------------------------------------------ decode, host buffers */
@@ -221,8 +238,10 @@ int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj
  * kernels' fast form interpolates each row's rays with a cubic through four nodes -- kept only when, over every pixel of the band, the
  * interpolated ray stays within 2 float32 ulp (of a number in [1, 2)) of the exact one and every component of at least 1e-3 within 4e-6
  * of itself (flat triangles, lanes whose rays cross zero, and the exact mode always read the per-pixel table).
- * *in_use = 1 if the kernels will read the node table for the tables built last (0: W % 4 != 0, too rough a lens, a band of at
- * most 64 MB of rays under slgc_tune "cam_nodes" 1, or "cam_nodes" 0); *max_err = the measured error, in units where 2.4e-7 is the acceptance limit (-1 if no node table was built). */
+ * *in_use = 1 if the kernels will read the node table for the tables built last (0: W % 4 != 0, too rough a lens, an image of at
+ * most 64 MB of rays under slgc_tune "cam_nodes" 1, or "cam_nodes" 0); *max_err = the measured error, in units where 2.4e-7 is the acceptance limit (-1 if no node table was built).
+ * With slgc_tune "image_rows" both the size and the measured error are the WHOLE image's, whatever band the tables cover.
+ * Building a node table reads its error back: that one call synchronises the context's stream (once per calibration / geometry). */
 int slgc_ray_table_info(slgc_ctx *ctx, int *in_use, double *max_err);
 
 /* Diagnostic: d_counts[0] += decodable pixels of the band, d_counts[1] += those among them that the dense triangulation redoes
@@ -262,6 +281,16 @@ int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, in
 /* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
 int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                          uint32_t seed, int noise, int shadow);
+
+/* Physically consistent synthetic capture (needs slgc_set_calibration): every camera pixel's ray is cast into a fixed scene (a tilted plane
+ * with a sphere in front, 0.4 - 0.65 m away), the hit point goes through the stereo pose and the projector's forward lens model to the
+ * projector pixel that lights it, and the frames encode THAT pixel -- one surface seen by camera and projector, which is what
+ * src/4-triangulate.py:50-64 assumes of its inputs.  Pixels the projector does not reach stay at ambient level in every frame.
+ * Optional outputs (device, may be NULL): d_h_true / d_v_true int16 [rows][W] = the encoded projector pixel (-1 = unlit);
+ * d_truth_xyz float32 [rows][W][3] = the true surface point in the frame Triangulate.triangulate reports (NaN = unlit).
+ * d_stack may be NULL (codes / truth only).  Bit-identical NumPy twin: oracle/oracle_np.py synth_physical. */
+int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
+                            int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz);
 
 /* HIP-event timing on the context's stream: id in [0,16). */
 int slgc_event_record(slgc_ctx *ctx, int id);

@@ -444,6 +444,141 @@ def synth_scene_int(n_frames: int, H: int, W: int, seed: int = 1, noise: int = 3
     return np.clip(img, 0, 255).astype(np.uint8), xs, ys
 
 
+# ----------------------------------------------------------------------------- physically consistent synthetic capture
+# One surface seen by the camera AND lit by the projector, the way /root/reference/src/4-triangulate.py:50-64 assumes its inputs were
+# made: every camera pixel's ray is cast into a scene (a tilted back plane with a sphere in front of it, 0.35-0.6 m from the camera), the
+# hit point goes through the stereo pose (x_p = R x_c + T) and the projector's FORWARD lens model (OpenCV's documented distortion
+# polynomial) to the projector pixel that lights it, and that pixel's (column, row) is what the Gray-code frames encode.  Pixels the
+# projector cannot reach (outside its raster, behind the sphere as seen from the projector, or where its lens model is no longer
+# monotonic) stay at ambient level in every frame -- the decoder's shadow mask.  All float64, + - * / sqrt only, evaluated in ONE fixed
+# order: the device generator (csrc/synth.hip: k_synth_physical_codes) is a bit-identical twin.
+PHYS_PLANE_POINT = (0.0, 0.0, 0.56)          # a point of the back plane, camera coordinates, metres
+PHYS_PLANE_NORMAL = (0.18, -0.10, -1.0)      # its normal (not normalised)
+PHYS_SPHERE_CENTRE = (0.045, 0.015, 0.46)
+PHYS_SPHERE_RADIUS = 0.06
+PHYS_R2_MAX = 0.16                           # projector lens: lit only where x'^2 + y'^2 <= this (the reference's `proj` model folds over at ~0.22)
+PHYS_UNDISTORT_ITERS = 20                    # fixed-point inverse of the camera lens run to convergence (the reference's own ray uses 5)
+
+
+def _dist14(dist):
+    k = np.zeros(14)
+    d = np.asarray(dist, dtype=np.float64).ravel()
+    k[:d.size] = d
+    return k
+
+
+def synth_physical_codes(H, W, proj_size, cam_mtx, cam_dist, proj_mtx, proj_dist, proj_R, proj_T, row0=0, rows=None, code_bits=15):
+    """-> (h int16 [rows,W], v int16 [rows,W], truth float64 [rows,W,3]): the projector pixel that lights each camera pixel (-1 = unlit) and
+    the true surface point in the frame Triangulate.triangulate reports (relative to the camera centre, projector axes: R x_c).
+    code_bits: a pattern of L bits per axis can only address projector pixels below 2^L (44 frames = 10 bits on a 1920-pixel projector:
+    BASELINE.json configs[1], [2]); the rest of the raster stays dark."""
+    rows = H - row0 if rows is None else rows
+    A = np.asarray(cam_mtx, dtype=np.float64)
+    P = np.asarray(proj_mtx, dtype=np.float64)
+    R = np.asarray(proj_R, dtype=np.float64).reshape(3, 3)
+    T = np.asarray(proj_T, dtype=np.float64).reshape(3)
+    k, q = _dist14(cam_dist), _dist14(proj_dist)
+    pw, ph = int(proj_size[0]), int(proj_size[1])
+    yy, xx = np.mgrid[row0:row0 + rows, 0:W]
+    u, v = xx.astype(np.float64), yy.astype(np.float64)
+    with np.errstate(all="ignore"):
+        # camera pixel -> ray (x, y, 1): fixed-point inverse of the forward model, PHYS_UNDISTORT_ITERS rounds, no early exit
+        x0 = (u - A[0, 2]) / A[0, 0]
+        y0 = (v - A[1, 2]) / A[1, 1]
+        x, y = x0, y0
+        for _ in range(PHYS_UNDISTORT_ITERS):
+            r2 = x * x + y * y
+            icd = (1.0 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1.0 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+            dx = ((2.0 * k[2]) * x * y + k[3] * (r2 + (2.0 * x) * x)) + (k[8] * r2 + (k[9] * r2) * r2)
+            dy = (k[2] * (r2 + (2.0 * y) * y) + (2.0 * k[3]) * x * y) + (k[10] * r2 + (k[11] * r2) * r2)
+            x = (x0 - dx) * icd
+            y = (y0 - dy) * icd
+        # nearest hit: sphere |t d - c|^2 = r^2 with d = (x, y, 1), else the plane n.(t d - p0) = 0
+        cx, cy, cz = PHYS_SPHERE_CENTRE
+        a = (x * x + y * y) + 1.0
+        b = (x * cx + y * cy) + cz
+        cc = ((cx * cx + cy * cy) + cz * cz) - PHYS_SPHERE_RADIUS * PHYS_SPHERE_RADIUS
+        disc = b * b - a * cc
+        on_sphere = disc > 0.0
+        ts = (b - np.sqrt(np.where(on_sphere, disc, 0.0))) / a
+        nx, ny, nz = PHYS_PLANE_NORMAL
+        px_, py_, pz_ = PHYS_PLANE_POINT
+        tp = ((nx * px_ + ny * py_) + nz * pz_) / ((nx * x + ny * y) + nz)
+        t = np.where(on_sphere, ts, tp)
+        X, Y, Z = t * x, t * y, t
+        # into the projector frame
+        Xp = ((R[0, 0] * X + R[0, 1] * Y) + R[0, 2] * Z) + T[0]
+        Yp = ((R[1, 0] * X + R[1, 1] * Y) + R[1, 2] * Z) + T[1]
+        Zp = ((R[2, 0] * X + R[2, 1] * Y) + R[2, 2] * Z) + T[2]
+        # a plane point is in the sphere's shadow when the segment to the projector centre C = -R^T T crosses the sphere
+        Cx = -((R[0, 0] * T[0] + R[1, 0] * T[1]) + R[2, 0] * T[2])
+        Cy = -((R[0, 1] * T[0] + R[1, 1] * T[1]) + R[2, 1] * T[2])
+        Cz = -((R[0, 2] * T[0] + R[1, 2] * T[1]) + R[2, 2] * T[2])
+        ex, ey, ez = Cx - X, Cy - Y, Cz - Z                      # towards the projector
+        fx_, fy_, fz_ = X - cx, Y - cy, Z - cz
+        ea = (ex * ex + ey * ey) + ez * ez
+        eb = (ex * fx_ + ey * fy_) + ez * fz_
+        ec = ((fx_ * fx_ + fy_ * fy_) + fz_ * fz_) - PHYS_SPHERE_RADIUS * PHYS_SPHERE_RADIUS
+        shadow = (~on_sphere) & ((eb * eb - ea * ec) > 0.0) & (eb < 0.0)
+        # forward lens model of the projector (OpenCV: radial quotient, tangential, thin prism), skew ignored like undistortPoints does
+        xn, yn = Xp / Zp, Yp / Zp
+        r2 = xn * xn + yn * yn
+        rad = (1.0 + ((q[4] * r2 + q[1]) * r2 + q[0]) * r2) / (1.0 + ((q[7] * r2 + q[6]) * r2 + q[5]) * r2)
+        xd = (xn * rad + ((2.0 * q[2]) * xn * yn + q[3] * (r2 + (2.0 * xn) * xn))) + (q[8] * r2 + (q[9] * r2) * r2)
+        yd = (yn * rad + (q[2] * (r2 + (2.0 * yn) * yn) + (2.0 * q[3]) * xn * yn)) + (q[10] * r2 + (q[11] * r2) * r2)
+        pu = np.floor((P[0, 0] * xd + P[0, 2]) + 0.5)
+        pv = np.floor((P[1, 1] * yd + P[1, 2]) + 0.5)
+        top = float(min(1 << code_bits, 32767) - 1)
+        lit = (Zp > 0.0) & (r2 <= PHYS_R2_MAX) & (pu >= 0.0) & (pu <= pw - 1.0) & (pv >= 0.0) & (pv <= ph - 1.0) & (~shadow) & (t > 0.0) & \
+              (pu <= top) & (pv <= top)
+        h = np.where(lit, pu, -1.0).astype(np.int16)
+        vv = np.where(lit, pv, -1.0).astype(np.int16)
+        truth = np.stack([(R[0, 0] * X + R[0, 1] * Y) + R[0, 2] * Z, (R[1, 0] * X + R[1, 1] * Y) + R[1, 2] * Z,
+                          (R[2, 0] * X + R[2, 1] * Y) + R[2, 2] * Z], axis=-1)
+        truth[~lit] = np.nan
+    return h, vv, truth
+
+
+def render_codes(n_frames, H, W, h, v, seed=1, noise=3, row0=0):
+    """Frames of a capture whose pixel (y, x) is lit by projector pixel (h, v) (-1 = unlit: ambient in every frame): the frame order of
+    generate_codes.py:53-79, ambient 15, a 140 / 180 checker of surface gains, hash noise -- twin of csrc/synth.hip: k_synth_render."""
+    rows = h.shape[0]
+    L = (n_frames - 2) // 4
+    yy, xx = np.mgrid[row0:row0 + rows, 0:W].astype(np.int64)
+    lit = (h != -1) & (v != -1)
+    gain = np.where((((xx >> 4) ^ (yy >> 4)) & 1) == 1, 180, 140)
+    hs, vs = h.astype(np.int64) & ((1 << L) - 1), v.astype(np.int64) & ((1 << L) - 1)
+    gx, gy = hs ^ (hs >> 1), vs ^ (vs >> 1)
+    img = np.full((n_frames, rows, W), 15, dtype=np.int64)
+    img[1] = np.where(lit, 15 + gain, 15)
+    for k in range(L):
+        bx = (gx >> (L - 1 - k)) & 1
+        by = (gy >> k) & 1
+        img[2 + 2 * k] = np.where(lit, 15 + gain * bx, 15)
+        img[3 + 2 * k] = np.where(lit, 15 + gain * by, 15)
+        img[2 + 2 * L + 2 * k] = np.where(lit, 15 + gain * (1 - bx), 15)
+        img[3 + 2 * L + 2 * k] = np.where(lit, 15 + gain * (1 - by), 15)
+    if noise > 0:
+        gp = (yy * W + xx).astype(np.uint32)
+        f = np.arange(n_frames, dtype=np.uint32)[:, None, None]
+        with np.errstate(over="ignore"):
+            x = gp[None] * np.uint32(0x9E3779B1) + f * np.uint32(0x85EBCA77) + np.uint32(seed)
+            x ^= x >> np.uint32(16)
+            x *= np.uint32(0x7FEB352D)
+            x ^= x >> np.uint32(15)
+            x *= np.uint32(0x846CA68B)
+            x ^= x >> np.uint32(16)
+        img += (x % np.uint32(2 * noise + 1)).astype(np.int64) - noise
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_physical(n_frames, H, W, proj_size, calib, seed=1, noise=3, row0=0, rows=None):
+    """-> (stack uint8 [N,rows,W], h, v, truth): see synth_physical_codes / render_codes.  calib = (cam_mtx, cam_dist, proj_mtx (scaled),
+    proj_dist, proj_R, proj_T) as slgc_set_calibration takes them."""
+    h, v, truth = synth_physical_codes(H, W, proj_size, *calib, row0=row0, rows=rows, code_bits=(n_frames - 2) // 4)
+    return render_codes(n_frames, H, W, h, v, seed=seed, noise=noise, row0=row0), h, v, truth
+
+
 # ----------------------------------------------------------------------------- "next" rows (SURVEY 8(f))
 
 

@@ -298,3 +298,34 @@ def test_device_resident_reference_product(ctx, workload):
         b.free()
     lists.free()
     bare.free()
+
+
+@pytest.mark.parametrize("workload", ["c1_1280x720x42", "c2_1920x1080x44", "c3_4096x3000x44"])
+def test_executed_path_is_observable(ctx, workload):
+    """slgc_last_scan_path: the call bench.py times runs the fused kernel specialised for the workload's frame count at the three BASELINE
+    sizes; a count request, a split request, the exact mode and a misaligned XYZ buffer take the two-kernel path -- and say so."""
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
+    ctx.set_calibration(*bench.calibration(W, H, pw, ph))
+    ctx.tune("cam_nodes", 1)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=1, noise=3, shadow=True)
+    maps, xyz, cnt = ctx.alloc(px * 4), ctx.alloc(px * 12 + 16), ctx.alloc(16).zero()
+
+    def scan(mode, count=None, xyz_ptr=None):
+        ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz_ptr or xyz.ptr, count, maps.at(0), maps.at(px * 2), mode=mode)
+        return ctx.last_scan_path()
+
+    big = W * H * 8 > 64 << 20
+    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": N, "node_table": big, "guard": True}
+    assert scan(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT) == {"path": "split", "ns_frames": N, "node_table": big, "guard": True}
+    assert scan(_native.TRI_ALGEBRAIC, count=cnt.ptr)["path"] == "split"
+    assert scan(_native.TRI_EXACT) == {"path": "split", "ns_frames": N, "node_table": False, "guard": False}
+    assert scan(_native.TRI_ALGEBRAIC, xyz_ptr=xyz.ptr + 4)["path"] == "split-ragged"          # XYZ not 16-byte aligned: per-pixel triangulation kernel
+    ctx.tune("park", 0)
+    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": 0, "node_table": big, "guard": True}
+    ctx.tune("park", 1)
+    ctx.synchronize()
+    for b in (stack, maps, xyz, cnt):
+        b.free()

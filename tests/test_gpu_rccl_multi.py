@@ -60,6 +60,18 @@ def test_single_rank_rccl_through_bench_self_verifies():
         assert r.returncode == 0 and j["verify"]["ok"], (extra, r.stderr[-2000:])
 
 
+@pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
+@pytest.mark.parametrize("extra", [["--exchange", "maps"], ["--exchange", "maps", "--wire", "hv24"], ["--exchange", "xyz"]], ids=["maps-int16", "maps-hv24", "xyz"])
+def test_single_rank_rccl_full_size_self_verifies(extra):
+    """BASELINE.json configs[3]'s image (4096x3000x44) through every RCCL call of the sharded path at nranks = 1: in-place ncclAllGather on the
+    communication stream, event slots, pipelined submit/flush -- and the run's own check against a single-GPU fused scan, bit for bit."""
+    r, j = run_bench("--force-sharded", "--steps", "12", "--warmup", "2", "--no-extras", "--workload", "c3_4096x3000x44", *extra)
+    assert r.returncode == 0 and j is not None, r.stderr[-2000:]
+    v = j["verify"]
+    assert v["ok"] and v["maps_equal_single_gpu_scan"] and v["xyz_sample_equal_single_gpu_scan"] and v["valid_pixels"] > 9_000_000, v
+    assert "configs[3]" in j["config"]["workload"] and j["sharded"]["rccl_nranks"] == 1
+
+
 @pytest.mark.skipif(not has_gpu() or n_devices() != 1, reason="the refusal only happens on a one-GPU box")
 def test_two_ranks_on_one_gpu_fail_cleanly():
     """RCCL's "Duplicate GPU detected": both rank processes must exit (no hang), rank 0 still prints a JSON line naming the error."""
