@@ -383,6 +383,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "stagger")) ctx->tune_stagger = value < 0 ? 0 : value;
+    else if (!strcmp(name, "lds_pad")) ctx->tune_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(name, "stagger_max")) ctx->tune_stagger_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
@@ -420,6 +421,15 @@ extern "C" int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen)
     hipDeviceProp_t p;
     HIP_TRY(ctx, hipGetDeviceProperties(&p, ctx->device));
     snprintf(buf, buflen, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName, p.multiProcessorCount);   // some boxes report an empty marketing name
+    return SLGC_OK;
+}
+
+extern "C" int slgc_device_pci_bus_id(slgc_ctx *ctx, char *buf, int buflen)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!buf || buflen < 16) return slgc_fail(ctx, SLGC_EINVAL, "bad buffer");
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(buf, buflen, ctx->device));
     return SLGC_OK;
 }
 

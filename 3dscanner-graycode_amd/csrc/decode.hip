@@ -1011,6 +1011,11 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         blocks *= (unsigned)n_batch;
     }
     const bool wave = b.f.wave_tail != 0;
+    struct LdsPad {                       // restores the launch default on every way out
+        slgc_ctx *c;
+        ~LdsPad() { c->launch_lds = 0; }
+    } lds_pad{ctx};
+    ctx->launch_lds = (n_batch <= 1 && blocks <= (unsigned)ctx->tune_stagger_max) ? (unsigned)ctx->tune_lds_pad : 0u;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;
     if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, 2>), dim3(blocks), dim3(128), b);

@@ -471,9 +471,9 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
     const int tiles_x = proj_tiles_x(ctx, proj_w), tiles_y = (proj_h + 7) / 8;
     const size_t npix = (size_t)rows * W, nproj = (size_t)tiles_x * tiles_y * (wide ? 128 : 64);
     // the whole image this band belongs to (slgc_tune "image_rows"); a band that is the image itself needs no separate treatment
-    const int img_rows = (ctx->tune_image_rows > 0 && !(row0 == 0 && rows == ctx->tune_image_rows)) ? ctx->tune_image_rows : 0;
-    if (img_rows && (row0 < 0 || row0 + rows > img_rows))
-        return slgc_fail(ctx, SLGC_EINVAL, "band rows %d..%d outside the image of %d rows set with slgc_tune(\"image_rows\")", row0, row0 + rows, img_rows);
+    // (a band that does not fit into that image is not a band of it: the setting does not apply)
+    const int img_rows = (ctx->tune_image_rows > 0 && !(row0 == 0 && rows == ctx->tune_image_rows) && row0 >= 0 && row0 + rows <= ctx->tune_image_rows)
+                             ? ctx->tune_image_rows : 0;
     if (!(ctx->lut_cam && ctx->lut_cam_ver == ctx->calib_ver && ctx->lut_cam_W == W && ctx->lut_cam_row0 == row0 && ctx->lut_cam_rows == rows &&
           ctx->lut_image_rows == img_rows)) {
         if (ctx->lut_cam || ctx->lut_nodes) {

@@ -42,6 +42,7 @@ SIGNATURES = {
     "slgc_last_scan_path": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "slgc_tune": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
+    "slgc_device_pci_bus_id": (_i, [_vp, C.c_char_p, _i]),
     "slgc_direct_indirect": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "slgc_is_lit": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _d, _d, _vp, _vp]),
     "slgc_codes": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _vp, _vp]),
@@ -330,6 +331,11 @@ class Context:
         buf = C.create_string_buffer(256)
         self._ck(lib().slgc_device_name(self._h, buf, 256))
         return buf.value.decode()
+
+    def device_pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(64)
+        self._ck(lib().slgc_device_pci_bus_id(self._h, buf, 64))
+        return buf.value.decode().lower()
 
     def event_record(self, idx: int):
         self._ck(lib().slgc_event_record(self._h, idx))

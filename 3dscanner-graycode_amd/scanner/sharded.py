@@ -217,8 +217,8 @@ class ShardedScanner:
         self.ctx, self.exchange, self.plan = ctx, exchange, plan
         self.proj_size, self.N, self.mode, self.kind = proj_size, n_frames, mode, exchange_kind
         # the camera-ray table decision (per-pixel or node table) is taken for the whole image, not for this rank's band: a pixel's XYZ is
-        # then bit-identical for any number of ranks (and equal to a single-GPU scan of the image)
-        ctx.tune("image_rows", plan.H)
+        # then bit-identical for any number of ranks (and equal to a single-GPU scan of the image).  Set around every call that launches
+        # kernels (_whole_image) and cleared afterwards: the context may serve other scanners and plain scans in between.
         self.rank = exchange.rank
         self.row0, self.rows = plan.band(self.rank)
         band_px, full_px = self.rows * plan.W, plan.H * plan.W
@@ -244,9 +244,31 @@ class ShardedScanner:
             self.records = ctx.alloc(max(16, band_px * RECORD_BYTES))
             self.all_records = ctx.alloc(max(16, full_px * RECORD_BYTES))
 
+    class _WholeImage:
+        def __init__(self, scanner):
+            self.s = scanner
+
+        def __enter__(self):
+            self.s._wi_depth = getattr(self.s, "_wi_depth", 0) + 1
+            if self.s._wi_depth == 1:
+                self.s.ctx.tune("image_rows", self.s.plan.H)
+
+        def __exit__(self, *exc):
+            self.s._wi_depth -= 1
+            if self.s._wi_depth == 0:
+                self.s.ctx.tune("image_rows", 0)
+
+    def _whole_image(self):
+        """slgc_tune("image_rows", H) for the duration of a call (re-entrant)."""
+        return ShardedScanner._WholeImage(self)
+
     def scan_maps(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
         """Band decode -> map all-gatherv -> full-image triangulation on every rank.  Nothing here synchronises with the host.
         Leaves int16 maps (h_full, v_full) and dense float32 XYZ [H][W][3] (NaN = undecodable) on every rank."""
+        with self._whole_image():
+            return self._scan_maps(d_band_stack, plane_stride, n_runs, run_stride, eps)
+
+    def _scan_maps(self, d_band_stack, plane_stride, n_runs, run_stride, eps):
         c, W, H = self.ctx, self.plan.W, self.plan.H
         self.flush()
         self.h_full, self.v_full = self._sets[0]
@@ -297,6 +319,10 @@ class ShardedScanner:
     def compute_only(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
         """The kernels of one sharded scan on this rank WITHOUT the exchange (bench.py: what the links have to keep up with).  The
         maps / XYZ it leaves behind are not a reassembled result."""
+        with self._whole_image():
+            return self._compute_only(d_band_stack, plane_stride, n_runs, run_stride, eps)
+
+    def _compute_only(self, d_band_stack, plane_stride, n_runs, run_stride, eps):
         c, W = self.ctx, self.plan.W
         px0 = self.row0 * W
         if self.kind == "xyz":
@@ -322,10 +348,14 @@ class ShardedScanner:
         """Pipelined scan ("maps": decode this scan's band, start its exchange on the communication stream, then finish the
         PREVIOUS scan -- wait for its exchange, triangulate; "xyz": fused kernel on the band, start the exchange, wait for the
         previous one).  Call :meth:`flush` after the last one.  No host synchronisation."""
-        if self.kind == "xyz":
-            return self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
-        if self.kind != "maps":
+        if self.kind not in ("maps", "xyz"):
             raise ValueError("submit()/flush() pipeline the 'maps' and 'xyz' strategies")
+        with self._whole_image():
+            if self.kind == "xyz":
+                return self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
+            return self._submit_maps(d_band_stack, plane_stride, n_runs, run_stride, eps)
+
+    def _submit_maps(self, d_band_stack, plane_stride, n_runs, run_stride, eps):
         c, W = self.ctx, self.plan.W
         s = self._submitted % 2
         h_full, v_full = self._sets[s]
@@ -369,7 +399,8 @@ class ShardedScanner:
     def flush(self):
         """Finish the scan still in flight (its maps end up in h_full / v_full, its cloud in xyz_full)."""
         if self.kind in ("maps", "xyz") and self._pending is not None:
-            self._finish(self._pending)
+            with self._whole_image():
+                self._finish(self._pending)
             self._pending = None
 
     def scan(self, d_band_stack: int, plane_stride: int, n_runs: int = 1, run_stride: int = 0, eps=1):
@@ -379,8 +410,13 @@ class ShardedScanner:
             return self.scan_maps(d_band_stack, plane_stride, n_runs, run_stride, eps)
         if self.kind == "xyz":
             self.flush()
-            self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
+            with self._whole_image():
+                self._submit_xyz(d_band_stack, plane_stride, n_runs, run_stride, eps)
             return self.flush()
+        with self._whole_image():
+            return self._scan_records(d_band_stack, plane_stride, n_runs, run_stride, eps)
+
+    def _scan_records(self, d_band_stack, plane_stride, n_runs, run_stride, eps):
         c, W = self.ctx, self.plan.W
         band_px = self.rows * W
         c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0,

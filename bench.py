@@ -327,10 +327,11 @@ def main():
                     help="extra bytes between frame planes in HBM (multiple of 16; 0 = contiguous [N,H,W] like the reference)")
     ap.add_argument("--preheat", type=float, default=PREHEAT_S,
                     help="seconds of untimed back-to-back scans before the counted warm-up (clock ramp of a fresh box); 0 under a counter profiler")
-    ap.add_argument("--scene", default="s-scene", choices=["s-scene", "physical"],
-                    help="synthetic capture of the timed region: SURVEY.md 8(d)'s S-scene (arbitrary smooth code maps, ~80 %% of the pixels decodable: the "
-                         "heavier input, default) or the physically consistent plane + sphere scene (slgc_synth_physical_dev: epipolar-consistent codes, "
-                         "12-28 %% of the pixels lit with the benchmark calibrations); the other one is timed as an extra leg of the same run")
+    ap.add_argument("--scene", default="physical", choices=["s-scene", "physical"],
+                    help="synthetic capture of the timed region: the physically consistent plane + sphere scene (slgc_synth_physical_dev: one surface "
+                         "seen by camera and projector through the benchmark calibration, 9-28 %% of the camera pixels lit; default) or SURVEY.md 8(d)'s "
+                         "S-scene (arbitrary smooth code maps, ~80 %% decodable but epipolar-inconsistent).  The kernels do the same work per pixel "
+                         "whether it decodes or not; the other scene is timed as an extra leg of the same run, and the decode-only legs always use the S-scene")
     ap.add_argument("--image-rows", type=int, default=0,
                     help="single-GPU band workloads: height of the whole image the band belongs to (slgc_tune image_rows; 0 = the band is the image)")
     ap.add_argument("--sustained", type=float, default=1.0,
@@ -433,11 +434,15 @@ def run_rank(args, rank, local_rank, world):
         ctx.tune("image_rows", args.image_rows)
     # per-calibration work, hoisted out of the scans and timed on its own: both undistortPoints calls evaluated into the two ray tables
     ctx.synchronize()
+    if use_comm:
+        ctx.tune("image_rows", cam_h)       # what the scanner sets around its own calls: the tables built here are the ones it will use
     ctx.event_record(0)
     ctx.build_ray_tables_dev(cam_h if use_comm and args.exchange == "maps" else rows, cam_w, 0 if use_comm and args.exchange == "maps" else row0,
                              (proj_w, proj_h))
     ctx.event_record(1)
     luts_us = ctx.event_elapsed_ms(0, 1) * 1e3
+    if use_comm:
+        ctx.tune("image_rows", 0)
     ctx.synchronize()
     pipelined = use_comm and args.exchange in ("maps", "xyz") and not args.no_overlap
 
@@ -507,6 +512,7 @@ def run_rank(args, rank, local_rank, world):
         # takes the guarded float64 path), physical = one surface seen by camera and projector (few lit pixels with these calibrations)
         o_name = "physical" if args.scene == "s-scene" else "s-scene"
         o_stacks = make_stacks(o_name)
+        s_scene_stacks = o_stacks if o_name == "s-scene" else stacks
         o_el, o_kms, o_kn, _, o_samples = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, src=o_stacks)
         o_exec = ctx.last_scan_path()
         o_valid, o_flag = scene_stats(o_stacks)
@@ -514,8 +520,6 @@ def run_rank(args, rank, local_rank, world):
         if o_name == "physical" or args.scene == "physical":
             acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), calib, maps, xyz, band_px, mode_fused)
         other_scene = (o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc)
-        for b in o_stacks:
-            b.free()
 
     sustained = None
     if single and not args.no_extras and args.sustained > 0:
@@ -531,12 +535,13 @@ def run_rank(args, rank, local_rank, world):
     if extras:
         # the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way)
         for i in range(3):
-            ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
         ctx.synchronize()
         ctx.prof_begin(args.steps + 8)
         for i in range(args.steps):
-            ctx.decode_dev(stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
         dec_alone = ctx.prof_end() + (ctx.prof_samples(),)
+        dec_alone_exec = ctx.last_scan_path()
 
     ref_product = None
     if extras and hasattr(ctx, "cloud_lists_dev"):
@@ -653,9 +658,9 @@ def run_rank(args, rank, local_rank, world):
                                          "roofline": kernel_roofline("fused" if other_executed["path"] == "fused" else "split", o_kms, o_kn, o_samples, other_executed),
                                          "note": "same scan, same run, timed right after the main region"}
         if dec_alone is not None:
-            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", *dec_alone),
-                                          "note": "decode kernel launched back to back on the rotated stacks, same run (the north star's "
-                                                  ">= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
+            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", *dec_alone, ex=dec_alone_exec), "scene": "s-scene",
+                                          "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "
+                                                  "kernel's heavier input), same run (the north star's >= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
         if ref_product is not None:
             out["reference_product"] = ref_product
         if sustained is not None:
@@ -787,11 +792,14 @@ class GpuSampler:
     """Shader clock and busy percentage of the GPU from sysfs (amdgpu: pp_dpm_sclk marks the active level with '*', gpu_busy_percent),
     sampled from a thread while a leg runs.  Whatever is not readable on this box stays None."""
 
-    def __init__(self, period=0.05):
+    def __init__(self, pci=None, period=0.05):
         import glob
         import threading
         self.period, self.clk, self.busy = period, [], []
-        self.dev = next((d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))), None)
+        cands = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+        mine = [d for d in cands if pci and os.path.basename(os.path.realpath(d)).lower() == pci]      # the HIP device's own node, by PCI address
+        direct = os.path.join("/sys/bus/pci/devices", pci or "-")
+        self.dev = mine[0] if mine else direct if os.path.exists(os.path.join(direct, "pp_dpm_sclk")) else (cands[0] if len(cands) == 1 else None)
         self._stop = threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
 
@@ -831,7 +839,11 @@ def sustained_leg(ctx, step, drain, seconds, mpix_per_step):
     """The headline step launched back to back for `seconds` (>= 1 s: long enough for an SMI sampler -- the driver's or the one here -- to see
     the GPU busy), one host synchronisation every 64 scans."""
     n = 0
-    with GpuSampler() as smp:
+    try:
+        pci = ctx.device_pci_bus_id()
+    except Exception:  # noqa: BLE001
+        pci = None
+    with GpuSampler(pci) as smp:
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             for _ in range(64):

@@ -100,6 +100,8 @@ enum {
 };
 int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
+/* PCI address of the context's device, "0000:c1:00.0" (how bench.py finds the device's clock / busy nodes under /sys/bus/pci/devices). */
+int slgc_device_pci_bus_id(slgc_ctx *ctx, char *buf, int buflen);
 
 /* ------------------------------------------------------------------ decode, host buffers */
 

@@ -52,7 +52,7 @@ def test_generator_equals_numpy_twin(ctx, case):
     """Stack bytes, encoded codes and true points bit-identical with oracle_np.synth_physical (float64 + - * / sqrt in one order)."""
     if case == "bench_c1_crop":
         W, H, pw, ph, N = 1280, 720, 1280, 800, 42
-        calib, row0, rows = bench.calibration(W, H, pw, ph), 200, 96
+        calib, row0, rows = bench.calibration(W, H, pw, ph), 420, 96
     elif case == "matched":
         W, H, pw, ph, N = 320, 200, 256, 192, 34
         calib, row0, rows = matched_rig(W, H, pw, ph), 0, H

@@ -59,7 +59,7 @@ class Board:
 class StagedExchange:
     """RcclExchange protocol over device pointers, staged through shared host memory.  mode: sync | deferred | thread (module docstring)."""
 
-    def __init__(self, ctx, native, rank, world, handle, mode="sync", delay_s=0.02):
+    def __init__(self, ctx, native, rank, world, handle, mode="sync", delay_s=0.004):
         path, nbytes, self.bar, self.words = handle
         self.ctx, self.native, self.rank, self.nranks, self.mode, self.delay = ctx, native, rank, world, mode, delay_s
         self.host = np.memmap(path, dtype=np.uint8, mode="r+", shape=(nbytes,))
@@ -312,8 +312,9 @@ def test_sharded_scanner_ranks_share_one_gpu(world, H, mode):
     results = _run_ranks(_worker_small, world, H * W * 16, (mode, H, W, N))
     assert len({tuple(info[0]) for _, _, info in results}) == 1
     for _, _, (_, stats) in results:
-        assert stats["begun"] == stats["waited"] > 0                                  # every exchange that was begun was waited for
-        if mode != "sync":
+        assert stats["begun"] > 0
+        if mode != "sync":                                                            # (sync: complete on return, nothing left to wait for)
+            assert stats["begun"] == stats["waited"]                                  # every exchange that was begun was waited for
             assert stats["max_pending"] >= 2                                          # ... and exchanges really were in flight across calls
 
 
