@@ -1268,11 +1268,48 @@ extern "C" int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!d_h || !d_v || !d_cam_pts || !d_proj_pts || !d_total) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
-    if ((d_xyz == nullptr) != (d_pts == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "d_xyz and d_pts go together");
+    if (d_xyz && !d_pts) return slgc_fail(ctx, SLGC_EINVAL, "d_xyz without d_pts");
     if (d_colors && !d_white_rgb) return slgc_fail(ctx, SLGC_EINVAL, "colours need the white image");
     if (cam_w < 0 || cam_h < 0 || proj_w < 1 || proj_h < 1) return slgc_fail(ctx, SLGC_EINVAL, "bad size");
+    if (d_pts && !d_xyz) {          // points wanted, no dense XYZ given: triangulate every valid pixel inside the list build (slgc_cloud_dev's second half)
+        if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+        if ((size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad projector size");
+        if ((rc = ensure_luts(ctx, cam_h, cam_w, 0, proj_w, proj_h))) return rc;
+        return launch_cloud_tri(ctx, d_h, d_v, d_colors ? d_white_rgb : nullptr, cam_w, cam_h, proj_w, proj_h, d_cam_pts, d_proj_pts, d_pts, d_colors, d_total);
+    }
     return launch_cloud_lists(ctx, d_h, d_v, d_xyz, d_colors ? d_white_rgb : nullptr, cam_w, cam_h, proj_w, proj_h, d_cam_pts, d_proj_pts, d_pts,
                               d_colors, d_total);
+}
+
+extern "C" int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int cam_h, int cam_w,
+                              int proj_w, int proj_h, double eps, double m, const uint8_t *d_white_rgb, int16_t *d_h, int16_t *d_v, float *d_cam_pts,
+                              float *d_proj_pts, double *d_pts, double *d_colors, unsigned long long *d_total)
+{
+    (void)m;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_cam_pts || !d_proj_pts || !d_total) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (d_colors && !d_white_rgb) return slgc_fail(ctx, SLGC_EINVAL, "colours need the white image");
+    if ((d_h == nullptr) != (d_v == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "d_h and d_v go together");
+    if (proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad projector size");
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, cam_h, cam_w, eps, &g, &runs, &e))) return rc;
+    if (!d_h) {
+        void *maps;
+        if ((rc = slgc_ws(ctx, 3, (size_t)cam_h * cam_w * 4 + 64, &maps))) return rc;
+        d_h = (int16_t *)maps;
+        d_v = d_h + (((size_t)cam_h * cam_w + 31) & ~(size_t)31);
+    }
+    if ((rc = ensure_luts(ctx, cam_h, cam_w, 0, proj_w, proj_h))) return rc;
+    ctx->last_ragged = 0;
+    if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, cam_h, cam_w, e, d_h, d_v, 0))) return rc;
+    if ((rc = launch_cloud_tri(ctx, d_h, d_v, d_colors ? d_white_rgb : nullptr, cam_w, cam_h, proj_w, proj_h, d_cam_pts, d_proj_pts, d_pts, d_colors, d_total)))
+        return rc;
+    ctx->last_scan_path = SLGC_PATH_CLOUD;
+    return SLGC_OK;
 }
 
 extern "C" int slgc_compact_dev(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,

@@ -158,15 +158,29 @@ __device__ __forceinline__ double unit_of_byte(unsigned b)
     return __builtin_fma(__builtin_fma(-q, 255.0, x), rcp, q);
 }
 
-// XYZ = true (device-resident product, slgc_cloud_lists_dev): the dense float32 XYZ of the scan rides through the same transpose and
+// SRC = 1 (device-resident product, slgc_cloud_lists_dev): the dense float32 XYZ of the scan rides through the same transpose and
 // leaves as the reference's float64 (3,M) array (triangulate.py:95; M = *total, written by the column scan before this kernel runs).
-template <typename MapT, bool XYZ, int TC>
-__global__ void __launch_bounds__(kScatterThreads, XYZ ? 6 : 4)
+// SRC = 2 (slgc_cloud_dev): there is no dense XYZ -- the tile's camera rays ride through the transpose (per-pixel table, or the 19 nodes per
+// row the tile's 16 groups interpolate from) and every valid pixel is triangulated where it is written: projector ray gathered from its table,
+// triangulate1 = the fused scan kernel's arithmetic, bit for bit.  Saves the scan 12 B/pixel of XYZ written and 12 B/pixel read back.
+struct TriScatter {
+    const float2 *cam_lut;     // [H][W] exact camera rays
+    CamNodes cn;               // every-4th-column nodes (cn.nodes == nullptr: read cam_lut)
+    const float2 *proj_lut;
+    int ptiles_x, wide;
+    TriF32 kf;
+    double T[3], t_len;
+};
+
+template <typename MapT, int SRC, int TC>
+__global__ void __launch_bounds__(kScatterThreads, SRC == 1 ? 6 : 4)
 k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H, int proj_w, int proj_h, const uint8_t *__restrict__ white,
                  const unsigned *__restrict__ counts, const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
                  float *__restrict__ proj, double *__restrict__ colors, const float *__restrict__ xyz, double *__restrict__ pts,
-                 const unsigned long long *__restrict__ total, int tiles_x, int abl)
+                 const unsigned long long *__restrict__ total, int tiles_x, int abl, const TriScatter ts)
 {
+    constexpr bool XYZ = SRC == 1, TRI = SRC == 2;
+    static_assert(!TRI || TC == 64, "the in-kernel triangulation is written for 64-column tiles (16 four-pixel groups + 3 nodes per row)");
     constexpr bool PACKED = sizeof(MapT) == 2;          // int16 maps: (pu, pv) share a dword; int64 maps (API parity) keep 32 bits each
     constexpr int TR = kTilePixels / TC, NSEG = TR / kSegRows;
     constexpr int CPH = TC >= 16 ? TC / 16 : 1;         // columns one half-wave writes
@@ -178,6 +192,7 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
     __shared__ int s_pv[PACKED ? 1 : TR][PACKED ? 1 : TC + 1];
     __shared__ unsigned s_white[TR][WD + 1];            // +1: rows land in different banks
     __shared__ float s_xyz[XYZ ? TR : 1][XYZ ? 3 * TC + 1 : 1];
+    __shared__ float2 s_cam[TRI ? TR : 1][TRI ? TC + 1 : 1];      // the tile's camera rays -- or, with the node table, nodes 0..18 of each row in [row][0..18]
     __shared__ unsigned long long s_base[NSEG][TC];     // where each column segment's first record goes
     const int tid = threadIdx.x, lane = tid & 63;
     const int x_tile = (int)(blockIdx.x % (unsigned)tiles_x) * TC, y_tile = (int)(blockIdx.x / (unsigned)tiles_x) * TR;
@@ -186,7 +201,8 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
     const bool white_dwords = colors && !LISTS_ABL(16) && (((uintptr_t)white | (unsigned)W) & 3u) == 0 && npix >= 2;   // row starts dword aligned
     const bool white_bytes = colors && !LISTS_ABL(16) && !white_dwords;
     unsigned long long M = 0;
-    if constexpr (XYZ) M = *total;
+    if constexpr (XYZ || TRI) M = *total;
+    const bool nodes = TRI && ts.cn.nodes != nullptr;
 
     // Phase 1: unconditional loads on clamped addresses (rows past H re-read row H - 1, elements past the image its last one; phase 2
     // never looks at those slots), all of a lane's loads in flight together.
@@ -206,6 +222,22 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
         for (int q = 0; q < NX; ++q) {
             const int i = q * kScatterThreads + tid, row = i / (3 * TC), k = i % (3 * TC);
             xq[q] = LISTS_ABL(8) ? 0.0f : xyz[min(3 * ((size_t)min(y_tile + row, H - 1) * W + x_tile) + k, 3 * npix - 1)];
+        }
+    }
+    float2 cq[TRI ? NM : 1];
+    if constexpr (TRI) {
+        if (nodes) {                                        // 19 nodes per row: node n of the table row sits at x = 4 (n - 1); the tile's groups need x_tile / 4 .. + 18
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = min(q * kScatterThreads + tid, TR * 19 - 1), row = i / 19, n = i % 19;
+                cq[q] = ts.cn.nodes[(size_t)min(y_tile + row, H - 1) * ts.cn.ne + min((uint32_t)(x_tile / 4 + n), ts.cn.ne - 1u)];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int i = q * kScatterThreads + tid, row = i / TC, col = i % TC;
+                cq[q] = ts.cam_lut[min((size_t)min(y_tile + row, H - 1) * W + x_tile + col, npix - 1)];
+            }
         }
     }
 #pragma unroll
@@ -252,6 +284,21 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
             s_xyz[i / (3 * TC)][i % (3 * TC)] = xq[q];
         }
     }
+    if constexpr (TRI) {
+        if (nodes) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = q * kScatterThreads + tid;
+                if (i < TR * 19) s_cam[i / 19][i % 19] = cq[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NM; ++q) {
+                const int i = q * kScatterThreads + tid;
+                s_cam[i / TC][i % TC] = cq[q];
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const int i = q * kScatterThreads + tid;
@@ -269,6 +316,18 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
         const int j = k * 32 + r;
         rec_lane[k] = (half * 32 + j / 3) * 4;
         ch_shift[k] = 8 * (j % 3);
+    }
+    // SRC == 2: the projector rays of this lane's CPH pixels are requested now, all in flight together (unconditional: an undecodable pixel
+    // reads entry 0, unused) -- not one memory round trip per column inside the loop
+    float2 prj[TRI ? CPH : 1];
+    if constexpr (TRI) {
+        static_assert(!TRI || (SPLIT == 1 && SPH == 1), "one segment per column and half-wave");
+#pragma unroll
+        for (int j = 0; j < CPH; ++j) {
+            const unsigned hv = s_hv[r][hw + 16 * j];
+            const bool ok = hv != kInvalidHV;
+            prj[j] = ts.proj_lut[ok ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+        }
     }
 #pragma unroll
     for (int j = 0; j < CPH; ++j) {
@@ -294,6 +353,33 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
                     pts[o] = (double)s_xyz[row][3 * c];                              // Pts (3,M) float64, :95
                     pts[M + o] = (double)s_xyz[row][3 * c + 1];
                     pts[2 * M + o] = (double)s_xyz[row][3 * c + 2];
+                }
+                if constexpr (TRI) {
+                    // triangulate.py:84-95 for this correspondence, as the fused scan kernel evaluates it (tri_math.h): camera ray of pixel
+                    // (x, y_tile + row), projector ray of the clamped (pu, pv) from its table
+                    const size_t pix = (size_t)(y_tile + row) * W + x;
+                    float cxr, cyr;
+                    if (nodes) {
+                        const int g = c >> 2;
+                        const float2 n0 = s_cam[row][g], n1 = s_cam[row][g + 1], n2 = s_cam[row][g + 2], n3 = s_cam[row][g + 3];
+                        float fx[4], fy[4];
+                        cam_rays_from_nodes(cam_v4f{n0.x, n0.y, n1.x, n1.y}, cam_v4f{n2.x, n2.y, n3.x, n3.y}, fx, fy);
+                        cam_rays_exact_where_tiny(fx, fy, ts.cam_lut + (pix - (size_t)(c & 3)));      // the group's decision, like the lane that owns it in the scan kernels
+                        const int j = c & 3;
+                        cxr = j == 0 ? fx[0] : j == 1 ? fx[1] : j == 2 ? fx[2] : fx[3];
+                        cyr = j == 0 ? fy[0] : j == 1 ? fy[1] : j == 2 ? fy[2] : fy[3];
+                    } else {
+                        const float2 cr = s_cam[row][c];
+                        cxr = cr.x;
+                        cyr = cr.y;
+                    }
+                    const float2 pr = prj[j];
+                    const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix);
+                    if (!LISTS_ABL(2)) {
+                        pts[o] = (double)r3.x;                                       // Pts (3,M) float64, :95
+                        pts[M + o] = (double)r3.y;
+                        pts[2 * M + o] = (double)r3.z;
+                    }
                 }
             }
             if (colors && !LISTS_ABL(4)) {
@@ -497,9 +583,9 @@ int compact(slgc_ctx *ctx, Pred pred, Emit emit, size_t n, unsigned long long *d
 }
 
 // The four passes of the x-major list build on ctx->stream (nothing synchronises with the host).
-template <typename MapT, bool XYZ>
+template <typename MapT, int SRC>
 int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int cam_h, int proj_w, int proj_h, const uint8_t *d_white, float *d_cam,
-                 float *d_proj, double *d_colors, const float *d_xyz, double *d_pts, unsigned long long *d_total)
+                 float *d_proj, double *d_colors, const float *d_xyz, double *d_pts, unsigned long long *d_total, const TriScatter &ts = TriScatter{})
 {
     constexpr int TC = SLGC_SCATTER_TC, TR = kTilePixels / TC;
     const size_t npix = (size_t)cam_w * cam_h;
@@ -517,9 +603,9 @@ int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int
     hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
     if (npix) {
         const int tiles_x = (cam_w + TC - 1) / TC, tiles_y = (cam_h + TR - 1) / TR;
-        hipLaunchKernelGGL((k_xmajor_scatter<MapT, XYZ, TC>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w,
+        hipLaunchKernelGGL((k_xmajor_scatter<MapT, SRC, TC>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w,
                            cam_h, proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_colors, d_xyz, d_pts,
-                           (const unsigned long long *)d_total, tiles_x, lists_abl());
+                           (const unsigned long long *)d_total, tiles_x, lists_abl(), ts);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
@@ -537,8 +623,8 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
         EmitCorr emit{d_h, d_v, d_white, cam_w, proj_w, proj_h, d_cam, d_proj, d_white ? d_colors : nullptr};
         return compact(ctx, pred, emit, npix, d_total);
     }
-    return xmajor_lists<int64_t, false>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
-                                        d_total);
+    return xmajor_lists<int64_t, 0>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
+                                    d_total);
 }
 
 // Device-resident form of the reference-shaped product (slgc_cloud_lists_dev): int16 maps + dense float32 XYZ (+ white image) ->
@@ -547,10 +633,31 @@ int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, co
                        int proj_w, int proj_h, float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total)
 {
     if (d_xyz && d_pts)
-        return xmajor_lists<int16_t, true>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, d_xyz, d_pts,
-                                           d_total);
-    return xmajor_lists<int16_t, false>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
+        return xmajor_lists<int16_t, 1>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, d_xyz, d_pts,
                                         d_total);
+    return xmajor_lists<int16_t, 0>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr,
+                                    d_total);
+}
+
+// slgc_cloud_dev: the same lists straight from the int16 maps -- every valid pixel triangulated inside the scatter (no dense XYZ anywhere).
+// The ray tables of the whole image must be in place (ensure_luts(cam_h, cam_w, 0, ...), done by the caller).
+int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const uint8_t *d_white, int cam_w, int cam_h, int proj_w, int proj_h,
+                     float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total)
+{
+    if (!d_pts)                      // lists only: nothing to triangulate
+        return xmajor_lists<int16_t, 0>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr, d_total);
+    TriScatter ts{};
+    ts.cam_lut = (const float2 *)ctx->lut_cam;
+    ts.cn = SLGC_CAM_NODES_FOR(ctx, cam_w, (size_t)cam_w * cam_h / 4 < (1u << 24));
+    ts.proj_lut = (const float2 *)ctx->lut_proj;
+    ts.ptiles_x = proj_tiles_x(ctx, proj_w);
+    ts.wide = ctx->tune_proj_tile;
+    ts.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
+    memcpy(ts.T, ctx->calib.T, sizeof ts.T);
+    ts.t_len = ctx->calib.t_len;
+    ctx->last_nodes = ts.cn.nodes ? 1 : 0;
+    ctx->last_guard = 1;
+    return xmajor_lists<int16_t, 2>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, d_pts, d_total, ts);
 }
 
 // pass 0: count only (total -> *d_total); pass 1: count again + scatter (outputs sized from pass 0's total).

@@ -147,6 +147,22 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
     }
 }
 
+// One pixel through the same arithmetic as triangulate4 (bit-identical results): the x-major scatter of slgc_cloud_dev triangulates a pixel where
+// it writes it.  cam_exact = this pixel's entry of the exact per-pixel camera table (read only on the guarded path).
+template <bool GUARD>
+__device__ __forceinline__ Xyzf triangulate1(float cx, float cy, float px, float py, const TriF32 &k, const double (&T)[3], double t_len,
+                                             const float2 *__restrict__ cam_exact)
+{
+    const TriFastTerms t = tri_fast_terms(cx, cy, px, py, k);
+    const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
+    Xyzf r{cx * s, cy * s, s};
+    if (GUARD && tri_flat(t, cx, cy, px, py, k)) {
+        const float2 cr = *cam_exact;
+        r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{px, py}, T, t_len);
+    }
+    return r;
+}
+
 // ---- camera rays from a table kept at every 4th column (CamNodes) ----
 // The camera ray table is the largest non-algorithmic stream of the scan kernels (8 B / pixel).  Along a row the ray is a smooth function of
 // x, so the kernels can read NODES at x = -4, 0, 4, ..., W + 4 of every row (2 B / pixel) and put the cubic through the four nodes around

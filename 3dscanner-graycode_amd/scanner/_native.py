@@ -73,6 +73,7 @@ SIGNATURES = {
     "slgc_selftest_classify": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_cloud_lists_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "slgc_cloud_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slgc_pack_hv24_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
@@ -313,7 +314,7 @@ class Context:
         """0 = uint8 stack as given, 1 = float64 stack narrowed to uint8 on the host, 2 = float64 kernel (slgc_last_input_path)."""
         return int(lib().slgc_last_input_path(self._h))
 
-    SCAN_PATHS = {0: "none", 1: "fused", 2: "split", 3: "split-ragged", 4: "batch-fused"}
+    SCAN_PATHS = {0: "none", 1: "fused", 2: "split", 3: "split-ragged", 4: "batch-fused", 5: "cloud"}
 
     def last_scan_path(self) -> dict:
         """Which kernels the last scan_dev / scan_batch_dev call launched (slgc_last_scan_path): {"path": "fused" | "split" |
@@ -569,10 +570,19 @@ class Context:
     def cloud_lists_dev(self, d_h: int, d_v: int, d_xyz, d_white, cam_w, cam_h, proj_size, lists: CloudLists):
         """int16 maps + dense float32 XYZ (+ device-resident uint8 RGB white image) -> the reference's x-major lists, float64 (3,M)
         points and colours, all in HBM (asynchronous).  d_xyz / d_white may be None."""
-        self._ck(lib().slgc_cloud_lists_dev(self._h, d_h, d_v, d_xyz if lists.pts is not None else None,
+        self._ck(lib().slgc_cloud_lists_dev(self._h, d_h, d_v, d_xyz if lists.pts is not None else None,      # d_xyz None + points wanted: triangulated in-kernel
                                             d_white if lists.colors is not None else None, int(cam_w), int(cam_h), int(proj_size[0]),
                                             int(proj_size[1]), lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
                                             lists.colors.ptr if lists.colors is not None else None, lists.count.ptr))
+
+    def cloud_dev(self, d_stack: int, n_runs, run_stride, plane_stride, N, cam_h, cam_w, proj_size, d_white, lists: CloudLists, d_h=None, d_v=None,
+                  eps=1, m=10):
+        """Whole scan -> the reference-shaped lists in one call (slgc_cloud_dev): decode kernel, then the x-major list build with the
+        triangulation inside it -- no dense XYZ.  lists.pts / lists.colors may be absent."""
+        self._ck(lib().slgc_cloud_dev(self._h, d_stack, int(n_runs), int(run_stride), int(plane_stride), int(N), int(cam_h), int(cam_w),
+                                      int(proj_size[0]), int(proj_size[1]), float(eps), float(m), d_white if lists.colors is not None else None, d_h, d_v,
+                                      lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
+                                      lists.colors.ptr if lists.colors is not None else None, lists.count.ptr))
 
     def compact_dev(self, d_xyz: int, rows, W, row0, d_points: int, d_keys, d_count: int):
         self._ck(lib().slgc_compact_dev(self._h, d_xyz, rows, W, row0, d_points, d_keys, d_count))

@@ -544,8 +544,9 @@ def run_rank(args, rank, local_rank, world):
         dec_alone_exec = ctx.last_scan_path()
 
     ref_product = None
-    if extras and hasattr(ctx, "cloud_lists_dev"):
-        ref_product = reference_product(ctx, _native, stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
+    if extras and row0 == 0:
+        ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
+        ref_product["scene"] = "s-scene"
 
     thr = thr_batched = None
     if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
@@ -856,40 +857,59 @@ def sustained_leg(ctx, step, drain, seconds, mpix_per_step):
 
 
 def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, maps, xyz, band_px, steps, mode_fused):
-    """The reference-shaped product, device resident: fused scan -> x-major cam_pts / proj_pts (float32 [M,2]), Pts float64 (3,M) and
-    colors float64 [M,3] gathered from a device-resident white image (triangulate.py:52-71, 95).  Timed end to end per scan."""
+    """The reference-shaped product, device resident: x-major cam_pts / proj_pts (float32 [M,2]), Pts float64 (3,M) and colors float64
+    [M,3] gathered from a device-resident white image (triangulate.py:52-71, 84-95).  Timed end to end per scan, two ways:
+    slgc_cloud_dev (decode kernel + list build that triangulates in-kernel: no dense XYZ) and, for comparison, round 2's
+    slgc_scan_dev + slgc_cloud_lists_dev (fused scan writes dense XYZ, the list build reads it back)."""
     white = ctx.alloc(band_px * 3)
     ctx.dev_memset(white.ptr, 0x80, band_px * 3)
     lists = ctx.alloc_cloud_lists(band_px, colors=True)
     K = max(5, steps // 4)
 
-    def one(i):
+    def via_cloud(i):
+        s = stacks[i % len(stacks)]
+        ctx.cloud_dev(s.ptr, 1, N * plane, plane, N, rows, W, proj_size, white.ptr, lists, d_h=maps.at(0), d_v=maps.at(band_px * 2))
+
+    def via_dense(i):
         s = stacks[i % len(stacks)]
         ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, W, row0, proj_size, xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode_fused)
         ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), xyz.ptr, white.ptr, W, rows, proj_size, lists)
 
-    for i in range(3):
-        one(i)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for i in range(K):
-        one(i)
-    ctx.synchronize()
-    el = time.perf_counter() - t0
+    def run(one):
+        for i in range(3):
+            one(i)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            one(i)
+        ctx.synchronize()
+        return time.perf_counter() - t0
+
+    el_dense = run(via_dense)
+    el = run(via_cloud)
+    executed = ctx.last_scan_path()
     M = lists.total()
-    # bytes of the list stage: maps read twice (count + scatter) 8, XYZ 12, white 3 per pixel in; 8 + 8 + 24 + 24 per valid pixel out
-    stage_bytes = band_px * (8 + 12 + 3) + M * 64
+    # the list stage alone: decode once, then K list builds back to back (maps stay in place)
+    ctx.decode_dev(stacks[0].ptr, 1, N * plane, plane, N, rows, W, maps.at(0), maps.at(band_px * 2))
     ctx.event_record(2)
     for _ in range(K):
-        ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), xyz.ptr, white.ptr, W, rows, proj_size, lists)
+        ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), None, white.ptr, W, rows, proj_size, lists)      # d_xyz = None: triangulate in-kernel
     ctx.event_record(3)
     stage_ms = ctx.event_elapsed_ms(2, 3) / K
+    # bytes of the list stage: maps read twice (count + scatter) 8, camera rays 2 (node table) or 8 (per-pixel table), white 3 per pixel
+    # in; 8 + 8 + 24 + 24 per valid pixel out
+    ray_b = 2 if executed["node_table"] else 8
+    stage_bytes = band_px * (8 + ray_b + 3) + M * 64
     out = {"value": round(band_px / 1e6 * K / el, 1), "unit": "Mpixels/s", "ms_per_scan": round(el / K * 1e3, 4), "steps": K, "points": int(M),
+           "executed": executed,
            "list_stage_ms": round(stage_ms, 4), "list_stage_bytes": int(stage_bytes),
            "list_stage_roofline": {"bound": "hbm", "achieved": round(stage_bytes / (stage_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-           "note": "fused scan + x-major list build (count, column prefix, LDS-transposed scatter with the colour gather and the float64 "
-                   "(3,M) points folded in); everything stays in HBM; list_stage_ms = the list build alone, mean of %d back-to-back builds" % K}
+           "via_dense_xyz": {"value": round(band_px / 1e6 * K / el_dense, 1), "ms_per_scan": round(el_dense / K * 1e3, 4),
+                             "note": "round 2's route: fused scan (writes 12 B/pixel of dense XYZ) + slgc_cloud_lists_dev (reads it back)"},
+           "note": "slgc_cloud_dev: decode kernel + x-major list build (count, column prefix, LDS-transposed scatter that triangulates each valid "
+                   "pixel in-kernel and folds in the colour gather and the float64 (3,M) points); everything stays in HBM, no dense XYZ; "
+                   "list_stage_ms = the list build alone, mean of %d back-to-back builds" % K}
     white.free()
     lists.free()
     return out

@@ -96,7 +96,8 @@ enum {
     SLGC_PATH_FUSED = 1,        /* one kernel: decode with the triangulation tail */
     SLGC_PATH_SPLIT = 2,        /* decode kernel + dense triangulation kernel, both on their vector paths */
     SLGC_PATH_SPLIT_RAGGED = 3, /* two kernels and a byte-wide / per-pixel fallback kernel took part (misaligned or ragged band) */
-    SLGC_PATH_BATCH_FUSED = 4   /* slgc_scan_batch_dev: all scans in one launch of the fused kernel */
+    SLGC_PATH_BATCH_FUSED = 4,  /* slgc_scan_batch_dev: all scans in one launch of the fused kernel */
+    SLGC_PATH_CLOUD = 5         /* slgc_cloud_dev: decode kernel + x-major list build that triangulates in-kernel (no dense XYZ) */
 };
 int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
@@ -255,10 +256,23 @@ int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, 
  * correspondence lists of get_cam_proj_pts (triangulate.py:52-71: columns outer, rows inner, clamp to the projector, colour =
  * white[y][x][:] / 255.0 from a device-resident uint8 RGB image) and, gathered in the same pass, the float64 (3,M) point array
  * Triangulate.triangulate returns (:95).  Asynchronous; *d_total (device) receives M; d_pts rows start at d_pts, d_pts + M,
- * d_pts + 2M.  Capacity of every list: cam_w * cam_h entries.  d_xyz / d_pts and d_white_rgb / d_colors may be NULL (pairwise). */
+ * d_pts + 2M.  Capacity of every list: cam_w * cam_h entries.  d_white_rgb / d_colors may be NULL (pairwise); d_pts may be NULL (lists
+ * only).  d_xyz = NULL with d_pts given: there is no dense XYZ -- every valid pixel is triangulated inside the list build from the maps and the
+ * ray tables (needs slgc_set_calibration; the second half of slgc_cloud_dev). */
 int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white_rgb, int cam_w,
                          int cam_h, int proj_w, int proj_h, float *d_cam_pts, float *d_proj_pts, double *d_pts, double *d_colors,
                          unsigned long long *d_total);
+
+/* The reference-shaped product of a whole scan in one call, nothing dense in between: decode the stack into the int16 maps (a product;
+ * d_h / d_v may be NULL: workspace), then build the x-major lists of get_cam_proj_pts (triangulate.py:52-71) with every valid pixel
+ * TRIANGULATED INSIDE the list build (triangulate.py:84-95; the fused scan kernel's arithmetic: same float32 XYZ, bit for bit, widened to the
+ * reference's float64 (3,M)) and its colour gathered from the device-resident white image (:64, :69).  Replaces slgc_scan_dev +
+ * slgc_cloud_lists_dev for callers that want the lists: the scan no longer writes 12 B/pixel of dense XYZ for the list build to read back.
+ * Whole images only (x-major order needs every row): rows = cam_h, row0 = 0.  Outputs as slgc_cloud_lists_dev (capacity cam_w * cam_h
+ * entries each; d_pts / d_colors may be NULL, d_colors needs d_white_rgb).  Asynchronous; *d_total (device) receives M. */
+int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int cam_h, int cam_w,
+                   int proj_w, int proj_h, double eps, double m, const uint8_t *d_white_rgb, int16_t *d_h, int16_t *d_v, float *d_cam_pts,
+                   float *d_proj_pts, double *d_pts, double *d_colors, unsigned long long *d_total);
 
 /* Row-major compaction of a dense band: keeps pixels with finite XYZ; writes float32 [M][3] points and uint32
  * linear pixel keys ((row0+y)*W + x); *d_count (device) receives M.  Capacity of outputs: rows*W records. */

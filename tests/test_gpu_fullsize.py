@@ -329,3 +329,67 @@ def test_executed_path_is_observable(ctx, workload):
     ctx.synchronize()
     for b in (stack, maps, xyz, cnt):
         b.free()
+
+
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "ragged", "ragged4"])
+def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
+    """slgc_cloud_dev: decode kernel, then the x-major list build with the triangulation INSIDE it (no dense XYZ round trip) -- the lists of
+    get_cam_proj_pts (triangulate.py:52-71) bit-exact against the oracle, the float64 (3,M) points (:84-95) bit-identical with the fused scan
+    kernel's float32 XYZ where that kernel runs (4096x3000: camera rays from the node table; 1920x1080: per-pixel table) and within 1e-4 of the
+    oracle's triangulation everywhere, on shapes that are not a multiple of the 64-column tile / 32-row chunk / 4-pixel group too."""
+    from scanner import _native
+    rng = np.random.default_rng(7)
+    if workload.startswith("ragged"):
+        W, H, pw, ph, N = (332, 77, 300, 200, 44) if workload == "ragged4" else (331, 45, 300, 200, 26)
+        K = np.array([[300.0, 0, W / 2], [0, 300.0, H / 2], [0, 0, 1]])
+        _, cd, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
+        calib = (K, cd, pk, pd, R, T)
+    else:
+        W, H, pw, ph, N = bench.WORKLOADS[workload]
+        calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    ctx.tune("cam_nodes", 1)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, seed=3, noise=3, shadow=True)
+    maps, maps2, xyz = ctx.alloc(px * 4 + 64), ctx.alloc(px * 4 + 64), ctx.alloc(px * 12)
+    voff = (px * 2 + 31) // 32 * 32
+    white_h = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    white = ctx.alloc(px * 3).upload(white_h)
+    lists = ctx.alloc_cloud_lists(px, colors=True)
+    ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, lists, d_h=maps.at(0), d_v=maps.at(voff))
+    path = ctx.last_scan_path()
+    assert path["path"] == "cloud" and path["node_table"] == (W * H * 8 > 64 << 20 and W % 4 == 0)
+    cam, proj, pts, col = lists.download()
+    h = maps.download((H, W), np.int16).astype(np.int64)
+    v = maps.download((H, W), np.int16, voff).astype(np.int64)
+    st = stack.download((N, H, W), np.uint8)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+    assert np.array_equal(h, ref_h) and np.array_equal(v, ref_v)
+    rcam, rproj, rcol = oc.cam_proj_pts(h, v, (W, H), (pw, ph), white_h, order="x")
+    assert len(rcam) > 0.5 * px
+    assert np.array_equal(cam, rcam) and np.array_equal(proj, rproj) and np.array_equal(col, rcol)
+    xs, ys = rcam[:, 0].astype(np.int64), rcam[:, 1].astype(np.int64)
+    want = ref_xyz[:, ys, xs]                                              # (3, M) float64, the oracle's triangulate.py:84-95
+    assert pts.shape == want.shape
+    fin = np.isfinite(want).all(axis=0)
+    assert np.array_equal(np.isfinite(pts).all(axis=0), fin)
+    err = np.abs(pts[:, fin] - want[:, fin]) / np.maximum(np.abs(want[:, fin]), 1e-300)
+    assert float(err.max()) <= XYZ_RTOL
+    # the same points as the fused scan kernel's dense XYZ, bit for bit (both run tri_math.h on the same rays)
+    ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps2.at(0), maps2.at(voff), mode=_native.TRI_ALGEBRAIC)
+    if ctx.last_scan_path()["path"] == "fused":
+        dense = xyz.download((H, W, 3), np.float32)
+        assert np.array_equal(pts, dense[ys, xs].astype(np.float64).T)
+    else:
+        assert workload == "ragged"                                        # 331 x 45 pixels are not a whole number of 4-pixel groups
+    # lists only (no points, no colours), maps in the library's workspace
+    bare = ctx.alloc_cloud_lists(px, colors=False, points=False)
+    ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), None, bare)
+    c2, p2, none_pts, none_col = bare.download()
+    assert none_pts is None and none_col is None and np.array_equal(c2, rcam) and np.array_equal(p2, rproj)
+    print(f"\n{workload}: {len(rcam)} points, worst rel. XYZ error vs the oracle {float(err.max()):.2e}, {path}")
+    for b in (stack, maps, maps2, xyz, white):
+        b.free()
+    lists.free()
+    bare.free()

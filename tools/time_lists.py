@@ -20,7 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c3_4096x3000x44")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=4)
-ap.add_argument("--knobs", default="xcd=0,1")
+ap.add_argument("--knobs", default="route=0,1", help="a slgc_tune knob, or route=0,1: 0 = the points come from the fused scan's dense XYZ, "
+                                                     "1 = triangulated inside the list build (slgc_cloud_dev's second half); both give the same lists")
 args = ap.parse_args()
 W, H, pw, ph, N = bench.WORKLOADS[args.workload]
 px = W * H
@@ -36,15 +37,21 @@ name, vals = args.knobs.split("=")
 vals = [int(v) for v in vals.split(",")]
 
 
+route = 0
+
+
 def one():
-    ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), xyz.ptr, white.ptr, W, H, (pw, ph), lists)
+    ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), xyz.ptr if route == 0 else None, white.ptr, W, H, (pw, ph), lists)
 
 
 res = {v: [] for v in vals}
 dig = {}
 for r in range(args.rounds):
     for v in vals:
-        ctx.tune(name, v)
+        if name == "route":
+            route = v
+        else:
+            ctx.tune(name, v)
         for _ in range(3):
             one()
         ctx.synchronize()
