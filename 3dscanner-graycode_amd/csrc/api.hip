@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_util.h"
 #include "slgc_internal.h"
 #include "tri_math.h"
 
@@ -74,58 +75,7 @@ int check_ctx(slgc_ctx *ctx)
 
 size_t esize(int dtype) { return dtype == SLGC_F64 ? 8 : 1; }
 
-// The reference's own caller hands over a float64 stack whose values are uint8 grey levels (src/3-capture_decode.py:66-70:
-// cv2.cvtColor output copied into an np.zeros float64 array).  Shipping it as it is costs 8 bytes per sample over PCIe and forces
-// the float64 kernel; instead the host side of the C-ABI narrows it: every sample is checked to be an integer in [0, 255]
-// and written as one byte into pinned staging, on host threads.  The FIRST sample that is not (a fraction, a negative, > 255,
-// NaN, inf) aborts the narrowing and the call falls back to the float64 kernel -- same arithmetic, same results either way
-// (a uint8 stack means "these grey levels").  Returns true when `dst` holds the narrowed samples of all runs.
-bool narrow_f64_to_u8(const void *const *stacks, int n_runs, size_t elems, uint8_t *dst)
-{
-    const size_t total = elems * (size_t)n_runs;
-    if (total == 0) return true;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nthr = hw ? hw : 4;
-    if (nthr > 16) nthr = 16;
-    const size_t chunk = 1u << 20;                               // samples per work item (8 MB of float64)
-    const size_t nchunks = (total + chunk - 1) / chunk;
-    if (nthr > nchunks) nthr = nchunks;
-    std::atomic<size_t> next{0};
-    std::atomic<bool> bad{false};
-    auto work = [&]() {
-        for (;;) {
-            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
-            if (c >= nchunks || bad.load(std::memory_order_relaxed)) return;
-            const size_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
-            size_t i = lo;
-            while (i < hi) {
-                const size_t r = i / elems, off = i - r * elems;
-                const size_t n = (hi - i) < (elems - off) ? (hi - i) : (elems - off);     // stay inside run r
-                const double *src = (const double *)stacks[r] + off;
-                uint8_t *out = dst + i;
-                unsigned wrong = 0;
-                for (size_t k = 0; k < n; ++k) {
-                    const double x = src[k];
-                    const bool in_range = (x >= 0.0) & (x <= 255.0);                      // false for NaN
-                    const int q = in_range ? (int)x : 0;
-                    out[k] = (uint8_t)q;
-                    wrong |= (unsigned)(!in_range) | (unsigned)((double)q != x);
-                }
-                if (wrong) {
-                    bad.store(true, std::memory_order_relaxed);
-                    return;
-                }
-                i += n;
-            }
-        }
-    };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    return !bad.load();
-}
-
+// narrow_f64_to_u8 and the staging-ring copy loop live in host_util.cpp (host only: unit-tested on the CPU under ASan / UBSan / TSan).
 int host_staging(slgc_ctx *ctx, size_t bytes, void **out)
 {
     if (ctx->stage_bytes < bytes) {
@@ -153,6 +103,27 @@ int host_staging(slgc_ctx *ctx, size_t bytes, void **out)
 constexpr size_t kDlChunk = 16u << 20;
 constexpr int kDlSlots = 4;
 
+struct DlRing {          // RingOps of download_par: chunk k lands in its pinned slot with a hipMemcpyAsync followed by the slot's event
+    slgc_ctx *ctx;
+    const char *d_src;
+    hipError_t err;
+};
+
+int dl_fetch(void *u, size_t k, void *slot, size_t offset, size_t nbytes)
+{
+    DlRing *r = (DlRing *)u;
+    r->err = hipMemcpyAsync(slot, r->d_src + offset, nbytes, hipMemcpyDeviceToHost, r->ctx->stream);
+    if (r->err == hipSuccess) r->err = hipEventRecord(r->ctx->dl_ev[k % kDlSlots], r->ctx->stream);
+    return r->err == hipSuccess ? 0 : 1;
+}
+
+int dl_wait(void *u, size_t k)
+{
+    DlRing *r = (DlRing *)u;
+    r->err = hipEventSynchronize(r->ctx->dl_ev[k % kDlSlots]);
+    return r->err == hipSuccess ? 0 : 1;
+}
+
 int download_par(slgc_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (bytes == 0 || !dst) return SLGC_OK;
@@ -171,69 +142,43 @@ int download_par(slgc_ctx *ctx, void *dst, const void *d_src, size_t bytes)
     if (!pinned && par && bytes >= (8u << 20)) {
         const uintptr_t lo = (uintptr_t)dst & ~(uintptr_t)4095, hi = ((uintptr_t)dst + bytes + 4095) & ~(uintptr_t)4095;
         const size_t pages = (hi - lo) >> 12;
-        std::vector<unsigned char> vec(pages);
-        if (mincore((void *)lo, hi - lo, vec.data()) == 0) {
+        unsigned char *vec = new (std::nothrow) unsigned char[pages];
+        if (vec && mincore((void *)lo, hi - lo, vec) == 0) {
             size_t seen = 0, in = 0;
             for (size_t i = 0; i < pages; i += 16, ++seen) in += vec[i] & 1u;
             resident = in * 10 >= seen * 9;
         }
+        delete[] vec;
     }
     if (pinned || resident || !par || bytes < (8u << 20) || nthr < 2) {
         HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return SLGC_OK;
     }
-    if (!ctx->dl_stage) {
-        if (hipHostMalloc(&ctx->dl_stage, kDlSlots * kDlChunk, hipHostMallocDefault) != hipSuccess)
-            return slgc_fail(ctx, SLGC_ENOMEM, "hipHostMalloc(%zu) failed", (size_t)kDlSlots * kDlChunk);
-        for (int i = 0; i < kDlSlots; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->dl_ev[i], hipEventDisableTiming));
+    if (!ctx->dl_stage) {                                                  // the ring exists only with all of its events
+        void *stage = nullptr;
+        hipEvent_t ev[kDlSlots] = {};
+        bool ok = hipHostMalloc(&stage, kDlSlots * kDlChunk, hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; i < kDlSlots && ok; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (int i = 0; i < kDlSlots; ++i)
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (stage) (void)hipHostFree(stage);
+            (void)hipGetLastError();
+            return slgc_fail(ctx, SLGC_ENOMEM, "pinned download ring (%zu bytes + %d events) could not be created", (size_t)kDlSlots * kDlChunk, kDlSlots);
+        }
+        for (int i = 0; i < kDlSlots; ++i) ctx->dl_ev[i] = ev[i];
+        ctx->dl_stage = stage;
     }
-    const size_t nchunks = (bytes + kDlChunk - 1) / kDlChunk;
-    const int parts = 8;                                                   // 2 MB slices of a chunk: one transparent huge page each, where the kernel grants them
     {
         const uintptr_t lo = ((uintptr_t)dst + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), hi = ((uintptr_t)dst + bytes) & ~(uintptr_t)((2u << 20) - 1);
-        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);  // fewer, larger first-touch faults; a no-op where THP is off
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);  // fewer, larger first-touch faults; a no-op where THP is off (the memory is the caller's: advice only)
     }
-    std::vector<std::atomic<int>> done(nchunks);
-    for (auto &d : done) d.store(0, std::memory_order_relaxed);
-    std::atomic<size_t> ready{0}, next{0};
-    std::atomic<bool> failed{false};
-    char *stage = (char *)ctx->dl_stage;
-    auto work = [&]() {
-        for (;;) {
-            const size_t task = next.fetch_add(1, std::memory_order_relaxed);
-            const size_t c = task / (size_t)parts, part = task % (size_t)parts;
-            if (c >= nchunks) return;
-            while (ready.load(std::memory_order_acquire) <= c) {
-                if (failed.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            const size_t n = c + 1 < nchunks ? kDlChunk : bytes - c * kDlChunk;
-            const size_t per = kDlChunk / parts;
-            const size_t lo = part * per < n ? part * per : n, hi = lo + per < n ? lo + per : n;
-            if (hi > lo && par != 2) memcpy((char *)dst + c * kDlChunk + lo, stage + (c % kDlSlots) * kDlChunk + lo, hi - lo);   // par == 2: transfers only (timing)
-            done[c].fetch_add(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
-    hipError_t err = hipSuccess;
-    for (size_t k = 0; k < nchunks && err == hipSuccess; ++k) {
-        if (k >= (size_t)kDlSlots)                                         // the slot's previous chunk must have left it
-            while (done[k - kDlSlots].load(std::memory_order_acquire) < parts) std::this_thread::yield();
-        const size_t n = k + 1 < nchunks ? kDlChunk : bytes - k * kDlChunk;
-        err = hipMemcpyAsync(stage + (k % kDlSlots) * kDlChunk, (const char *)d_src + k * kDlChunk, n, hipMemcpyDeviceToHost, ctx->stream);
-        if (err == hipSuccess) err = hipEventRecord(ctx->dl_ev[k % kDlSlots], ctx->stream);
-        if (err == hipSuccess && k >= 1) {
-            err = hipEventSynchronize(ctx->dl_ev[(k - 1) % kDlSlots]);
-            if (err == hipSuccess) ready.store(k, std::memory_order_release);
-        }
-    }
-    if (err == hipSuccess) err = hipEventSynchronize(ctx->dl_ev[(nchunks - 1) % kDlSlots]);
-    if (err == hipSuccess) ready.store(nchunks, std::memory_order_release);
-    else failed.store(true);
-    for (auto &t : pool) t.join();
-    if (err != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "download: %s", hipGetErrorString(err));
+    DlRing ring{ctx, (const char *)d_src, hipSuccess};
+    const slgc_host::RingOps ops{&ring, dl_fetch, dl_wait};
+    const int rc = slgc_host::ring_download(dst, bytes, ctx->dl_stage, kDlChunk, kDlSlots, 8, nthr, ops, par == 2 ? 0 : 1);      // 8 parts = 2 MB slices: one huge page each
+    if (rc < 0) return slgc_fail(ctx, SLGC_ENOMEM, "download: host threads / memory for the staging ring");
+    if (rc > 0) return slgc_fail(ctx, SLGC_EHIP, "download: %s", hipGetErrorString(ring.err));
     return SLGC_OK;
 }
 
@@ -251,7 +196,9 @@ int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs
         int rc = host_staging(ctx, elems * n_runs, &st);
         if (rc) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the staging buffer may still feed the previous call's copy
-        if (narrow_f64_to_u8(stacks, n_runs, elems, (uint8_t *)st)) {
+        const int narrowed = slgc_host::narrow_f64_to_u8(stacks, n_runs, elems, (uint8_t *)st);
+        if (narrowed < 0) return slgc_fail(ctx, SLGC_ENOMEM, "host threads for the float64 -> uint8 narrowing");
+        if (narrowed) {
             void *d;
             if ((rc = slgc_ws(ctx, 0, elems * n_runs, &d))) return rc;
             HIP_TRY(ctx, hipMemcpyAsync(d, st, elems * n_runs, hipMemcpyHostToDevice, ctx->stream));
@@ -326,6 +273,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     ctx->lut_nodes_err = -1.0f;
+    ctx->tune_lists_order = xcd_env("SLGC_LISTS_ORDER", 1);     // column-major: 217.6 -> 205.6 us at 4096x3000 (gpurun_out/r3g), neutral at the smaller sizes
     ctx->tune_stagger = xcd_env("SLGC_STAGGER", 0);
     ctx->tune_stagger_max = xcd_env("SLGC_STAGGER_MAX", 8192);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -383,6 +331,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "stagger")) ctx->tune_stagger = value < 0 ? 0 : value;
+    else if (!strcmp(name, "lists_order")) ctx->tune_lists_order = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "lds_pad")) ctx->tune_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(name, "stagger_max")) ctx->tune_stagger_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kScatterThreads, SRC == 1 ? 6 : 4)
 k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, int H, int proj_w, int proj_h, const uint8_t *__restrict__ white,
                  const unsigned *__restrict__ counts, const unsigned long long *__restrict__ colstart, float *__restrict__ cam,
                  float *__restrict__ proj, double *__restrict__ colors, const float *__restrict__ xyz, double *__restrict__ pts,
-                 const unsigned long long *__restrict__ total, int tiles_x, int abl, const TriScatter ts)
+                 const unsigned long long *__restrict__ total, int tiles_x, int abl, const TriScatter ts, int tiles_y, int order)
 {
     constexpr bool XYZ = SRC == 1, TRI = SRC == 2;
     static_assert(!TRI || TC == 64, "the in-kernel triangulation is written for 64-column tiles (16 four-pixel groups + 3 nodes per row)");
@@ -195,7 +195,15 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
     __shared__ float2 s_cam[TRI ? TR : 1][TRI ? TC + 1 : 1];      // the tile's camera rays -- or, with the node table, nodes 0..18 of each row in [row][0..18]
     __shared__ unsigned long long s_base[NSEG][TC];     // where each column segment's first record goes
     const int tid = threadIdx.x, lane = tid & 63;
-    const int x_tile = (int)(blockIdx.x % (unsigned)tiles_x) * TC, y_tile = (int)(blockIdx.x / (unsigned)tiles_x) * TR;
+    // Which tile this workgroup takes.  order 0: row-major.  The output is x-major -- a column's records are contiguous, so the run a tile
+    // writes for column x continues in the tile BELOW it, and the 128-byte lines at the seams are completed by that other workgroup.  order 2
+    // walks the tiles column-major inside each XCD (workgroup ids go round-robin over the 8 XCDs, each with its own L2): the two halves of a
+    // seam line are written by consecutive workgroups of one XCD and meet in its L2 instead of leaving it as two partial lines.  order 1:
+    // column-major without the XCD grouping (A/B).
+    uint32_t tile = blockIdx.x;
+    if (order == 2) tile = xcd_block(blockIdx.x, gridDim.x / 8u);
+    const int x_tile = (order ? (int)(tile / (unsigned)tiles_y) : (int)(tile % (unsigned)tiles_x)) * TC;
+    const int y_tile = (order ? (int)(tile % (unsigned)tiles_y) : (int)(tile / (unsigned)tiles_x)) * TR;
     const int cols = min(TC, W - x_tile);
     const size_t npix = (size_t)W * H;
     const bool white_dwords = colors && !LISTS_ABL(16) && (((uintptr_t)white | (unsigned)W) & 3u) == 0 && npix >= 2;   // row starts dword aligned
@@ -605,7 +613,7 @@ int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int
         const int tiles_x = (cam_w + TC - 1) / TC, tiles_y = (cam_h + TR - 1) / TR;
         hipLaunchKernelGGL((k_xmajor_scatter<MapT, SRC, TC>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w,
                            cam_h, proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_colors, d_xyz, d_pts,
-                           (const unsigned long long *)d_total, tiles_x, lists_abl(), ts);
+                           (const unsigned long long *)d_total, tiles_x, lists_abl(), ts, tiles_y, ctx->tune_lists_order);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;

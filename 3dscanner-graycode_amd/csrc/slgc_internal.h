@@ -58,6 +58,7 @@ struct slgc_ctx {
     int tune_fuse_xcd;      // the same map for the fused scan kernel
     int tune_stagger;       // fused scan kernel, launches of at most tune_stagger_max workgroups: start-up phase shift between workgroup groups (decode.hip)
     int tune_stagger_max;
+    int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
     int tune_lds_pad;       // fused scan kernel: extra dynamic LDS bytes per workgroup (an occupancy limiter for A/B: fewer resident workgroups, more rounds)
     unsigned launch_lds;    // dynamic LDS of the next SLGC_LAUNCH (0 except inside launch_scan_fused)
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)

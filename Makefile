@@ -3,8 +3,11 @@ all: build
 build:
 	$(MAKE) -C 3dscanner-graycode_amd -j8
 	$(MAKE) -C oracle
-test:            ## CPU suite (oracle vs goldens, host logic, ABI)
+test:            ## CPU suite (oracle vs goldens, host logic, ABI) incl. the sanitizer runs of the native CPU code
+	$(MAKE) -C oracle san
 	python -m pytest tests -x -q -m "not gpu"
+san:             ## ASan + UBSan + TSan on the CPU builds (host_util.cpp unit tests, C oracle through the golden vectors)
+	$(MAKE) -C oracle san-run
 test-gpu:        ## needs an MI355X
 	python -m pytest tests -x -q -m gpu
 bench:
@@ -14,4 +17,4 @@ golden:          ## regenerate tests/golden/*.npz by running the reference (buil
 clean:
 	$(MAKE) -C 3dscanner-graycode_amd clean
 	$(MAKE) -C oracle clean
-.PHONY: all build test test-gpu bench golden clean
+.PHONY: all build test san test-gpu bench golden clean

@@ -73,6 +73,10 @@ int slgc_synchronize(slgc_ctx *ctx);
  * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
  * to stay in the Infinity Cache between scans (> 64 MB; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
+ * "lists_order" = workgroup -> tile order of the x-major list build: 1 column-major (default: a column's run continues in the tile below, so
+ * the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000), 0 row-major, 2 column-major inside each XCD (no better).
+ * "stagger" / "stagger_max" / "lds_pad": start-up phase shifts and an occupancy limiter for launches of the fused kernel that fit one round of
+ * resident workgroups (1920x1080) -- measured, no gain, off.
  * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
  * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
  * scan its bands (0, the default: the band is the image).

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libslgc_oracle.so")
+_SO = os.environ.get("SLGC_ORACLE_SO") or os.path.join(_HERE, "libslgc_oracle.so")      # SLGC_ORACLE_SO: the sanitizer build (make -C oracle san)
 
 
 def build():
@@ -20,7 +20,7 @@ def build():
 
 
 def _load():
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "slgc_oracle.c")):
+    if "SLGC_ORACLE_SO" not in os.environ and (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "slgc_oracle.c"))):
         build()
     lib = C.CDLL(_SO)
     lib.orc_cam_proj_pts.restype = C.c_int64

@@ -37,7 +37,7 @@ name, vals = args.knobs.split("=")
 vals = [int(v) for v in vals.split(",")]
 
 
-route = 0
+route = int(os.environ.get("LISTS_ROUTE", "0"))
 
 
 def one():
