@@ -15,7 +15,7 @@ import numpy as np
 
 from .._native import default_context
 
-__all__ = ["read_images", "read_images_order", "remove_bad_images", "to_gray", "get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
+__all__ = ["read_images", "read_images_order", "remove_bad_images", "keep_from_counts", "to_gray", "get_direct_indirect", "get_is_lit", "get_codes", "gray_decode", "gray_to_decimal",
            "codes_to_pixels", "decode"]
 
 
@@ -52,15 +52,12 @@ def read_images(folder, dtype=np.float64):
     return images, np.array(names)
 
 
-def remove_bad_images(images, ctx=None):
-    """Indexes of the frames to keep (transition frames dropped), reference decode_codes.py:34-68.
-
-    The per-pair ``len(np.argwhere(cv2.absdiff(a, b) > 50))`` counts are one GPU reduction over all consecutive pairs
-    (csrc/ingest.hip); the keep/drop rule of :56-66 is expressed over that count array as a sliding three-count window.  ``images`` is the
-    reference's ``[n,H,W,3]`` (or ``[n,H,W]``) array, float64 or uint8."""
-    n = len(images)
-    # e[j] = number of elements that change by more than 50 between frames j and j+1 -- all pairs in ONE GPU reduction
-    e = [int(x) for x in (ctx or default_context()).frame_diff_counts(images, 50)]
+def keep_from_counts(counts):
+    """The keep / drop rule of decode_codes.py:52-66 over the change counts ``counts[j]`` = number of elements that differ by more than 50
+    between frames j and j + 1 (``len(np.argwhere(cv2.absdiff(a, b) > 50))``): indexes of the frames to keep.  Separate from the counting so
+    that a capture already in HBM (``Context.frame_diff_counts_dev``) goes through the same rule."""
+    e = [int(x) for x in counts]
+    n = len(e) + 1
     kept = []
 
     def far_from_last(*idx):            # the frame kept last is none of idx (or nothing is kept yet)
@@ -82,6 +79,15 @@ def remove_bad_images(images, ctx=None):
                 kept.append(i + 2)
                 e[i + 1] = e[i + 2] = -1
     return kept
+
+
+def remove_bad_images(images, ctx=None):
+    """Indexes of the frames to keep (transition frames dropped), reference decode_codes.py:34-68.
+
+    The per-pair ``len(np.argwhere(cv2.absdiff(a, b) > 50))`` counts are one GPU reduction over all consecutive pairs
+    (csrc/ingest.hip); the keep/drop rule of :56-66 is :func:`keep_from_counts`.  ``images`` is the reference's ``[n,H,W,3]`` (or
+    ``[n,H,W]``) array, float64 or uint8."""
+    return keep_from_counts((ctx or default_context()).frame_diff_counts(images, 50))
 
 
 def to_gray(images, ctx=None, coeff_bits=15):

@@ -68,7 +68,7 @@ def test_single_rank_rccl_full_size_self_verifies(extra):
     r, j = run_bench("--force-sharded", "--steps", "12", "--warmup", "2", "--no-extras", "--workload", "c3_4096x3000x44", *extra)
     assert r.returncode == 0 and j is not None, r.stderr[-2000:]
     v = j["verify"]
-    assert v["ok"] and v["maps_equal_single_gpu_scan"] and v["xyz_sample_equal_single_gpu_scan"] and v["valid_pixels"] > 9_000_000, v
+    assert v["ok"] and v["maps_equal_single_gpu_scan"] and v["xyz_sample_equal_single_gpu_scan"] and v["valid_pixels"] > 1_000_000, v
     assert "configs[3]" in j["config"]["workload"] and j["sharded"]["rccl_nranks"] == 1
 
 
