@@ -80,21 +80,33 @@ __device__ __forceinline__ int byte_of(const Words<PX> &r, int j)
     return (int)((r.w[j >> 2] >> (8 * (j & 3))) & 0xffu);
 }
 
-// Per-pixel thresholds from black/white and the 12 L_max/L_min frames.
+// Per-pixel thresholds from black/white and the 12 L_max/L_min frames: the reference's float64 sequence (decode_codes.py:113-120) with every
+// rounding kept and everything around the roundings done more cheaply -- float64 issues at half rate on gfx950 and this block was a fifth of
+// the decode kernel's vector-ALU time (round 3; exhaustively equal to the literal predicates over the whole uint8 domain: slgc_selftest_thresholds):
+//  * b_inv = white / (white + black): the operands are integers 0 .. 510, so the quotient needs none of the scaling / fix-up steps of the
+//    general IEEE division (v_div_scale x2, v_div_fmas, v_div_fixup): reciprocal seed, two Newton steps, quotient, one correction = the same
+//    correctly rounded result (0 / 0: -0 * inf = NaN propagates, as the reference's NaN does);
+//  * white + black is added as integers (one conversion instead of two and an add);
+//  * L_g + eps = fl(fl(2 a) * b_inv) + eps with a = L_max - L_d: doubling is exact, so fl(2 a * b_inv) = 2 fl(a * b_inv) and the sum is ONE
+//    fma(a * b_inv, 2, eps) -- the same single rounding of the same real number;
+//  * the clamps run on integers after the conversion: L_g + eps >= 0 (a >= 0 because L_d <= L_max - L_min <= L_max), so truncation is floor,
+//    and NaN (white = black = 0, the only way to get one) is an integer test on white + black instead of float64 compares / min / max.
 __device__ __forceinline__ void pixel_thresholds(int black, int white, int lmax, int lmin, int e, int &tt, int &cA)
 {
-    const double w = (double)white, b = (double)black;
-    const double b_inv = w / (w + b);                        // decode_codes.py:113 (0/0 -> NaN)
-    const double ld = (double)(lmax - lmin) * b_inv;         // :119  (L_max - L_min is exact)
-    const double t2 = 2.0 * ((double)lmax - ld);             // :120  2.0*(L_max - L_d) ...
-    const double lg = t2 * b_inv;                            //       ... * b_inv
-    const double ge = lg + (double)e;                        // L_g + eps (:172-182)
-    const bool direct = ld > ge;
-    // straight-line (no divergent branches): clamp in fp64, convert, fix the NaN case with a select
-    int tg = (int)fmin(fmax(floor(ge), -1.0), 255.0) + 1;     // floor(ge)+1 in [0, 256]
-    tg = (ge != ge) ? 256 : tg;                               // NaN: no x satisfies x > NaN
-    int tnd = (int)fmin(fmax(ceil(ld), 0.0), 1024.0) - e;     // NaN -> fmax(NaN, 0) = 0: no x satisfies x + e < NaN
-    tnd = min(max(tnd, 0), 256);
+    const int si = white + black;
+    const double w = (double)white, s = (double)si;
+    double y = __builtin_amdgcn_rcp(s);
+    y = __builtin_fma(__builtin_fma(-s, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-s, y, 1.0), y, y);
+    const double q0 = w * y;
+    const double b_inv = __builtin_fma(__builtin_fma(-s, q0, w), y, q0);      // decode_codes.py:113 (0/0 -> NaN)
+    const double ld = (double)(lmax - lmin) * b_inv;                         // :119  (L_max - L_min is exact)
+    const double a = (double)lmax - ld;                                       // :120  2.0*(L_max - L_d) ...
+    const double ge = __builtin_fma(a * b_inv, 2.0, (double)e);               //       ... * b_inv, + eps (:172-182)
+    const bool direct = ld > ge;                                              // false for NaN
+    const bool nan = si == 0;
+    const int tg = nan ? 256 : min((int)ge, 255) + 1;                         // floor(ge) + 1 in [1, 256]; NaN: no x satisfies x > NaN
+    const int tnd = nan ? 0 : max((int)__builtin_ceil(ld) - e, 0);            // ceil(ld) - e in [0, 255]; NaN: no x satisfies x + e < NaN
     tt = tnd | (tg << 16);
     cA = direct ? (e + 1) : kUnreachable;
 }
