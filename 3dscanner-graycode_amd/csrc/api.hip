@@ -191,13 +191,27 @@ int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs
     const size_t elems = (size_t)N * npix;
     ctx->last_input_path = *dtype == SLGC_U8 ? 0 : 2;
     static const int pack = xcd_env("SLGC_F64_PACK", 1);          // 0: always ship float64 (A/B of the narrowing)
-    if (*dtype == SLGC_F64 && pack && elems) {
+    bool plausible = *dtype == SLGC_F64 && pack && elems;
+    if (plausible) {              // a look at the head of every run before any page is pinned: a stack of fractions (a normalised capture) fails here
+        uint8_t probe[4096];
+        const size_t n = elems < sizeof probe ? elems : sizeof probe;
+        for (int r = 0; r < n_runs && plausible; ++r) {
+            const void *one = stacks[r];
+            plausible = slgc_host::narrow_f64_to_u8(&one, 1, n, probe, 1) == 1;
+        }
+    }
+    if (plausible) {
         void *st;
         int rc = host_staging(ctx, elems * n_runs, &st);
         if (rc) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the staging buffer may still feed the previous call's copy
         const int narrowed = slgc_host::narrow_f64_to_u8(stacks, n_runs, elems, (uint8_t *)st);
         if (narrowed < 0) return slgc_fail(ctx, SLGC_ENOMEM, "host threads for the float64 -> uint8 narrowing");
+        if (!narrowed) {          // a late sample is not a grey level: this caller's stacks take the float64 kernel -- do not sit on the pinned pages
+            (void)hipHostFree(ctx->stage);
+            ctx->stage = nullptr;
+            ctx->stage_bytes = 0;
+        }
         if (narrowed) {
             void *d;
             if ((rc = slgc_ws(ctx, 0, elems * n_runs, &d))) return rc;

@@ -149,7 +149,9 @@ class _ResultPool:
     them out again: a result array is an ordinary writable NumPy array over such a buffer, and when the array and every view of it are
     gone the buffer returns to the pool instead of to the operating system.  A script that handles one scan sees exactly np.empty's cost;
     a loop gets its results at the rate of the link from its second or third pass on, with nothing page-locked and no warm-up to pay.
-    Buffers are cached up to SLGC_RESULT_POOL_MB (default 4096); SLGC_RESULT_POOL=0 returns plain np.empty arrays."""
+    Buffers are cached up to SLGC_RESULT_POOL_MB (default 1024: two 4096x3000 scans' worth of int64 maps); ``result_pool_clear()`` returns
+    everything cached to the operating system; SLGC_RESULT_POOL=0 returns plain np.empty arrays.  A pooled array does not own its memory
+    (``arr.flags.owndata`` is False, ``ndarray.resize`` refuses): copy it if you need an owning array."""
 
     MIN_BYTES = 8 << 20
     GRANULE = 2 << 20
@@ -159,7 +161,7 @@ class _ResultPool:
         self.cached = 0
         self.lock = threading.Lock()
         self.enabled = os.environ.get("SLGC_RESULT_POOL", "1") != "0"
-        self.limit = int(os.environ.get("SLGC_RESULT_POOL_MB", "4096")) << 20
+        self.limit = int(os.environ.get("SLGC_RESULT_POOL_MB", "1024")) << 20
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -185,7 +187,22 @@ class _ResultPool:
                 self.cached += size
 
 
+    def clear(self):
+        with self.lock:
+            self.free.clear()
+            self.cached = 0
+
+
 _pool = _ResultPool()
+
+
+def result_pool_clear():
+    """Give the cached result buffers back to the operating system (they are re-created on demand)."""
+    _pool.clear()
+
+
+def result_pool_bytes() -> int:
+    return _pool.cached
 
 
 def _out(shape, dtype=np.float64):

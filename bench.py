@@ -592,7 +592,7 @@ def run_rank(args, rank, local_rank, world):
                 return f"k_decode_pk<4,128,nt> {spec}"
             return f"k_decode_pk<4,128,nt,FUSE=2> {spec} + triangulation tail (camera rays: {'node table' if ex['node_table'] else 'per-pixel table'})"
 
-        def kernel_roofline(pipeline, kms, kn, samples, ex=None):
+        def kernel_roofline(pipeline, kms, kn, samples, ex=None, scene=None):
             """SURVEY.md 8(d) byte definitions: decode kernel N + 4 B/pixel (N uint8 reads, 2 int16 writes); fused decode -> XYZ
             N + 12 B/pixel.  The fused kernel also writes the 4 B/pixel maps (a product): frac_incl_maps counts them too."""
             per_px = (N + 4) if pipeline == "split" else (N + 12)
@@ -607,8 +607,11 @@ def run_rank(args, rank, local_rank, world):
                 r["frac_incl_maps_note"] = "N + 16 B/pixel: the 4 B/pixel int16 maps the fused kernel also writes counted as algorithmic"
             t = traffic_db.get(f"{args.workload}/g{G}/{pipeline}")
             if t and t.get("csrc_fingerprint") == fp:
-                r["traffic"] = t["hbm_bytes_per_launch"]
+                # the counters were collected per scene for the fused kernel (tools/pmc.sh): fewer lit pixels = fewer projector-table lines gathered
+                sc = scene or args.scene
+                r["traffic"] = t.get("s_scene_hbm_bytes_per_launch") if (sc == "s-scene" and pipeline != "split" and "s_scene_hbm_bytes_per_launch" in t) else t["hbm_bytes_per_launch"]
                 r["traffic_source"] = t.get("source")
+                r["traffic_scene"] = "s-scene" if (pipeline == "split" or sc == "s-scene") else "physical"
             elif t:
                 r["traffic_note"] = ("profiles/traffic.json was measured on other kernel sources (fingerprint mismatch): stale, not reported; "
                                      "re-run tools/pmc.sh")
@@ -670,7 +673,7 @@ def run_rank(args, rank, local_rank, world):
             o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc = other_scene
             out["other_scene"] = {"scene": o_name, "value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
                                   "ms_per_step": round(o_el / args.steps * 1e3, 4), "executed": o_exec,
-                                  "roofline": kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec),
+                                  "roofline": kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec, scene=o_name),
                                   "valid_pixels_per_scan": o_valid, "guard_flagged_pixels": o_flag,
                                   "note": "the headline step on the other synthetic capture, same run (bench.py --scene picks which one is the headline)"}
             if acc is not None:

@@ -1034,6 +1034,22 @@ def test_results_live_in_recycled_buffers(ctx):
     h3, v3 = ctx.decode(st)
     assert {h3.ctypes.data, v3.ctypes.data} <= (first | second)           # recycled buffers
     assert np.array_equal(h3, ref_h) and np.array_equal(v3, ref_v)
+    # the pool can be emptied, and a float64 stack that does not hold grey levels leaves no pinned staging behind
+    from scanner import _native
+    del h3, v3
+    gc.collect()
+    assert _native.result_pool_bytes() > 0
+    _native.result_pool_clear()
+    assert _native.result_pool_bytes() == 0
+    for bad_at in (0, st.size - 1):                                        # caught by the look at the head / only by the full pass
+        f = st.astype(np.float64)
+        f.reshape(-1)[bad_at] += 0.5
+        hf, vf = ctx.decode(f)
+        assert ctx.last_input_path() == 2
+        rh, rv = oc.decode(f)
+        assert np.array_equal(hf, rh) and np.array_equal(vf, rv)
+    hn, vn = ctx.decode(st.astype(np.float64))
+    assert ctx.last_input_path() == 1 and np.array_equal(hn, ref_h) and np.array_equal(vn, ref_v)
 
 
 # ----------------------------------------------------------------------------------------- ingest ("next" rows)

@@ -25,6 +25,7 @@ ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--pipeline", default="fused", choices=["fused", "split", "decode"])
 ap.add_argument("--workload", default="c3_4096x3000x44")
+ap.add_argument("--scene", default="physical", choices=["physical", "s-scene"], help="synthetic capture (bench.py --scene)")
 ap.add_argument("--preheat", type=float, default=0.2, help="seconds of untimed launches first (0 under a counter profiler)")
 args = ap.parse_args()
 
@@ -35,7 +36,10 @@ ctx.set_calibration(*bench.calibration(W, H, pw, ph))
 stacks = []
 for b in range(max(2, -(-300_000_000 // (N * px)))):
     s = ctx.alloc(N * px)
-    ctx.synth_scene_dev(s.ptr, px, N, H, W, seed=1 + b, noise=3, shadow=True)
+    if args.scene == "physical":
+        ctx.synth_physical_dev(s.ptr, px, N, H, W, (pw, ph), seed=1 + b, noise=3)
+    else:
+        ctx.synth_scene_dev(s.ptr, px, N, H, W, seed=1 + b, noise=3, shadow=True)
     stacks.append(s)
 maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
 names, values = [], []

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/final/{kt,pmc,bench_*.json} -> profiles/<tag>_* (kernel stats, per-grid stats, PMC summary + the raw counter rows of the
-bench kernels, traffic.json stamped with the fingerprint of the kernel sources it was measured on).  usage: collect_profiles.py r02"""
+bench kernels, traffic.json stamped with the fingerprint of the kernel sources it was measured on).  usage: collect_profiles.py r03"""
 import csv
 import glob
 import json
@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 C3_GRID = 4096 * 3000 // 4          # threads of a 4-pixels-per-lane kernel over 4096x3000
 
 
@@ -45,7 +45,7 @@ d = json.load(open(os.path.join(dst, f"{tag}_pmc_summary_c3.json")))
 def kernel_key(fused):
     """k_decode_pk<PX, BLOCK, NT, MULTI, ABL, FUSE, NS> @grid: FUSE = 0 is the decode kernel, 1 / 2 the fused scan kernel."""
     for k in d:
-        m = re.match(r"k_decode_pk<([^>]*)> @grid=(\d+)", k)
+        m = re.match(r"k_decode_pk<([^>]*)> @grid=(\d+)$", k)                 # (keys ending in " [s-scene]" are the other capture: reported beside it)
         if m and int(m.group(2)) == C3_GRID and "FETCH_SIZE" in d[k]:
             args = [a.strip() for a in m.group(1).split(",")]
             if (int(args[5]) != 0) == fused:
@@ -63,6 +63,9 @@ t = {"c3_4096x3000x44/g1/split": {"kernel": dec, "hbm_bytes_per_launch": traffic
      "c3_4096x3000x44/g1/fused": {"kernel": fus, "hbm_bytes_per_launch": traffic(fus), "fetch_size_kb": d[fus]["FETCH_SIZE"]["mean"],
                                   "write_size_kb": d[fus]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
                                   "source": note + "; includes the projector-ray gathers and the 4 B/pixel maps, which SURVEY 8(d)'s N + 12 does not count"}}
+ss = fus + " [s-scene]"
+if ss in d and "FETCH_SIZE" in d[ss]:
+    t["c3_4096x3000x44/g1/fused"]["s_scene_hbm_bytes_per_launch"] = traffic(ss)
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
 line = [ln for ln in open(os.path.join(src, "bench_under_rocprof.log")) if ln.startswith("{")][0]
@@ -79,12 +82,20 @@ alg = {"split": 48 * 4096 * 3000, "fused": 56 * 4096 * 3000}
 print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / alg[k.rsplit("/", 1)[1]], 3)) for k, v in t.items()}, "fingerprint", fp)
 
 # the "next" rows, the list stage, the host API and the store-pattern microbenchmark of the same box
+try:
+    print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), newest("kt_c2/**/*kernel_trace.csv"),
+                          os.path.join(dst, f"{tag}_kernel_stats_by_grid_c2_1920x1080x44.csv")], capture_output=True, text=True).stdout.split("k_synth")[0])
+    line2 = [ln for ln in open(os.path.join(src, "bench_c2_under_rocprof.log")) if ln.startswith("{")][0]
+    open(os.path.join(dst, f"{tag}_bench_c2_1920x1080x44_under_rocprof.json"), "w").write(line2)
+except (ValueError, IndexError) as e_:
+    print("no 1920x1080 kernel trace", e_)
 for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_stats_list_stage")):
     try:
         shutil.copy(newest(sub + "/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{name}.csv"))
     except ValueError:
         print("no", sub)
-for f, name in (("next_rows.log", "next_rows.txt"), ("lists_plain.log", "list_stage.txt"), ("host_api.log", "host_api.txt"), ("dropin.log", "dropin.txt"), ("write_patterns.txt", "write_patterns.txt")):
+for f, name in (("next_rows.log", "next_rows.txt"), ("lists_plain.log", "list_stage.txt"), ("host_api.log", "host_api.txt"), ("dropin.log", "dropin.txt"), ("write_patterns.txt", "write_patterns.txt"),
+                ("cloud.log", "reference_product.txt")):
     if os.path.exists(os.path.join(src, f)):
         keep = [ln for ln in open(os.path.join(src, f), errors="replace") if not re.match(r"^(RCCL|HIP|ROCm|Hostname|Librccl|[WEI]\d{8}) ", ln)]
         open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)

@@ -12,18 +12,21 @@ grep '^{' "$out/bench_default.log" | tail -1 > "$out/bench_default.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py > "$out/bench_under_rocprof.log" 2>&1
 bash tools/pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 tail -3 "$out/pmc.log"
-# other configurations and the sharded path at nranks = 1
+# the other BASELINE configurations (physical scene = the default; the S-scene rides along as other_scene), 1920x1080 also under the kernel trace
 for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
   python3 bench.py --workload $w --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > "$out/bench_$w.json"
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --no-cpu-baseline --no-throughput-mode > "$out/bench_c2_under_rocprof.log" 2>&1
+python3 bench.py --scene s-scene --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sscene_headline.json"
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$out/bench_steps20.json"      # what the driver runs
 python3 bench.py --force-sharded --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
 python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_xyz.json"
 python3 bench.py --force-sharded --exchange records --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
-# the "next" rows and the list stage under the kernel trace, the store-pattern microbenchmark
+# the "next" rows, the list stage and the whole reference-shaped product under the kernel trace, the store-pattern microbenchmark
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_next" -- python3 tools/time_next_rows.py > "$out/next_rows.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs xcd=1 > "$out/lists.log" 2>&1
-python3 tools/time_lists.py --knobs xcd=1 2>/dev/null | grep "list stage" > "$out/lists_plain.log"
+LISTS_ROUTE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs lists_order=1 > "$out/lists.log" 2>&1
+python3 tools/time_lists.py --knobs route=0,1 2>/dev/null | grep "list stage" > "$out/lists_plain.log"
+for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_cloud.py --workload $w 2>/dev/null | grep "per scan"; done > "$out/cloud.log"
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
 python3 tools/time_dropin.py 2>/dev/null | grep -E "^pass|^c3|^  " > "$out/dropin.log"
 [ -x tools/ubench/write_patterns ] && tools/ubench/write_patterns > "$out/write_patterns.txt" 2>&1
@@ -34,8 +37,8 @@ for f in sorted(glob.glob("$out/bench_*.json")):
         j = json.load(open(f))
     except Exception as e:
         print(os.path.basename(f), "unreadable", e); continue
-    sp = j.get("split_pipeline", {})
-    print(os.path.basename(f), "value", j["value"], "ms/step", j["ms_per_step"], "frac", j["roofline"]["frac"], "| split", sp.get("value"), sp.get("roofline", {}).get("frac"),
-          "| alone", j.get("decode_kernel_alone", {}).get("roofline", {}).get("frac"), "| thr", j.get("throughput_mode", {}).get("value"))
+    sp, o = j.get("split_pipeline", {}), j.get("other_scene", {})
+    print(os.path.basename(f), "value", j["value"], "ms/step", j["ms_per_step"], "frac", j["roofline"]["frac"], "| other scene", o.get("value"), o.get("roofline", {}).get("frac"),
+          "| split", sp.get("value"), sp.get("roofline", {}).get("frac"), "| alone", j.get("decode_kernel_alone", {}).get("roofline", {}).get("frac"),
+          "| product", j.get("reference_product", {}).get("value"), "| thr", j.get("throughput_mode", {}).get("value"))
 PY
-ls "$out" "$out/kt"/* | head -20

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for the bench kernels (separate passes; never combined with tracing).
 # usage: tools/pmc.sh <outdir> [bench args...]
+# Per counter group three short bench runs, each launching ONE kind of scan kernel on ONE scene (the summary is keyed by kernel @ grid):
+#   passN         fused kernel on the headline (physical) scene        passN_split   decode kernel + dense triangulation kernel (S-scene stacks)
+#   passN_sscene  fused kernel on the S-scene
 set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -8,7 +11,12 @@ mkdir -p "$out"
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 10 --warmup 2 --preheat 0 --no-cpu-baseline --no-throughput-mode "$@" > "$out/pass$i.log" 2>&1
-  echo "pass $i ($ctrs): rc=$?"
+  common="--steps 10 --warmup 2 --preheat 0 --no-extras"
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py $common "$@" > "$out/pass$i.log" 2>&1
+  rc1=$?
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass${i}_split" -- python3 bench.py $common --pipeline split --scene s-scene "$@" > "$out/pass${i}_split.log" 2>&1
+  rc2=$?
+  timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass${i}_sscene" -- python3 bench.py $common --scene s-scene "$@" > "$out/pass${i}_sscene.log" 2>&1
+  echo "pass $i ($ctrs): rc=$rc1 $rc2 $?"
 done
 python3 tools/pmc_summary.py "$out"

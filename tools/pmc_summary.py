@@ -15,7 +15,9 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         name = row["Kernel_Name"]
         m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
         short = m.group(1) if m else name.split("(")[0].strip()
-        acc[f"{short} @grid={row['Grid_Size']}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        rel = os.path.relpath(f, out).split(os.sep)[0]
+        variant = " [s-scene]" if rel.endswith("_sscene") else ""              # tools/pmc.sh: the fused kernel on the other synthetic capture
+        acc[f"{short} @grid={row['Grid_Size']}{variant}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 for k, ctrs in sorted(acc.items()):
     summary[k] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in sorted(ctrs.items())}

@@ -69,8 +69,11 @@ for r in range(args.rounds):
                 hsh.update(np.ascontiguousarray(a).view(np.uint8).data)
             dig[v] = (M, hsh.hexdigest())
 M = dig[vals[0]][0]
-nbytes = px * (8 + 12 + 3) + M * 64
+nodes = ctx.ray_table_info()[0]
 for v in vals:
+    tri = (v if name == "route" else route) == 1
+    # maps twice (count + scatter) 8, white 3, and the dense XYZ 12 -- or, triangulating in-kernel, the camera rays 2 (nodes) / 8 per pixel in; 64 per point out
+    nbytes = px * (8 + 3 + ((2 if nodes else 8) if tri else 12)) + M * 64
     t = np.array(res[v])
     print(f"{args.workload} {name}={v}: list stage median {np.median(t):7.1f} us  min {t.min():7.1f}  | {nbytes / np.median(t) / 1e6:6.2f} TB/s "
           f"= {nbytes / np.median(t) / 1e6 / 8:.3f} of 8 TB/s | points {dig[v][0]} digest {dig[v][1]}")
