@@ -166,7 +166,15 @@ def cpu_baseline():
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]
-def throughput_lanes(_native, device, per_rank, n_streams=2):
+def synth_into(c, scene, d_ptr, plane, n, H, W, proj_size, seed, row0=0, rows=None):
+    """One synthetic capture into HBM: the physically consistent scene (needs the context's calibration) or SURVEY 8(d)'s S-scene."""
+    if scene == "physical":
+        c.synth_physical_dev(d_ptr, plane, n, H, W, proj_size, row0=row0, rows=rows, seed=seed, noise=3)
+    else:
+        c.synth_scene_dev(d_ptr, plane, n, H, W, row0=row0, rows=rows, seed=seed, noise=3, shadow=True)
+
+
+def throughput_lanes(_native, device, per_rank, n_streams=2, scene="s-scene"):
     """BASELINE.json configs[4] on one GPU: `n_streams` contexts (HIP streams), each with its own rotated 1920x1080x44 stacks
     (>= 4 distinct stacks in total: 364 MB > Infinity Cache) and one set of output buffers.  -> [(ctx, stacks, maps, xyz)]"""
     cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
@@ -178,7 +186,7 @@ def throughput_lanes(_native, device, per_rank, n_streams=2):
         stacks = []
         for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):
             st = c.alloc(n * px)
-            c.synth_scene_dev(st.ptr, px, n, ch, cw, seed=11 + 7 * sidx + b)
+            synth_into(c, scene, st.ptr, px, n, ch, cw, (pw, ph), 11 + 7 * sidx + b)
             stacks.append(st)
         lanes.append((c, stacks, c.alloc(px * 4), c.alloc(px * 12)))
     return lanes
@@ -198,7 +206,7 @@ def throughput_step(lanes, per_rank, i, mode):
     return plan
 
 
-def throughput_batched(ctx, _native, G, steps, mode, device, collective=False):
+def throughput_batched(ctx, _native, G, steps, mode, device, collective=False, scene="s-scene"):
     """configs[4] through slgc_scan_batch_dev: the GPU's share of the 16 scans in ONE launch per step (3 rotated sets of stacks: > Infinity
     Cache), no collective.  Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
     cw, ch, pw, ph, n = WORKLOADS["c2_1920x1080x44"]
@@ -210,7 +218,7 @@ def throughput_batched(ctx, _native, G, steps, mode, device, collective=False):
     for b in range(3):
         st = c.alloc(per_rank * n * px)
         for s in range(per_rank):
-            c.synth_scene_dev(st.at(s * n * px), px, n, ch, cw, seed=11 + 16 * b + s)
+            synth_into(c, scene, st.at(s * n * px), px, n, ch, cw, (pw, ph), 11 + 16 * b + s)
         sets.append(st)
     maps_h, maps_v, xyz = c.alloc(per_rank * px * 2), c.alloc(per_rank * px * 2), c.alloc(per_rank * px * 12)
 
@@ -235,13 +243,13 @@ def throughput_batched(ctx, _native, G, steps, mode, device, collective=False):
     return el, per_rank * G, cw * ch / 1e6
 
 
-def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2, collective=False):
+def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2, collective=False, scene="s-scene"):
     """16 independent 1920x1080x44 scans per step spread over the G GPUs, no collective (replicas only -- SURVEY.md 8(e)).  Each GPU
     streams its scans back to back over `n_streams` HIP streams so the tail of one scan's kernel overlaps the head of the next.
     Returns (seconds, scans per step over all ranks, Mpixels per scan)."""
     cw, ch = WORKLOADS["c2_1920x1080x44"][:2]
     per_rank = max(1, 16 // G)
-    lanes = throughput_lanes(_native, device, per_rank, n_streams)
+    lanes = throughput_lanes(_native, device, per_rank, n_streams, scene)
 
     def sync_all():
         for c, _, _, _ in lanes:
@@ -550,8 +558,8 @@ def run_rank(args, rank, local_rank, world):
 
     thr = thr_batched = None
     if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
-        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm)
-        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm)
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
+        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
 
     # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
     count.zero()
@@ -685,7 +693,7 @@ def run_rank(args, rank, local_rank, world):
                                       "config": f"{t_scans} independent 1920x1080x44 scans per step ({t_scans // G} per GPU), no collective "
                                                 "(BASELINE.json configs[4], replicas only)",
                                       "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "streams_per_gpu": args.streams,
-                                      "scaling": "weak"}
+                                      "scene": args.scene, "scaling": "weak"}
             if thr_batched is not None:
                 b_el, b_scans, b_mpix = thr_batched
                 out["throughput_mode"]["batched"] = {"value": round(b_scans * b_mpix * t_steps / b_el, 1), "unit": "Mpixels/s",

@@ -191,14 +191,15 @@ def test_bench_configuration_two_runs_every_pixel(ctx):
         b.free()
 
 
-def test_throughput_mode_scans_match_oracle(ctx):
+@pytest.mark.parametrize("scene", ["physical", "s-scene"])
+def test_throughput_mode_scans_match_oracle(ctx, scene):
     """BASELINE.json configs[4]: bench.py's own lanes (contexts / streams / rotated stacks), one step of 16 scans; the results of two
     of the scans (one per lane) are compared with the oracle, every pixel."""
     from scanner import _native
     W, H, pw, ph, N = bench.WORKLOADS["c2_1920x1080x44"]
     calib = bench.calibration(W, H, pw, ph)
     px = W * H
-    lanes = bench.throughput_lanes(_native, 0, 16, 2)
+    lanes = bench.throughput_lanes(_native, 0, 16, 2, scene)
     try:
         plan = bench.throughput_step(lanes, 16, 0, _native.TRI_ALGEBRAIC)                 # [(lane index, stack index)] in issue order
         for c, _, _, _ in lanes:

@@ -351,6 +351,24 @@ def _worker_full(rank, world, handle, mode, ref_dir, q):
             for j, got in enumerate(_pipelined(sc, [bufs[i] for i in order], plane)):
                 _check_dense(got, refs[order[j]], f"{kind}/{wire} world {world} pipelined scan {j}")
             report[f"{kind}/{wire}"] = ctx.last_scan_path()
+            if rank == world - 1:
+                # ... and bit for bit what ONE GPU computes for the whole image (the ray-table choice is the whole image's for every band:
+                # slgc_tune "image_rows"): the last rank scans the full stack alone with the fused kernel
+                sc.scan(bufs[0].ptr, plane)
+                gh, gv, gx = sc.fetch_dense()
+                px = W * H
+                full, m1, x1 = ctx.alloc(N * px), ctx.alloc(px * 4), ctx.alloc(px * 12)
+                ctx.synth_scene_dev(full.ptr, px, N, H, W, row0=0, rows=H, seed=SEEDS[0], noise=3, shadow=True)
+                ctx.scan_dev(full.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), x1.ptr, None, m1.at(0), m1.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+                ctx.synchronize()
+                assert ctx.last_scan_path()["path"] == "fused"
+                assert np.array_equal(gh, m1.download((H, W), np.int16)) and np.array_equal(gv, m1.download((H, W), np.int16, px * 2))
+                one = x1.download((H, W, 3), np.float32)
+                assert np.array_equal(gx.view(np.uint32), one.view(np.uint32)), f"{kind}/{wire}: XYZ of {world} ranks differs from the single-GPU scan"
+                for b in (full, m1, x1):
+                    b.free()
+            else:
+                sc.scan(bufs[0].ptr, plane)                                           # (every rank takes part in the exchange of that extra scan)
             del sc
         sc = sharded.ShardedScanner(ctx, ex, plan, (pw, ph), N, mode=_native.TRI_ALGEBRAIC, exchange_kind="records")
         total = sc.scan(bufs[0].ptr, plane)
