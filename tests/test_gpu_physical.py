@@ -132,3 +132,47 @@ def test_recovered_surface_within_code_quantisation_of_the_truth(ctx, workload):
     assert np.median(err) < 0.4e-3 and n_flat <= 0.001 * n_ok
     for b in (stack, hv, truth, maps, xyz, cnt):
         b.free()
+
+
+def test_random_rigs_recover_the_true_surface(ctx):
+    """Property over 12 random stereo rigs (focal lengths, principal points, lens coefficients, toe-in, baseline, image and projector sizes,
+    frame counts, ragged shapes included): whatever path slgc_scan_dev takes, the maps are the projected codes and the surface lies within the
+    quantisation bound of the truth."""
+    from scanner import _native
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for trial in range(12):
+        W, H = int(rng.integers(60, 180)) * 4 + (0 if trial % 3 else int(rng.integers(0, 4))), int(rng.integers(90, 400))
+        pw, ph = int(rng.integers(200, 600)), int(rng.integers(150, 450))
+        L = int(np.ceil(np.log2(max(pw, ph))))
+        N = 4 * L + 2 + 2 * int(rng.integers(0, 2))                                   # enough bits for the whole raster, sometimes two spare frames
+        K = np.array([[rng.uniform(1.9, 2.6) * W, 0, W / 2 + rng.uniform(-6, 6)], [0, rng.uniform(1.9, 2.6) * W, H / 2 + rng.uniform(-6, 6)], [0, 0, 1]])
+        pk = np.array([[rng.uniform(1.6, 2.2) * pw, 0, pw / 2 + rng.uniform(-8, 8)], [0, rng.uniform(1.6, 2.2) * pw, ph / 2 + rng.uniform(-8, 8)], [0, 0, 1]])
+        sc = rng.uniform(0, 1.5)
+        cd = sc * np.array([-0.08, 0.05, 0.0007, -0.0004, 0.01])
+        pd = rng.uniform(0, 1.5) * np.array([0.04, -0.06, -0.0005, 0.0008, 0.02])
+        th = np.deg2rad(rng.uniform(-28, -18))
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        T = np.array([[rng.uniform(0.16, 0.24)], [rng.uniform(-0.01, 0.01)], [rng.uniform(0.02, 0.06)]])
+        calib = (K, cd, pk, pd, R, T)
+        ctx.set_calibration(*calib)
+        px = W * H
+        stack, hv, truth = generate(ctx, N, H, W, (pw, ph), seed=100 + trial, noise=int(rng.integers(0, 5)))
+        maps, xyz = ctx.alloc(px * 4 + 64), ctx.alloc(px * 12)
+        voff = (px * 2 + 31) // 32 * 32
+        ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(voff), mode=_native.TRI_ALGEBRAIC)
+        ctx.synchronize()
+        h_true, v_true = hv.download((H, W), np.int16), hv.download((H, W), np.int16, px * 2)
+        h, v = maps.download((H, W), np.int16), maps.download((H, W), np.int16, voff)
+        got, tru = xyz.download((H, W, 3), np.float32), truth.download((H, W, 3), np.float32)
+        lit, ok = h_true != -1, (h != -1) & (v != -1)
+        assert lit.mean() > 0.1, (trial, lit.mean())
+        assert not (ok & ~lit).any() and ok.sum() >= 0.85 * lit.sum(), (trial, ok.sum(), lit.sum())       # (N = 4 L + 4: the reference's fractional pattern_len drops some lit pixels)
+        assert np.array_equal(h[ok], h_true[ok]) and np.array_equal(v[ok], v_true[ok]), trial
+        err = np.linalg.norm(got[ok].astype(np.float64) - tru[ok], axis=1)
+        ratio = float((err / quantisation_bound(tru[ok], T, pk)).max())
+        assert ratio <= 1.0, (trial, ratio, ctx.last_scan_path())
+        worst = max(worst, ratio)
+        for b in (stack, hv, truth, maps, xyz):
+            b.free()
+    print(f"\n12 random rigs: worst error / quantisation bound {worst:.3f}")
