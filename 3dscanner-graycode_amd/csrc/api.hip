@@ -288,8 +288,6 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     ctx->lut_nodes_err = -1.0f;
     ctx->tune_lists_order = xcd_env("SLGC_LISTS_ORDER", 1);     // column-major: 217.6 -> 205.6 us at 4096x3000 (gpurun_out/r3g), neutral at the smaller sizes
-    ctx->tune_stagger = xcd_env("SLGC_STAGGER", 0);
-    ctx->tune_stagger_max = xcd_env("SLGC_STAGGER_MAX", 8192);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return SLGC_EHIP;
@@ -344,10 +342,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (!strcmp(name, "stagger")) ctx->tune_stagger = value < 0 ? 0 : value;
     else if (!strcmp(name, "lists_order")) ctx->tune_lists_order = value < 0 ? 0 : (value > 2 ? 2 : value);
-    else if (!strcmp(name, "lds_pad")) ctx->tune_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
-    else if (!strcmp(name, "stagger_max")) ctx->tune_stagger_max = value < 0 ? 0 : value;
     else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG
@@ -1046,6 +1041,8 @@ extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs
     RunPtrs runs{};
     int e;
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
+    ctx->last_scan_path = SLGC_PATH_NONE;          // a decode alone is not a scan; slgc_triangulate_maps_dev after it completes the two-kernel path
+    ctx->last_ragged = 0;
     return decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant);
 }
 
@@ -1088,7 +1085,9 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
-    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
+    if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
+    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    return SLGC_OK;
 }
 
 extern "C" int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h)
@@ -1131,7 +1130,9 @@ extern "C" int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, i
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_wire || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 1) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
-    return launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count, d_wire);
+    if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count, d_wire))) return rc;
+    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    return SLGC_OK;
 }
 
 extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,

@@ -257,7 +257,6 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
     uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
-    uint32_t stagger;         // small launches (one residency round): start-up phase shift between groups of workgroups, see k_decode_pk (0 = off)
     uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
     uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
     TriF32 kf;                // T and |T|^2 in float32 for the fast form
@@ -405,20 +404,6 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
     uint32_t bid = FUSE != 0 ? (a.f.xcd_run ? xcd_block_fine(blockIdx.x, a.f.xcd_run, gridDim.x) : xcd_block(blockIdx.x, a.f.xcd_chunk)) : blockIdx.x;   // fused scan: optional XCD-aware tile maps (A/B)
-    if constexpr (FUSE != 0) {
-        // A scan that fits one round of resident workgroups (1920x1080: 4 050 of 4 096 slots) runs in lock step: every wave is in the same phase
-        // -- threshold loads, float64 block, bit loop, tail -- at the same time, and nothing overlaps.  stagger shifts groups of workgroups
-        // against each other: bits 0..4 = which bit of the dispatch order picks the group, bits 5..6 = log2(groups), bits 8..15 = sleep units
-        // (s_sleep 32 = 2 048 cycles) per group step; bit 16 = no sleeping, the groups get different issue priorities instead.
-        if (a.f.stagger) {
-            const uint32_t grp = (blockIdx.x >> (a.f.stagger & 31u)) & ((1u << ((a.f.stagger >> 5) & 3u)) - 1u);
-            if (a.f.stagger & 0x10000u) {
-                if (grp & 1u) __builtin_amdgcn_s_setprio(2);
-            } else {
-                for (uint32_t i = 0; i < grp * ((a.f.stagger >> 8) & 255u); ++i) __builtin_amdgcn_s_sleep(32);
-            }
-        }
-    }
     uint32_t scan = 0u;                                                                      // batched launch: which of the independent scans this workgroup belongs to
     if constexpr (FUSE != 0) {
         if (a.f.batch_bps) {
@@ -1015,7 +1000,6 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     unsigned blocks = (groups + 127) / 128;
     b.f.xcd_chunk = (ctx->tune_fuse_xcd == 1 && n_batch <= 1) ? xcd_chunk_for(ctx, blocks) : 0u;
     b.f.xcd_run = (ctx->tune_fuse_xcd >= 2 && n_batch <= 1 && blocks >= 64) ? (uint32_t)ctx->tune_fuse_xcd : 0u;       // fuse_xcd = n >= 2: fine map, n tiles per XCD
-    b.f.stagger = (n_batch <= 1 && blocks <= (unsigned)ctx->tune_stagger_max) ? (uint32_t)ctx->tune_stagger : 0u;
     if (n_batch > 1) {          // the caller has checked: every scan is a whole number of workgroups, blocks * n_batch * blocks < 2^32
         b.f.batch_bps = blocks;
         b.f.batch_magic = (uint32_t)((0x100000000ull + blocks - 1) / blocks);
@@ -1023,11 +1007,6 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         blocks *= (unsigned)n_batch;
     }
     const bool wave = b.f.wave_tail != 0;
-    struct LdsPad {                       // restores the launch default on every way out
-        slgc_ctx *c;
-        ~LdsPad() { c->launch_lds = 0; }
-    } lds_pad{ctx};
-    ctx->launch_lds = (n_batch <= 1 && blocks <= (unsigned)ctx->tune_stagger_max) ? (unsigned)ctx->tune_lds_pad : 0u;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;
     if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, 2>), dim3(blocks), dim3(128), b);

@@ -56,11 +56,7 @@ struct slgc_ctx {
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel
-    int tune_stagger;       // fused scan kernel, launches of at most tune_stagger_max workgroups: start-up phase shift between workgroup groups (decode.hip)
-    int tune_stagger_max;
     int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
-    int tune_lds_pad;       // fused scan kernel: extra dynamic LDS bytes per workgroup (an occupancy limiter for A/B: fewer resident workgroups, more rounds)
-    unsigned launch_lds;    // dynamic LDS of the next SLGC_LAUNCH (0 except inside launch_scan_fused)
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_image_rows;    // height of the whole image a band belongs to (0 = the band IS the image): the node-table decision (size and accuracy) is taken
@@ -249,10 +245,10 @@ inline uint32_t xcd_chunk_for(const slgc_ctx *ctx, unsigned blocks)
 #define SLGC_LAUNCH(ctx, kernel, grid, block, ...)                                                                        \
     do {                                                                                                                  \
         if ((ctx)->prof_cur[0]) {                                                                                         \
-            hipExtLaunchKernelGGL(kernel, grid, block, (ctx)->launch_lds, (ctx)->stream, (ctx)->prof_cur[0], (ctx)->prof_cur[1], 0, __VA_ARGS__); \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, (ctx)->prof_cur[0], (ctx)->prof_cur[1], 0, __VA_ARGS__); \
             (ctx)->prof_bound = true;                                                                                     \
             (ctx)->prof_cur[0] = (ctx)->prof_cur[1] = nullptr; /* one kernel per sample: a ragged-tail launch is not timed */ \
         } else {                                                                                                          \
-            hipLaunchKernelGGL(kernel, grid, block, (ctx)->launch_lds, (ctx)->stream, __VA_ARGS__);                       \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                       \
         }                                                                                                                 \
     } while (0)

@@ -75,8 +75,6 @@ int slgc_synchronize(slgc_ctx *ctx);
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
  * "lists_order" = workgroup -> tile order of the x-major list build: 1 column-major (default: a column's run continues in the tile below, so
  * the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000), 0 row-major, 2 column-major inside each XCD (no better).
- * "stagger" / "stagger_max" / "lds_pad": start-up phase shifts and an occupancy limiter for launches of the fused kernel that fit one round of
- * resident workgroups (1920x1080) -- measured, no gain, off.
  * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
  * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
  * scan its bands (0, the default: the band is the image).
@@ -90,7 +88,7 @@ int slgc_tune(slgc_ctx *ctx, const char *name, int value);
  * kernel.  Results are identical on all three. */
 int slgc_last_input_path(slgc_ctx *ctx);
 
-/* Which kernels the last slgc_scan_dev / slgc_scan_batch_dev call on this context launched (slgc_scan_dev silently takes the two-kernel
+/* Which kernels the last slgc_scan_dev / slgc_scan_batch_dev / slgc_cloud_dev call (or slgc_decode_dev + slgc_triangulate_maps_dev pair) on this context launched (slgc_scan_dev silently takes the two-kernel
  * path when a buffer is misaligned, the band is ragged, a count is requested or the mode asks for it): returns one of SLGC_PATH_* (or a
  * negative status).  Optional outputs: *ns_frames = the frames-per-run specialisation the decode / fused kernel was compiled for (42, 44,
  * 46; 0 = the generic kernel); *node_table = 1 if the triangulation read the every-4th-column camera table; *guard = 1 float32 fast form
