@@ -55,11 +55,16 @@ class Triangulate(object):
         """Reference triangulate.py:39-71 -> (cam_pts f32 [M,2], proj_pts f32 [M,2], colors f64 [M,3]).
 
         x-major point order like the reference (``order='row'`` gives row-major).  The reference
-        raises UnboundLocalError when ``img_white`` is None (:71); here colors is None instead.
+        raises UnboundLocalError when ``img_white`` is None (:71); here colors is None instead.  With no decodable pixel at all
+        the reference's ``np.array([], dtype=np.float32)`` has shape (0,), not (0, 2): reproduced (:66-69).
         """
         o = _native.ORDER_X if order == "x" else _native.ORDER_ROW
-        return self._context().cam_proj_pts(self.h_pixels, self.v_pixels, (self.cam_w, self.cam_h),
-                                            (self.proj_w, self.proj_h), img_white, o)
+        cam, proj, col = self._context().cam_proj_pts(self.h_pixels, self.v_pixels, (self.cam_w, self.cam_h),
+                                                      (self.proj_w, self.proj_h), img_white, o)
+        if len(cam) == 0:
+            cam, proj = cam.reshape(0), proj.reshape(0)
+            col = None if col is None else col.reshape(0)
+        return cam, proj, col
 
     def triangulate(self, cam_pts, proj_pts, exact=True):
         """Reference triangulate.py:73-97 -> float64 (3,M), camera-centred, projector axes.

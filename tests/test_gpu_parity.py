@@ -472,6 +472,12 @@ def test_golden_triangulate_cases(ctx, tri_cases):
         assert np.array_equal(cam_r, ref_r[0]) and np.array_equal(proj_r, ref_r[1]) and np.array_equal(col_r, ref_r[2])
         cam_n, proj_n, col_n = t.get_cam_proj_pts(None)
         assert col_n is None and np.array_equal(cam_n, c["cam_pts"])
+        # no decodable pixel at all: the reference's np.array([], dtype=float32) has shape (0,) (triangulate.py:66-69), and triangulate() of it is empty
+        t0 = Triangulate(np.full_like(c["h"], -1), c["v"], tuple(int(x) for x in c["cam_size"]), c["cam_mtx"], c["cam_dist"],
+                         tuple(int(x) for x in c["proj_size"]), tuple(int(x) for x in c["proj_size"]), c["proj_mtx"].copy(), c["proj_dist"], c["R"], c["T"], None, ctx=ctx)
+        e_cam, e_proj, e_col = t0.get_cam_proj_pts(c["white"])
+        assert e_cam.shape == (0,) and e_cam.dtype == np.float32 and e_proj.shape == (0,) and e_col.shape == (0,) and e_col.dtype == np.float64
+        assert t0.triangulate(e_cam, e_proj).shape == (3, 0)
 
 
 def test_cam_proj_pts_large_vs_oracle(ctx):

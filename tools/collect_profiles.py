@@ -63,6 +63,12 @@ t = {"c3_4096x3000x44/g1/split": {"kernel": dec, "hbm_bytes_per_launch": traffic
      "c3_4096x3000x44/g1/fused": {"kernel": fus, "hbm_bytes_per_launch": traffic(fus), "fetch_size_kb": d[fus]["FETCH_SIZE"]["mean"],
                                   "write_size_kb": d[fus]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
                                   "source": note + "; includes the projector-ray gathers and the 4 B/pixel maps, which SURVEY 8(d)'s N + 12 does not count"}}
+C2_GRID = 1920 * 1080 // 4
+c2k = next((k for k in d if re.match(r"k_decode_pk<[^>]*, 2, 44> @grid=%d$" % C2_GRID, k) and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]), None)
+if c2k:
+    t["c2_1920x1080x44/g1/fused"] = {"kernel": c2k, "hbm_bytes_per_launch": traffic(c2k), "fetch_size_kb": d[c2k]["FETCH_SIZE"]["mean"],
+                                     "write_size_kb": d[c2k]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
+                                     "source": note + "; 1920x1080 physical scene: the per-pixel camera table (16.6 MB) and the projector table are read through L2 from the Infinity Cache"}
 ss = fus + " [s-scene]"
 if ss in d and "FETCH_SIZE" in d[ss]:
     t["c3_4096x3000x44/g1/fused"]["s_scene_hbm_bytes_per_launch"] = traffic(ss)

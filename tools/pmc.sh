@@ -3,7 +3,7 @@
 # usage: tools/pmc.sh <outdir> [bench args...]
 # Per counter group three short bench runs, each launching ONE kind of scan kernel on ONE scene (the summary is keyed by kernel @ grid):
 #   passN         fused kernel on the headline (physical) scene        passN_split   decode kernel + dense triangulation kernel (S-scene stacks)
-#   passN_sscene  fused kernel on the S-scene
+#   passN_sscene  fused kernel on the S-scene                          passN_c2      (FETCH_SIZE / WRITE_SIZE only) fused kernel at 1920x1080, physical scene
 set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -17,6 +17,10 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_I
   timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass${i}_split" -- python3 bench.py $common --pipeline split --scene s-scene "$@" > "$out/pass${i}_split.log" 2>&1
   rc2=$?
   timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass${i}_sscene" -- python3 bench.py $common --scene s-scene "$@" > "$out/pass${i}_sscene.log" 2>&1
-  echo "pass $i ($ctrs): rc=$rc1 $rc2 $?"
+  rc3=$?
+  if [ $i -le 2 ]; then      # HBM bytes of the fused kernel at 1920x1080 (BASELINE configs[1]) as well
+    timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass${i}_c2" -- python3 bench.py $common --workload c2_1920x1080x44 > "$out/pass${i}_c2.log" 2>&1
+  fi
+  echo "pass $i ($ctrs): rc=$rc1 $rc2 $rc3 $?"
 done
 python3 tools/pmc_summary.py "$out"
