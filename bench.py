@@ -94,8 +94,14 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SLGC_UID_KEY=key, MASTER_ADDR="127.0.0.1",
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if os.environ.get("SLGC_RANKS_AS_HOSTS") == "1":
+            # TEST MODE for boxes with fewer GPUs than ranks: RCCL refuses two ranks on one device of one host ("Duplicate GPU detected"), so every
+            # rank claims a host of its own (NCCL_HOSTID) and the ranks talk over the loopback socket transport.  Every RCCL call of the sharded
+            # path then runs with nranks > 1 for real -- in-place ncclAllGather, grouped ncclBroadcast, the communication stream and its events --
+            # at the speed of a TCP socket: a correctness mode, never a measurement.
+            env.update(NCCL_HOSTID=f"slgc-rank-{r}-{key}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    deadline = time.time() + float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900"))
+    deadline = time.time() + float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900")) + 15.0       # rank 0's own watchdog (same limit) prints its line first
     rcs = [None] * n
     while any(rc is None for rc in rcs):
         for i, p in enumerate(procs):
@@ -366,7 +372,13 @@ def main():
         sys.exit(1)
 
 
+STAGE = ["start"]          # where the run is (printed by the watchdogs: a hang names its stage)
+
+
 def run_rank(args, rank, local_rank, world):
+    if os.environ.get("SLGC_RANKS_AS_HOSTS") == "1" and world > 1 and "NCCL_HOSTID" not in os.environ:
+        # the same TEST MODE under an external launcher (torch.distributed.run gives every rank the same environment): see spawn_ranks
+        os.environ.update(NCCL_HOSTID=f"slgc-rank-{rank}-{os.environ.get('MASTER_PORT', '0')}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
     from scanner import _native
     cam_w, cam_h, proj_w, proj_h, N = WORKLOADS[args.workload]
     G = args.gpus
@@ -384,13 +396,14 @@ def run_rank(args, rank, local_rank, world):
         def give_up():
             if rank == 0:
                 print(json.dumps({"metric": "Mpixels/s decode+triangulate", "value": None, "unit": "Mpixels/s", "n_gpus": G, "steps": args.steps,
-                                  "warmup": args.warmup, "error": "timed out after SLGC_BENCH_TIMEOUT_S in the multi-rank run"}), flush=True)
+                                  "warmup": args.warmup, "error": f"timed out after SLGC_BENCH_TIMEOUT_S in the multi-rank run (stage: {STAGE[0]})"}), flush=True)
             os._exit(4)
 
         killer = threading.Timer(float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900")), give_up)
         killer.daemon = True
         killer.start()
 
+    STAGE[0] = "context"
     n_dev = max(1, _native.device_count())
     device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
     ctx = _native.Context(device)
@@ -400,9 +413,13 @@ def run_rank(args, rank, local_rank, world):
         ctx.comm_init(0, 1, _native.Context.comm_unique_id())
     if G > 1:
         from scanner import sharded
+        STAGE[0] = "rccl unique id"
         uid, uid_path = sharded.share_unique_id(rank, _native.Context.comm_unique_id, key=os.environ.get("SLGC_UID_KEY"))
+        STAGE[0] = "ncclCommInitRank"
         ctx.comm_init(rank, G, uid)
+        STAGE[0] = "first barrier"
         ctx.comm_barrier()
+        STAGE[0] = "setup"
         if rank == 0:
             try:
                 os.remove(uid_path)
@@ -474,11 +491,15 @@ def run_rank(args, rank, local_rank, world):
         if preheat and args.preheat > 0:                     # untimed: bring the clocks up before the counted warm-up
             t_end = time.perf_counter() + args.preheat
             i = 0
-            while time.perf_counter() < t_end:
+            more = True
+            while more:
                 for _ in range(16):
                     step(i, **kw)
                     i += 1
                 drain()
+                more = time.perf_counter() < t_end
+                if use_comm:                                 # every rank must run the SAME number of scans (each one is a collective): the
+                    more = ctx.comm_allreduce_max(1.0 if more else 0.0) > 0.5       # ranks agree on going on -- a clock per rank would not
         for i in range(W_):
             step(i, **kw)
         drain()
@@ -500,7 +521,9 @@ def run_rank(args, rank, local_rank, world):
             kms = ctx.comm_allreduce_max(kms)
         return el, kms, kn, tot, samples
 
+    STAGE[0] = "timed region (incl. pre-heat and warm-up)"
     elapsed, dec_ms, dec_n, total_pts, dec_samples = timed(args.steps, args.warmup)
+    STAGE[0] = "extras"
     executed = ctx.last_scan_path()                          # what the library actually launched in the timed region (not what this script asked for)
     last_stack = (args.steps - 1) % len(stacks)              # what the output buffers hold now
     single = G == 1 and not use_comm
@@ -578,8 +601,10 @@ def run_rank(args, rank, local_rank, world):
     verify = None
     shard_info = None
     if use_comm:
+        STAGE[0] = "sharded report (compute-only timing)"
         shard_info = sharded_report(ctx, sharded_scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, (proj_w, proj_h), mode, elapsed)
         if not args.no_verify and args.exchange in ("maps", "xyz"):
+            STAGE[0] = "verification"
             verify = verify_sharded(ctx, sharded_scanner, G, rank, N, cam_w, cam_h, (proj_w, proj_h), 1 + last_stack, args.plane_pad, args.scene)
 
     out = None
@@ -721,13 +746,14 @@ def run_rank(args, rank, local_rank, world):
     # Extras of the multi-rank run, AFTER everything above is measured and assembled: a watchdog prints the line as it stands and ends
     # the process if they do not come back (a hang in a collective that has never run on more than one GPU must not cost the run).
     def bail():
-        emit({"sharded_alternatives": {"error": "timed out: the line was printed without them"}})
+        emit({"sharded_alternatives": {"error": f"timed out: the line was printed without them (stage: {STAGE[0]})"}})
         os._exit(3 if (verify is not None and not verify.get("ok", False)) else 5)      # 5 = the extras hung (the headline above is complete)
 
     watchdog = threading.Timer(float(os.environ.get("SLGC_BENCH_ALT_TIMEOUT_S", "120")), bail)
     watchdog.daemon = True
     watchdog.start()
     alternatives = None
+    STAGE[0] = "sharded alternatives"
     if use_comm and args.exchange == "maps" and not args.no_extras and pipelined:
         # The first run on real xGMI is rare: time the other exchange forms too (same stacks, same pipelining, each verified against the maps
         # the main strategy left) -- extras after the counted region, a failure here is reported and changes nothing above.
@@ -765,6 +791,7 @@ def run_rank(args, rank, local_rank, world):
             except Exception as e:  # noqa: BLE001
                 alternatives[label] = {"error": f"{type(e).__name__}: {e}"}
 
+    STAGE[0] = "final barrier"
     watchdog.cancel()
     emit({"sharded_alternatives": alternatives} if (rank == 0 and alternatives) else None)
     if use_comm:
