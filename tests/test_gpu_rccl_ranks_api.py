@@ -1,0 +1,131 @@
+"""The C-ABI's collectives and the one-call sharded scan with SEVERAL RCCL ranks, all on the one GPU of the test box (-m gpu).
+
+RCCL refuses two ranks on one device of one host; here every rank process claims a host of its own (NCCL_HOSTID) and RCCL runs over its
+loopback socket transport (see tests/test_gpu_rccl_multi.py).  Unlike the bench-driven runs there, these ranks call the entry points directly:
+``slgc_comm_allgather_i64``, ``slgc_comm_allreduce_max_f64``, ``slgc_comm_allgatherv`` (equal shards in place = ncclAllGather; ragged, with
+an empty shard = grouped ncclBroadcast), the split ``_begin`` / ``slgc_comm_wait`` form overlapping a kernel, and ``slgc_scan_sharded_dev`` --
+band decode, in-place map all-gatherv (int16 and the 3-byte wire), full-image triangulation -- against the C oracle on every rank."""
+import os
+import sys
+import time
+import uuid
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+
+def _worker(rank, world, key, H, q):
+    try:
+        os.environ.update(NCCL_HOSTID=f"slgc-api-{rank}-{key}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
+        for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):
+            sys.path.insert(0, p)
+        import oracle_c as oc
+        import oracle_np as onp
+        from scanner import _native, sharded
+        from scanner import reference_calibration as rc
+        ctx = _native.Context(0)
+        uid, path = sharded.share_unique_id(rank, _native.Context.comm_unique_id, key=key)
+        ctx.comm_init(rank, world, uid)
+        ctx.comm_barrier()
+        # ---- small collectives
+        assert ctx.comm_allgather_i64(100 + rank) == [100 + r for r in range(world)]
+        assert ctx.comm_allreduce_max(float(rank)) == float(world - 1)
+        # ---- all-gatherv: equal shards in place (ncclAllGather), then ragged with an empty shard (grouped ncclBroadcast)
+        n = 4096
+        full = ctx.alloc(world * n).zero()
+        full.upload(np.full(n, 10 + rank, np.uint8), rank * n)
+        ctx.comm_allgatherv(full.at(rank * n), full.ptr, [n] * world, [r * n for r in range(world)])
+        ctx.synchronize()
+        assert np.array_equal(full.download((world, n), np.uint8), np.repeat(np.arange(10, 10 + world, dtype=np.uint8)[:, None], n, 1))
+        counts = [0 if r == 1 else 1000 + 37 * r for r in range(world)]
+        displs = list(np.cumsum([0] + [c + 8 for c in counts[:-1]]))              # gaps between the shards must stay untouched
+        rag = ctx.alloc(int(displs[-1] + counts[-1] + 64)).zero()
+        mine = ctx.alloc(max(16, counts[rank])).upload(np.full(max(1, counts[rank]), 50 + rank, np.uint8))
+        ctx.comm_allgatherv_begin(mine.ptr, rag.ptr, counts, displs, 1)           # split form: a kernel overlaps the exchange
+        junk = ctx.alloc(1 << 20).zero()
+        ctx.comm_wait(1)
+        ctx.synchronize()
+        got = rag.download((rag.nbytes,), np.uint8)
+        for r in range(world):
+            assert (got[displs[r]:displs[r] + counts[r]] == 50 + r).all(), r
+            assert not got[displs[r] + counts[r]:displs[r] + counts[r] + 8].any()
+        # ---- the one-call sharded scan against the oracle (int16 exchange, then the 3-byte wire)
+        N, W = 26, 128
+        K = rc.CAM_MTX.copy()
+        K[0, 2], K[1, 2], K[0, 0], K[1, 1] = W / 2, H / 2, 250.0, 250.0
+        psize = (160, 120)
+        pk = onp.scale_proj_mtx(rc.PROJ_MTX, psize, (1920, 1080))
+        th = np.deg2rad(-20.0)
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        T = np.array([[0.25], [0.02], [0.04]])
+        ctx.set_calibration(K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
+        st = onp.synth_scene_int(N, H, W, seed=9, noise=4)[0]
+        fh, fv, fx = oc.scan_dense(st, psize, K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T)
+        ok = (fh != -1) & (fv != -1)
+        row0, rows = _native.shard_band(H, world, rank)
+        band = np.ascontiguousarray(st[:, row0:row0 + rows])
+        d_band = ctx.alloc(max(16, band.nbytes))
+        if rows:
+            d_band.upload(band)
+        dh, dv, dx = ctx.alloc(H * W * 2), ctx.alloc(H * W * 2), ctx.alloc(H * W * 12)
+        for wire in (0, 1):
+            ctx.tune("wire", wire)
+            for b in (dh, dv, dx):
+                b.zero()
+            ctx.scan_sharded_dev(d_band.ptr, 1, max(1, rows * W) * N, max(1, rows * W), N, H, W, psize, dh.ptr, dv.ptr, dx.ptr, mode=_native.TRI_EXACT)
+            ctx.synchronize()
+            assert np.array_equal(dh.download((H, W), np.int16), fh) and np.array_equal(dv.download((H, W), np.int16), fv), wire
+            gx = dx.download((H, W, 3), np.float32)
+            assert np.array_equal(np.isfinite(gx[..., 0]), ok)
+            np.testing.assert_allclose(gx[ok], np.moveaxis(fx, 0, -1)[ok], rtol=1e-4, atol=0)
+        ctx.tune("wire", 0)
+        ctx.comm_barrier()
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        ctx.close()
+        q.put((rank, "ok", int(ok.sum())))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (4, 3)])
+def test_collectives_and_one_call_sharded_scan_with_real_rccl_ranks(world, H):
+    """(4, 3): more ranks than rows -> a rank with an empty band takes part in every collective."""
+    import multiprocessing as mp
+    import queue as pyqueue
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    key = f"api_{uuid.uuid4().hex[:10]}"
+    procs = [mpc.Process(target=_worker, args=(r, world, key, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results, deadline = [], time.time() + 240
+    try:
+        while len(results) < world and time.time() < deadline:
+            try:
+                results.append(q.get(timeout=1.0))
+            except pyqueue.Empty:
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    break
+                continue
+            if results[-1][1] != "ok":
+                break
+        for rank, status, info in results:
+            assert status == "ok", f"rank {rank}: {info}"
+        assert len(results) == world, f"only {len(results)} of {world} ranks reported (exit codes {[p.exitcode for p in procs]})"
+        assert len({info for _, _, info in results}) == 1
+    finally:
+        t_end = time.time() + 10
+        for p in procs:
+            p.join(timeout=max(0.1, t_end - time.time()))
+        for p in procs:
+            if p.is_alive():
+                p.kill()                                                              # exact processes this test started
