@@ -83,6 +83,30 @@ def _worker(rank, world, key, H, q):
             assert np.array_equal(np.isfinite(gx[..., 0]), ok)
             np.testing.assert_allclose(gx[ok], np.moveaxis(fx, 0, -1)[ok], rtol=1e-4, atol=0)
         ctx.tune("wire", 0)
+        # ---- ShardedScanner over the real exchange, pipelined: three different captures in flight over two buffer sets and four event
+        #      slots, EVERY scan's reassembled result against the oracle (a reused slot or a single-buffered band = wrong pixels in scan 1 or 2)
+        plan = sharded.ShardPlan(H, W, world)
+        caps = [st] + [onp.synth_scene_int(N, H, W, seed=30 + j, noise=3 + j)[0] for j in range(2)]
+        refs = [(fh, fv, fx)] + [oc.scan_dense(cp, psize, K, rc.CAM_DIST, pk, rc.PROJ_DIST, R, T) for cp in caps[1:]]
+        bufs = []
+        for cp in caps:
+            b = np.ascontiguousarray(cp[:, row0:row0 + rows])
+            bufs.append(ctx.alloc(max(16, b.nbytes)).upload(b) if rows else ctx.alloc(16))
+        for kind, wire in (("maps", "int16"), ("maps", "hv24"), ("xyz", "int16")):
+            sc = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, psize, N, mode=_native.TRI_ALGEBRAIC, exchange_kind=kind, wire=wire)
+            outs = []
+            for j, b in enumerate(bufs + bufs[:1]):                                     # four submits: both buffer sets are reused
+                sc.submit(b.ptr, max(1, rows * W))
+                if j:
+                    outs.append(sc.fetch_dense())
+            sc.flush()
+            outs.append(sc.fetch_dense())
+            for j, (gh, gv, gx) in enumerate(outs):
+                rh, rv, rx = refs[j % 3]
+                okj = (rh != -1) & (rv != -1)
+                assert np.array_equal(gh, rh) and np.array_equal(gv, rv), (kind, wire, j)
+                assert np.array_equal(np.isfinite(gx[..., 0]), okj), (kind, wire, j)
+                np.testing.assert_allclose(gx[okj], np.moveaxis(rx, 0, -1)[okj], rtol=1e-4, atol=0)
         ctx.comm_barrier()
         if rank == 0:
             try:
