@@ -429,7 +429,7 @@ def full_size_reference(tmp_path_factory):
     os.rmdir(ref_dir)
 
 
-@pytest.mark.parametrize("world,mode", [(2, "deferred"), (8, "thread"), (7, "deferred")])
+@pytest.mark.parametrize("world,mode", [(2, "thread"), (8, "deferred"), (7, "deferred")])
 def test_configs3_full_size_every_pixel(full_size_reference, world, mode):
     """BASELINE.json configs[3]: 4096x3000x44 row-sharded over `world` ranks (7: ragged bands, 428 / 429 rows), maps (int16 and 3-byte
     wire), xyz and records strategies, one scan and three pipelined scans each, every pixel of what every rank ends up holding."""
