@@ -376,6 +376,7 @@ STAGE = ["start"]          # where the run is (printed by the watchdogs: a hang 
 
 
 def run_rank(args, rank, local_rank, world):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's host driver only supports dmabuf IPC: RCCL's P2P set-up fails without it
     if os.environ.get("SLGC_RANKS_AS_HOSTS") == "1" and world > 1 and "NCCL_HOSTID" not in os.environ:
         # the same TEST MODE under an external launcher (torch.distributed.run gives every rank the same environment): see spawn_ranks
         os.environ.update(NCCL_HOSTID=f"slgc-rank-{rank}-{os.environ.get('MASTER_PORT', '0')}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
