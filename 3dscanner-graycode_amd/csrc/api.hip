@@ -1253,7 +1253,9 @@ extern "C" int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs,
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
-    if (!d_cam_pts || !d_proj_pts || !d_total) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (!d_total) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if ((d_cam_pts == nullptr) != (d_proj_pts == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "d_cam_pts and d_proj_pts go together");
+    if (!d_cam_pts && !d_pts) return slgc_fail(ctx, SLGC_EINVAL, "nothing to produce: neither the correspondence lists nor the points are wanted");
     if (d_colors && !d_white_rgb) return slgc_fail(ctx, SLGC_EINVAL, "colours need the white image");
     if ((d_h == nullptr) != (d_v == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "d_h and d_v go together");
     if (proj_w < 1 || proj_h < 1 || (size_t)proj_w * proj_h >= (1u << 28)) return slgc_fail(ctx, SLGC_EINVAL, "bad projector size");

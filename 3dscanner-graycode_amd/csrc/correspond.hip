@@ -353,7 +353,7 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
                 const unsigned long long o = o0 + rank;
                 const int pu = PACKED ? (int)(short)(hv & 0xffffu) : (int)hv;
                 const int pv = PACKED ? (int)(short)(hv >> 16) : s_pv[PACKED ? 0 : row][PACKED ? 0 : c];
-                if (!LISTS_ABL(1)) {
+                if (cam && !LISTS_ABL(1)) {              // (slgc_cloud_dev may leave the two correspondence lists out: the points and colours are the product)
                     reinterpret_cast<float2 *>(cam)[o] = make_float2((float)x, (float)(y_tile + row));          // :59 [i, j] = (x, y)
                     reinterpret_cast<float2 *>(proj)[o] = make_float2((float)pu, (float)pv);
                 }

@@ -251,10 +251,10 @@ class DeviceBuffer:
 class CloudLists:
     """Device buffers of the reference-shaped product (slgc_cloud_lists_dev): capacity ``npix`` entries each."""
 
-    def __init__(self, ctx: "Context", npix: int, colors: bool = True, points: bool = True):
+    def __init__(self, ctx: "Context", npix: int, colors: bool = True, points: bool = True, lists: bool = True):
         self.ctx, self.npix = ctx, int(npix)
-        self.cam = ctx.alloc(max(16, self.npix * 8))
-        self.proj = ctx.alloc(max(16, self.npix * 8))
+        self.cam = ctx.alloc(max(16, self.npix * 8)) if lists else None           # lists=False (slgc_cloud_dev only): points + colours, no correspondence lists
+        self.proj = ctx.alloc(max(16, self.npix * 8)) if lists else None
         self.pts = ctx.alloc(max(16, self.npix * 24)) if points else None
         self.colors = ctx.alloc(max(16, self.npix * 24)) if colors else None
         self.count = ctx.alloc(8).zero()
@@ -267,7 +267,8 @@ class CloudLists:
     def download(self):
         """-> (cam_pts f32 [M,2], proj_pts f32 [M,2], Pts f64 (3,M) or None, colors f64 [M,3] or None), as the reference returns them."""
         M = self.total()
-        cam, proj = self.cam.download((M, 2), np.float32), self.proj.download((M, 2), np.float32)
+        cam = self.cam.download((M, 2), np.float32) if self.cam is not None else None
+        proj = self.proj.download((M, 2), np.float32) if self.proj is not None else None
         pts = self.pts.download((3, M), np.float64) if self.pts is not None else None
         col = self.colors.download((M, 3), np.float64) if self.colors is not None else None
         return cam, proj, pts, col
@@ -581,8 +582,8 @@ class Context:
         self._ck(lib().slgc_triangulate_maps_dev(self._h, d_h, d_v, rows, W, row0, int(proj_size[0]), int(proj_size[1]),
                                                  int(mode), d_xyz, d_count))
 
-    def alloc_cloud_lists(self, npix: int, colors: bool = True, points: bool = True) -> CloudLists:
-        return CloudLists(self, npix, colors, points)
+    def alloc_cloud_lists(self, npix: int, colors: bool = True, points: bool = True, lists: bool = True) -> CloudLists:
+        return CloudLists(self, npix, colors, points, lists)
 
     def cloud_lists_dev(self, d_h: int, d_v: int, d_xyz, d_white, cam_w, cam_h, proj_size, lists: CloudLists):
         """int16 maps + dense float32 XYZ (+ device-resident uint8 RGB white image) -> the reference's x-major lists, float64 (3,M)
@@ -598,7 +599,8 @@ class Context:
         triangulation inside it -- no dense XYZ.  lists.pts / lists.colors may be absent."""
         self._ck(lib().slgc_cloud_dev(self._h, d_stack, int(n_runs), int(run_stride), int(plane_stride), int(N), int(cam_h), int(cam_w),
                                       int(proj_size[0]), int(proj_size[1]), float(eps), float(m), d_white if lists.colors is not None else None, d_h, d_v,
-                                      lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
+                                      lists.cam.ptr if lists.cam is not None else None, lists.proj.ptr if lists.proj is not None else None,
+                                      lists.pts.ptr if lists.pts is not None else None,
                                       lists.colors.ptr if lists.colors is not None else None, lists.count.ptr))
 
     def compact_dev(self, d_xyz: int, rows, W, row0, d_points: int, d_keys, d_count: int):

@@ -924,7 +924,14 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
         ctx.synchronize()
         return time.perf_counter() - t0
 
+    prod = ctx.alloc_cloud_lists(band_px, colors=True, lists=False)
+
+    def via_cloud_points(i):
+        s = stacks[i % len(stacks)]
+        ctx.cloud_dev(s.ptr, 1, N * plane, plane, N, rows, W, proj_size, white.ptr, prod, d_h=maps.at(0), d_v=maps.at(band_px * 2))
+
     el_dense = run(via_dense)
+    el_points = run(via_cloud_points)
     el = run(via_cloud)
     executed = ctx.last_scan_path()
     M = lists.total()
@@ -944,6 +951,9 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
            "list_stage_ms": round(stage_ms, 4), "list_stage_bytes": int(stage_bytes),
            "list_stage_roofline": {"bound": "hbm", "achieved": round(stage_bytes / (stage_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "points_and_colours_only": {"value": round(band_px / 1e6 * K / el_points, 1), "ms_per_scan": round(el_points / K * 1e3, 4),
+                                       "note": "slgc_cloud_dev without the two correspondence lists (intermediates of src/4-triangulate.py:62-64; the script keeps "
+                                               "pts_3d and colors, :67-68): 48 instead of 64 bytes written per point"},
            "via_dense_xyz": {"value": round(band_px / 1e6 * K / el_dense, 1), "ms_per_scan": round(el_dense / K * 1e3, 4),
                              "note": "round 2's route: fused scan (writes 12 B/pixel of dense XYZ) + slgc_cloud_lists_dev (reads it back)"},
            "note": "slgc_cloud_dev: decode kernel + x-major list build (count, column prefix, LDS-transposed scatter that triangulates each valid "
@@ -951,6 +961,7 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
                    "list_stage_ms = the list build alone, mean of %d back-to-back builds" % K}
     white.free()
     lists.free()
+    prod.free()
     return out
 
 

@@ -271,7 +271,9 @@ int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, 
  * reference's float64 (3,M)) and its colour gathered from the device-resident white image (:64, :69).  Replaces slgc_scan_dev +
  * slgc_cloud_lists_dev for callers that want the lists: the scan no longer writes 12 B/pixel of dense XYZ for the list build to read back.
  * Whole images only (x-major order needs every row): rows = cam_h, row0 = 0.  Outputs as slgc_cloud_lists_dev (capacity cam_w * cam_h
- * entries each; d_pts / d_colors may be NULL, d_colors needs d_white_rgb).  Asynchronous; *d_total (device) receives M. */
+ * entries each; d_pts / d_colors may be NULL, d_colors needs d_white_rgb).  d_cam_pts / d_proj_pts may be NULL together: the two
+ * correspondence lists are intermediates of src/4-triangulate.py:62-64 -- what that script keeps is pts_3d and colors (:67-68) -- and leaving
+ * them out saves a quarter of the bytes the list build writes.  Asynchronous; *d_total (device) receives M. */
 int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int cam_h, int cam_w,
                    int proj_w, int proj_h, double eps, double m, const uint8_t *d_white_rgb, int16_t *d_h, int16_t *d_v, float *d_cam_pts,
                    float *d_proj_pts, double *d_pts, double *d_colors, unsigned long long *d_total);

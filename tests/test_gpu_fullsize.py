@@ -389,6 +389,12 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), None, bare)
     c2, p2, none_pts, none_col = bare.download()
     assert none_pts is None and none_col is None and np.array_equal(c2, rcam) and np.array_equal(p2, rproj)
+    # points + colours only (what src/4-triangulate.py:67-68 keeps): the same arrays, the two correspondence lists never written
+    prod = ctx.alloc_cloud_lists(px, colors=True, lists=False)
+    ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, prod)
+    n3, n4, pts3, col3 = prod.download()
+    assert n3 is None and n4 is None and np.array_equal(pts3, pts) and np.array_equal(col3, col)
+    prod.free()
     print(f"\n{workload}: {len(rcam)} points, worst rel. XYZ error vs the oracle {float(err.max()):.2e}, {path}")
     for b in (stack, maps, maps2, xyz, white):
         b.free()
