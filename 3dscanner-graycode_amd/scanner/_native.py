@@ -588,6 +588,8 @@ class Context:
     def cloud_lists_dev(self, d_h: int, d_v: int, d_xyz, d_white, cam_w, cam_h, proj_size, lists: CloudLists):
         """int16 maps + dense float32 XYZ (+ device-resident uint8 RGB white image) -> the reference's x-major lists, float64 (3,M)
         points and colours, all in HBM (asynchronous).  d_xyz / d_white may be None."""
+        if lists.cam is None:
+            raise ValueError("cloud_lists_dev always writes the correspondence lists: allocate the CloudLists with lists=True (only cloud_dev can leave them out)")
         self._ck(lib().slgc_cloud_lists_dev(self._h, d_h, d_v, d_xyz if lists.pts is not None else None,      # d_xyz None + points wanted: triangulated in-kernel
                                             d_white if lists.colors is not None else None, int(cam_w), int(cam_h), int(proj_size[0]),
                                             int(proj_size[1]), lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
