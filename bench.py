@@ -332,8 +332,10 @@ def main():
     ap.add_argument("--exchange", default="maps", choices=["maps", "records", "xyz"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default); all-gather maps + "
                          "float32 XYZ bands produced by the fused kernel on each band (xyz); or all-gatherv compacted 16-byte XYZ+key records")
-    ap.add_argument("--wire", default="int16", choices=["auto", "int16", "hv24"],
-                    help="sharded 'maps' exchange: send the int16 maps (4 B/pixel, default) or the packed 3 B/pixel wire format")
+    ap.add_argument("--wire", default="auto", choices=["auto", "int16", "hv24"],
+                    help="sharded 'maps' exchange: the int16 maps as they are (4 B/pixel) or packed to 3 B/pixel (codes of <= 11 bits); auto (default) = "
+                         "packed when there is more than one rank and the codes fit -- a sharded scan is bound by its exchange (SURVEY.md 8(e)), a quarter "
+                         "fewer bytes on the links for two small streaming kernels; the other wire is timed after the counted region (sharded_alternatives)")
     ap.add_argument("--no-overlap", action="store_true", help="sharded modes: do not pipeline the exchange with the neighbouring scans")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path (RCCL exchange at nranks = 1) even on 1 GPU")
     ap.add_argument("--no-verify", action="store_true", help="sharded modes: skip the post-run cross-rank / single-GPU verification")
@@ -763,8 +765,9 @@ def run_rank(args, rank, local_rank, world):
         h_main, v_main, _ = sharded_scanner.fetch_dense()
         main_digest = digest64(h_main, v_main)
         alternatives = {}
-        for label, kind, wire in (("maps_hv24", "maps", "hv24"), ("xyz", "xyz", "int16")):
-            if label == "maps_hv24" and (args.wire == "hv24" or int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS):
+        other_wire = "int16" if sharded_scanner.wire == "hv24" else "hv24"           # whichever wire the main strategy did not use
+        for label, kind, wire in (("maps_" + other_wire, "maps", other_wire), ("xyz", "xyz", "int16")):
+            if wire == "hv24" and int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS:
                 continue
             try:
                 alt = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
@@ -786,7 +789,7 @@ def run_rank(args, rank, local_rank, world):
                 ha, va, _ = alt.fetch_dense()
                 same = ctx.comm_allgather_i64(1 if digest64(ha, va) == main_digest else 0)
                 alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K,
-                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "xyz": 16}[label],
+                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "maps_int16": 4, "xyz": 16}[label],
                                        "maps_equal_main_strategy_on_every_rank": bool(all(same))}
                 del alt
             except Exception as e:  # noqa: BLE001

@@ -99,9 +99,9 @@ def test_two_ranks_on_one_gpu_fail_cleanly():
 # The run verifies itself: every rank compares what it reassembled, bit for bit, with a single-GPU fused scan of the same stack and its digest
 # with every other rank's.  What this does not cover is the xGMI transport itself and its speed.
 CASES = [
-    (2, "t_512x1024x44", ["--exchange", "maps"]),                          # even bands: in-place ncclAllGather, both maps in one group
+    (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "int16"]),       # even bands: in-place ncclAllGather, both maps in one group
     (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "hv24"]),        # packed 3 B/pixel wire, unpacked inside the triangulation kernel
-    (3, "t_516x1031x44", ["--exchange", "maps"]),                          # ragged bands: grouped ncclBroadcast per contributing rank
+    (3, "t_516x1031x44", ["--exchange", "maps", "--wire", "int16"]),       # ragged bands: grouped ncclBroadcast per contributing rank
     (2, "t_516x1031x44", ["--exchange", "xyz"]),                           # fused kernel per band, three in-place band exchanges
     (4, "t_516x1031x44", ["--exchange", "records"]),                       # count all-gather + all-gatherv of 16-byte records
     (5, "t_512x1024x44", ["--exchange", "xyz", "--no-overlap"]),           # more ranks than divide the rows evenly, one scan at a time
@@ -149,5 +149,6 @@ def test_driver_launcher_two_ranks_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong" and j["sharded"]["rccl_nranks"] == 2 and j["verify"]["ok"]
     alt = j["sharded_alternatives"]
-    assert alt["maps_hv24"]["maps_equal_main_strategy_on_every_rank"] and alt["xyz"]["maps_equal_main_strategy_on_every_rank"], alt
+    assert j["sharded"]["wire"] == "hv24"                                   # the default wire with more than one rank: 3 B/pixel
+    assert alt["maps_int16"]["maps_equal_main_strategy_on_every_rank"] and alt["xyz"]["maps_equal_main_strategy_on_every_rank"], alt
     assert j["throughput_mode"]["value"] > 0 and j["throughput_mode"]["scaling"] == "weak"
