@@ -98,6 +98,14 @@ def test_two_ranks_on_one_gpu_fail_cleanly():
 # 3-byte wire, the count all-gather + all-gatherv of the records strategy -- runs exactly as it will over xGMI, at the speed of a TCP socket.
 # The run verifies itself: every rank compares what it reassembled, bit for bit, with a single-GPU fused scan of the same stack and its digest
 # with every other rank's.  What this does not cover is the xGMI transport itself and its speed.
+def _skip_if_transport_unavailable(r, j):
+    """The loopback socket transport is a property of the box, not of the code under test: a run that dies while the communicator is being
+    formed (no usable `lo`, sockets forbidden) skips; anything later -- a wrong result, a hang, an error in a collective -- fails."""
+    err = str((j or {}).get("error", ""))
+    if j is not None and j.get("value") is None and ("slgc_comm_init" in err or "CommInitRank" in err or "unique id" in err):
+        pytest.skip(f"RCCL could not form a communicator over the loopback socket transport on this box: {err[:300]}")
+
+
 CASES = [
     (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "int16"]),       # even bands: in-place ncclAllGather, both maps in one group
     (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "hv24"]),        # packed 3 B/pixel wire, unpacked inside the triangulation kernel
@@ -113,6 +121,7 @@ CASES = [
 def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
     r, j = run_bench("--gpus", str(nranks), "--steps", "9", "--warmup", "2", "--no-extras", "--scene", "s-scene", "--workload", workload, *extra,
                      timeout=100, ranks_as_hosts=True, attempts=2)
+    _skip_if_transport_unavailable(r, j)
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     assert j["n_gpus"] == nranks and j["sharded"]["rccl_nranks"] == nranks and j["valid_pixels_per_scan"] > 1000
     if "records" not in extra:
@@ -128,6 +137,7 @@ def test_rccl_configs3_full_size_on_one_gpu_over_loopback(nranks, extra):
     transport, all ranks on the one GPU), pipelined, self-verified bit for bit on every rank."""
     r, j = run_bench("--gpus", str(nranks), "--steps", "5", "--warmup", "1", "--no-extras", "--workload", "c3_4096x3000x44", *extra,
                      timeout=150, ranks_as_hosts=True, attempts=2)
+    _skip_if_transport_unavailable(r, j)
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     v = j["verify"]
     assert j["sharded"]["rccl_nranks"] == nranks and "configs[3]" in j["config"]["workload"]
@@ -145,6 +155,7 @@ def test_driver_launcher_two_ranks_on_one_gpu():
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "c2_1920x1080x44", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    _skip_if_transport_unavailable(r, json.loads(lines[-1]) if lines else None)
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong" and j["sharded"]["rccl_nranks"] == 2 and j["verify"]["ok"]
