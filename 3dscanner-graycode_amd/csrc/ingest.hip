@@ -10,6 +10,8 @@
 //                        carries 16 pixels through ALL frames (every frame byte is read once: N B / pixel), two pixels per
 //                        32-bit operation; float64 frames and ragged sizes take the generic kernel.  The keep/drop state
 //                        machine (:56-66) is host logic.
+#include <cmath>
+
 #include "slgc_internal.h"
 
 namespace {
@@ -85,18 +87,29 @@ __device__ __forceinline__ unsigned wave_sum(unsigned c)
                       __builtin_amdgcn_readlane((int)c, 48));
 }
 
-__global__ void __launch_bounds__(256) k_frame_diff_u8x16(const uint4 *__restrict__ frames, size_t chunks, int n_frames, unsigned c_fields,
-                                                          unsigned long long *__restrict__ counts)
+// blockIdx.y = a segment of consecutive frame pairs [pair0, pair1): the launcher cuts the frames into segments when the workgroups of one
+// pass would fill the chip's resident slots unevenly (4096x3000: 3 000 workgroups on 2 048 slots = two rounds for 1.46 rounds of work; two
+// segments = 6 000 shorter workgroups = 2.93 rounds, at the price of reading one frame per lane twice).  Loads run two frames ahead
+// (deeper: no faster), non-temporal: every frame byte is read once.
+// counts: kFdSlots partial rows of n_frames - 1 counters, a workgroup adds into row blockIdx.x % kFdSlots (a single row takes ~3 000 atomic adds
+// per counter on three cache lines); k_frame_diff_fold sums the rows.
+constexpr int kFdSlots = 64;
+__global__ void __launch_bounds__(256) k_frame_diff_u8x16(const uint4 *__restrict__ frames, size_t chunks, int n_frames, int pairs_per_seg, unsigned c_fields,
+                                                          unsigned long long *__restrict__ counts, int row_stride)
 {
-    extern __shared__ unsigned s_cnt[];                                  // n_frames - 1 counters of this workgroup
-    for (int p = threadIdx.x; p < n_frames - 1; p += 256) s_cnt[p] = 0u;
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    extern __shared__ unsigned s_cnt[];                                  // pairs_per_seg counters of this workgroup
+    for (int p = threadIdx.x; p < pairs_per_seg; p += 256) s_cnt[p] = 0u;
     __syncthreads();
+    const int pair0 = (int)blockIdx.y * pairs_per_seg, pair1 = min(n_frames - 1, pair0 + pairs_per_seg);      // frames pair0 .. pair1
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool active = q < chunks;
     const size_t qc = active ? q : chunks - 1;
+    const v4u_ *fr = reinterpret_cast<const v4u_ *>(frames) + qc;
+    auto fetch = [&](int f) { return __builtin_nontemporal_load(fr + (size_t)f * chunks); };
     unsigned lo[4], hi[4];
     {
-        const uint4 a = frames[qc];
+        const v4u_ a = fetch(pair0);
         const unsigned w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -104,12 +117,11 @@ __global__ void __launch_bounds__(256) k_frame_diff_u8x16(const uint4 *__restric
             hi[k] = (w[k] >> 8) & kFieldMask;
         }
     }
-    const int last = n_frames - 1;                                       // loads run two frames ahead (the last frame is re-read at the end)
-    uint4 n1 = frames[(size_t)1 * chunks + qc], n2 = frames[(size_t)min(2, last) * chunks + qc];
-    for (int f = 1; f < n_frames; ++f) {
-        const uint4 b = n1;
+    v4u_ n1 = fetch(min(pair0 + 1, pair1)), n2 = fetch(min(pair0 + 2, pair1));   // (the segment's last frame is re-read past its end)
+    for (int f = pair0 + 1; f <= pair1; ++f) {
+        const v4u_ b = n1;
         n1 = n2;
-        n2 = frames[(size_t)min(f + 2, last) * chunks + qc];
+        n2 = fetch(min(f + 2, pair1));
         const unsigned w[4] = {b.x, b.y, b.z, b.w};
         unsigned c = 0;
 #pragma unroll
@@ -122,11 +134,21 @@ __global__ void __launch_bounds__(256) k_frame_diff_u8x16(const uint4 *__restric
         }
         if (!active) c = 0;
         const unsigned total = wave_sum(c);
-        if ((threadIdx.x & 63) == 0 && total) atomicAdd(&s_cnt[f - 1], total);
+        if ((threadIdx.x & 63) == 0 && total) atomicAdd(&s_cnt[f - 1 - pair0], total);
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < n_frames - 1; p += 256)
-        if (s_cnt[p]) atomicAdd(counts + p, (unsigned long long)s_cnt[p]);
+    unsigned long long *row = counts + (size_t)(blockIdx.x % kFdSlots) * row_stride;
+    for (int p = threadIdx.x; p < pair1 - pair0; p += 256)
+        if (s_cnt[p]) atomicAdd(row + pair0 + p, (unsigned long long)s_cnt[p]);
+}
+
+__global__ void __launch_bounds__(64) k_frame_diff_fold(const unsigned long long *__restrict__ rows, int row_stride, int n, unsigned long long *__restrict__ counts)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= n) return;
+    unsigned long long t = 0;
+    for (int r = 0; r < kFdSlots; ++r) t += rows[(size_t)r * row_stride + p];
+    counts[p] = t;
 }
 
 __global__ void k_fill_u64(unsigned long long *__restrict__ out, int n, unsigned long long v)
@@ -163,8 +185,28 @@ int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int
         const unsigned t = (unsigned)thresh;                             // floor, 0..254
         if (elems % 16 == 0 && ((uintptr_t)d_frames & 15) == 0 && (size_t)(n_frames - 1) * 4 <= 48 * 1024) {
             const size_t chunks = elems / 16;
-            hipLaunchKernelGGL(k_frame_diff_u8x16, dim3((unsigned)((chunks + 255) / 256)), dim3(256), (size_t)(n_frames - 1) * 4, ctx->stream,
-                               (const uint4 *)d_frames, chunks, n_frames, (0x7fffu - t) * 0x00010001u, d_counts);
+            // frame segments: the number (1 .. 4) whose workgroups fill whole rounds of the 256 CUs x 8 resident workgroups best, counting the
+            // frame each extra segment reads twice
+            const double wgs = (double)((chunks + 255) / 256), slots = 2048.0;
+            static const int force = xcd_env("SLGC_FD_SEGS", 0);        // A/B
+            int segs = 1;
+            double best = 1e30;
+            for (int sgs = 1; sgs <= 4 && sgs <= n_frames - 1; ++sgs) {
+                const double rounds = wgs * sgs / slots, cost = std::ceil(rounds) / rounds * (1.0 + (double)(sgs - 1) / (double)(n_frames - 1));
+                if (cost < best - 1e-9) { best = cost; segs = sgs; }
+            }
+            if (force >= 1 && force <= n_frames - 1) segs = force;
+            const int per = (n_frames - 1 + segs - 1) / segs;
+            const dim3 grid((unsigned)((chunks + 255) / 256), (unsigned)((n_frames - 1 + per - 1) / per));
+            const int row_stride = (n_frames - 1 + 15) & ~15;             // rows start on their own 128-byte lines
+            void *rows;
+            int rc = slgc_ws(ctx, 4, (size_t)kFdSlots * row_stride * 8, &rows);      // (slot 4: the list build's counts; slot 7 may hold the caller's d_counts)
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(rows, 0, (size_t)kFdSlots * row_stride * 8, ctx->stream));
+            hipLaunchKernelGGL(k_frame_diff_u8x16, grid, dim3(256), (size_t)per * 4, ctx->stream, (const uint4 *)d_frames, chunks, n_frames, per,
+                               (0x7fffu - t) * 0x00010001u, (unsigned long long *)rows, row_stride);
+            hipLaunchKernelGGL(k_frame_diff_fold, dim3((unsigned)((n_frames - 1 + 63) / 64)), dim3(64), 0, ctx->stream, (const unsigned long long *)rows, row_stride,
+                               n_frames - 1, d_counts);
             HIP_TRY(ctx, hipGetLastError());
             return SLGC_OK;
         }
