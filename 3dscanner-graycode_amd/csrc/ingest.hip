@@ -16,16 +16,28 @@
 
 namespace {
 
-// 16 pixels = 48 input bytes = three 16-byte loads per lane, one 16-byte store
+// 16 pixels per lane = 48 input bytes, one 16-byte store.  The 48 bytes of a lane are three 16-byte pieces 48 bytes apart from the next
+// lane's: read that way a wave's load instruction touches three times the cache lines it uses.  The workgroup reads its 12 KB with
+// consecutive lanes on consecutive 16-byte pieces (three fully coalesced 1 KB-per-wave loads, non-temporal: every byte is read once), parks
+// them in LDS and every lane picks its own 48 bytes up from there.
 __global__ void __launch_bounds__(256) k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t npix, int ry, int gy,
                                                      int by, int shift)
 {
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    __shared__ uint4 s_in[768];
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (q * 16 >= npix) return;
     const int rnd = 1 << (shift - 1);
-    if (q * 16 + 16 <= npix && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)gray & 15) == 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(bgr) + q * 3;
-        const uint4 a = src[0], b = src[1], c = src[2];
+    const size_t wg_px0 = (size_t)blockIdx.x * 4096;
+    const bool whole = wg_px0 + 4096 <= npix && ((uintptr_t)bgr & 15) == 0 && ((uintptr_t)gray & 15) == 0;      // workgroup-uniform
+    if (whole) {
+        const v4u_ *src = reinterpret_cast<const v4u_ *>(bgr) + (size_t)blockIdx.x * 768;
+        v4u_ t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = __builtin_nontemporal_load(src + i * 256 + threadIdx.x);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s_in[i * 256 + threadIdx.x] = make_uint4(t[i].x, t[i].y, t[i].z, t[i].w);
+        __syncthreads();
+        const uint4 a = s_in[3 * threadIdx.x], b = s_in[3 * threadIdx.x + 1], c = s_in[3 * threadIdx.x + 2];
         const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
         uint32_t out[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
