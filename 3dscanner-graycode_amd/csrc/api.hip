@@ -1151,12 +1151,7 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     RunPtrs runs{};
     int e;
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
-    if (!d_h || !d_v) {
-        void *maps;
-        if ((rc = slgc_ws(ctx, 3, (size_t)rows * W * 4 + 64, &maps))) return rc;
-        d_h = (int16_t *)maps;
-        d_v = d_h + (((size_t)rows * W + 31) & ~(size_t)31);
-    }
+    if (!d_h || !d_v) d_h = d_v = nullptr;          // no map buffers: the fused kernel then stores XYZ only
     const size_t npix = (size_t)rows * W;
     if (mode == SLGC_TRI_ALGEBRAIC && !d_count && npix % 4 == 0 && scan_fused_eligible(g, runs, plane_stride, npix, d_h, d_v, d_xyz) &&
         proj_w >= 1 && proj_h >= 1 && (size_t)proj_w * proj_h < (1u << 28) && !want_split) {
@@ -1169,6 +1164,12 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     }
     ctx->last_scan_path = SLGC_PATH_NONE;
     ctx->last_ragged = 0;
+    if (!d_h) {                                     // the two-kernel path hands the maps over through HBM: scratch of the context
+        void *maps;
+        if ((rc = slgc_ws(ctx, 3, (size_t)rows * W * 4 + 64, &maps))) return rc;
+        d_h = (int16_t *)maps;
+        d_v = d_h + (((size_t)rows * W + 31) & ~(size_t)31);
+    }
     if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, 0))) return rc;
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
     ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
@@ -1183,7 +1184,8 @@ extern "C" int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if (n_scans < 0 || !d_stacks || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative count");
+    if (n_scans < 0 || !d_stacks || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative count");
+    if (!d_h || !d_v) d_h = d_v = nullptr;          // XYZ only
     const size_t npix = (size_t)rows * W;
     DecodeGeom g;
     RunPtrs runs{};
@@ -1201,8 +1203,8 @@ extern "C" int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n
         return prof_mark(ctx, 1);
     }
     for (int s = 0; s < n_scans; ++s)                                     // any other shape / mode: scan after scan
-        if ((rc = slgc_scan_dev(ctx, d_stacks + (size_t)s * scan_stride, 1, 0, plane_stride, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h + s * npix,
-                                d_v + s * npix, d_xyz + 3 * s * npix, nullptr)))
+        if ((rc = slgc_scan_dev(ctx, d_stacks + (size_t)s * scan_stride, 1, 0, plane_stride, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h ? d_h + s * npix : nullptr,
+                                d_v ? d_v + s * npix : nullptr, d_xyz + 3 * s * npix, nullptr)))
             return rc;
     return SLGC_OK;
 }

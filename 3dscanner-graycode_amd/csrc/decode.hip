@@ -253,7 +253,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     const float2 *proj_lut;   // 8x8-tiled projector rays
     float *xyz;               // [npix][3]
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
-    int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads)
+    int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads); bit 2: the maps are not stored at all
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
     uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
@@ -575,7 +575,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         wv_[2 * q + 1] = __builtin_amdgcn_perm(ov[2 * q + 1], ov[2 * q], 0x07060302u);
     }
     if constexpr (NW == 1) {
-        if (a.f.nt_store & 2) {          // fused scan only: the maps are a product there, nothing re-reads them (the two-kernel path keeps them cacheable for K3)
+        if (FUSE != 0 && (a.f.nt_store & 4)) {          // fused scan, caller passed no map buffers: XYZ is the only product (wave-uniform branch)
+        } else if (a.f.nt_store & 2) {   // fused scan only: the maps are a product there, nothing re-reads them (the two-kernel path keeps them cacheable for K3)
             __builtin_amdgcn_raw_buffer_store_b64(v2u{wh_[0], wh_[1]}, rh, off * 2u, 0, 2);
             __builtin_amdgcn_raw_buffer_store_b64(v2u{wv_[0], wv_[1]}, rv, off * 2u, 0, 2);
         } else {
@@ -990,7 +991,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const int lut_w = ctx->lut_cam_W;
     b.f.cn = SLGC_CAM_NODES_FOR(ctx, lut_w, cam_lut == ctx->lut_cam && npix4 / 4 < (1u << 24));
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
-    b.f.nt_store = ctx->tune_fuse_nt;
+    b.f.nt_store = (ctx->tune_fuse_nt & 3) | ((d_h == nullptr || d_v == nullptr) ? 4 : 0);
     b.f.wave_tail = ctx->tune_fuse_tail;
     b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);

@@ -653,9 +653,10 @@ class Context:
             self._ck(lib().slgc_prof_samples(self._h, _ptr(out), n.value, C.byref(n)))
         return out
 
-    def scan_batch_dev(self, d_stacks: int, n_scans, scan_stride, plane_stride, N, rows, W, row0, proj_size, d_xyz: int, d_h: int, d_v: int,
+    def scan_batch_dev(self, d_stacks: int, n_scans, scan_stride, plane_stride, N, rows, W, row0, proj_size, d_xyz: int, d_h=None, d_v=None,
                        eps=1.0, m=10.0, mode=TRI_ALGEBRAIC):
-        """n_scans independent single-run scans of one geometry in one launch (throughput mode); outputs back to back per scan."""
+        """n_scans independent single-run scans of one geometry in one launch (throughput mode); outputs back to back per scan.
+        d_h = d_v = None: XYZ only (the fused kernel then stores no maps)."""
         self._ck(lib().slgc_scan_batch_dev(self._h, d_stacks, int(n_scans), int(scan_stride), int(plane_stride), int(N), int(rows), int(W), int(row0),
                                            int(proj_size[0]), int(proj_size[1]), float(eps), float(m), int(mode), d_h, d_v, d_xyz))
 

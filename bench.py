@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
                     launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s
   cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on BASELINE configs[0] at full size,
                     1 thread, plus the plain-C oracle on 1 and on all host cores (N = 1 only)
-  split_pipeline / decode_kernel_alone / throughput_mode / reference_product    N = 1 extras, same run
+  split_pipeline / xyz_only / decode_kernel_alone / throughput_mode / reference_product    N = 1 extras, same run
 """
 import argparse
 import hashlib
@@ -474,7 +474,7 @@ def run_rank(args, rank, local_rank, world):
     ctx.synchronize()
     pipelined = use_comm and args.exchange in ("maps", "xyz") and not args.no_overlap
 
-    def step(i, counted=False, mode=mode, src=None):
+    def step(i, counted=False, mode=mode, src=None, no_maps=False):
         src = stacks if src is None else src
         s = src[i % len(src)]
         if pipelined:
@@ -482,7 +482,7 @@ def run_rank(args, rank, local_rank, world):
         if use_comm:
             return sharded_scanner.scan(s.ptr, plane)
         ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
-                     maps.at(0), maps.at(band_px * 2), mode=mode)
+                     None if no_maps else maps.at(0), None if no_maps else maps.at(band_px * 2), mode=mode)
         return None
 
     def drain():
@@ -564,6 +564,12 @@ def run_rank(args, rank, local_rank, world):
         om = mode_fused if args.pipeline == "split" else mode_split
         other = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=om)
         other_executed = ctx.last_scan_path()
+
+    xyz_only = None
+    if extras:
+        # the same scan for a caller that wants the cloud only (no map buffers passed): the fused kernel then moves exactly SURVEY 8(d)'s N + 12 B/pixel
+        xyz_only = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, no_maps=True)
+        xyz_only_executed = ctx.last_scan_path()
 
     dec_alone = None
     if extras:
@@ -697,6 +703,17 @@ def run_rank(args, rank, local_rank, world):
                                          "executed": other_executed,
                                          "roofline": kernel_roofline("fused" if other_executed["path"] == "fused" else "split", o_kms, o_kn, o_samples, other_executed),
                                          "note": "same scan, same run, timed right after the main region"}
+        if xyz_only is not None:
+            x_el, x_kms, x_kn, _, x_samples = xyz_only
+            xr = kernel_roofline("fused" if xyz_only_executed["path"] == "fused" else "split", x_kms, x_kn, x_samples, xyz_only_executed)
+            xr.pop("frac_incl_maps", None), xr.pop("frac_incl_maps_note", None)
+            xr["traffic"] = None                              # the committed counters are of the kernel that also stores the maps
+            xr.pop("traffic_source", None), xr.pop("traffic_scene", None)
+            out["xyz_only"] = {"value": round(mpix_per_step * args.steps / x_el, 1), "unit": "Mpixels/s", "ms_per_step": round(x_el / args.steps * 1e3, 4),
+                               "steps": args.steps, "executed": xyz_only_executed, "roofline": xr,
+                               "note": "the headline scan with d_h = d_v = NULL (cloud wanted, maps not): same kernel, the two int16 map stores "
+                                       "skipped; XYZ bit-identical (tests/test_gpu_fullsize.py).  NOT the headline: the reference's decode script "
+                                       "keeps the maps, so `value` is measured with them stored"}
         if dec_alone is not None:
             out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", *dec_alone, ex=dec_alone_exec), "scene": "s-scene",
                                           "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "

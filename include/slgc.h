@@ -205,7 +205,8 @@ int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t ru
                     int rows, int W, double eps, double m, int16_t *d_h, int16_t *d_v, int variant);
 
 /* Decode -> clamp -> triangulate on a row band: dense float32 XYZ [rows][W][3] (NaN where undecodable),
- * optional int16 maps (may be NULL), and *d_count += number of valid pixels.  row0 = first row of the band in the
+ * optional int16 maps (d_h = d_v = NULL: XYZ is the only product -- the one-kernel form then stores no maps at all, N + 12 bytes per
+ * pixel of HBM traffic instead of N + 16; the two-kernel form keeps them in scratch of the context), and *d_count += number of valid pixels.  row0 = first row of the band in the
  * full image (camera y of local row 0).  With mode = SLGC_TRI_ALGEBRAIC, no count requested and 4-byte aligned buffers
  * this is ONE kernel (decode with the triangulation tail); otherwise (or with SLGC_TRI_SPLIT) two kernels. */
 int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
@@ -213,7 +214,8 @@ int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_
                   int16_t *d_v, float *d_xyz, unsigned long long *d_count);
 /* Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry in one launch -- stacks scan_stride bytes
  * apart, d_h / d_v [n_scans][rows * W] int16 and d_xyz [n_scans][rows * W][3] float32 back to back.  Same results as n_scans calls of
- * slgc_scan_dev (which is what shapes that are not a whole number of 512-pixel workgroups, and the other modes, fall back to). */
+ * slgc_scan_dev (which is what shapes that are not a whole number of 512-pixel workgroups, and the other modes, fall back to).
+ * d_h = d_v = NULL: XYZ only, as there. */
 int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n_scans, size_t scan_stride, size_t plane_stride, int N, int rows, int W,
                         int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz);
 

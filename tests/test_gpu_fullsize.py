@@ -332,6 +332,44 @@ def test_executed_path_is_observable(ctx, workload):
         b.free()
 
 
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "c1_1280x720x42"])
+def test_scan_without_map_buffers_is_xyz_only(ctx, workload):
+    """slgc_scan_dev / slgc_scan_batch_dev with d_h = d_v = NULL: the same XYZ bit for bit as with map buffers, on the fused kernel (which then
+    stores no maps: poisoned guard words either side of the XYZ stay put), on the two-kernel path (maps in scratch) and batched."""
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
+    ctx.set_calibration(*bench.calibration(W, H, pw, ph))
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_physical_dev(stack.ptr, px, N, H, W, (pw, ph), seed=5, noise=2)
+    maps, ref, got = ctx.alloc(px * 4), ctx.alloc(px * 12), ctx.alloc(px * 12 + 512)
+    for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT, _native.TRI_EXACT):
+        ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), ref.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+        with_maps = ctx.last_scan_path()["path"]
+        ctx.dev_memset(got.ptr, 0x5a, px * 12 + 512)
+        ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), got.ptr + 256, None, None, None, mode=mode)
+        assert ctx.last_scan_path()["path"] == with_maps == ("fused" if mode == _native.TRI_ALGEBRAIC else "split")
+        ctx.synchronize()
+        a, b = ref.download((px, 3), np.float32), got.download((px, 3), np.float32, 256)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), mode
+        assert np.isfinite(a[:, 2]).sum() > px // 50
+        assert (got.download((256,), np.uint8) == 0x5a).all() and (got.download((256,), np.uint8, 256 + px * 12) == 0x5a).all()
+    if px % 512 == 0:
+        B = 3
+        stacks, bx, bx2, bm = ctx.alloc(B * N * px), ctx.alloc(B * px * 12), ctx.alloc(B * px * 12), ctx.alloc(B * px * 4)
+        for s in range(B):
+            ctx.synth_physical_dev(stacks.at(s * N * px), px, N, H, W, (pw, ph), seed=9 + s, noise=2)
+        ctx.scan_batch_dev(stacks.ptr, B, N * px, px, N, H, W, 0, (pw, ph), bx.ptr, bm.at(0), bm.at(B * px * 2))
+        ctx.scan_batch_dev(stacks.ptr, B, N * px, px, N, H, W, 0, (pw, ph), bx2.ptr)
+        assert ctx.last_scan_path()["path"] == "batch-fused"
+        ctx.synchronize()
+        assert np.array_equal(bx.download((B * px * 3,), np.uint32), bx2.download((B * px * 3,), np.uint32))
+        for b_ in (stacks, bx, bx2, bm):
+            b_.free()
+    for b_ in (stack, maps, ref, got):
+        b_.free()
+
+
 @pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "ragged", "ragged4"])
 def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     """slgc_cloud_dev: decode kernel, then the x-major list build with the triangulation INSIDE it (no dense XYZ round trip) -- the lists of
