@@ -287,6 +287,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     ctx->lut_nodes_err = -1.0f;
+    ctx->tune_lists_lines = xcd_env("SLGC_LISTS_LINES", 1);
     ctx->tune_lists_order = xcd_env("SLGC_LISTS_ORDER", 1);     // column-major: 217.6 -> 205.6 us at 4096x3000 (gpurun_out/r3g), neutral at the smaller sizes
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -342,6 +343,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "lists_lines")) ctx->tune_lists_lines = value != 0;
     else if (!strcmp(name, "lists_order")) ctx->tune_lists_order = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
@@ -362,6 +364,8 @@ extern "C" int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_tabl
     if (guard) *guard = ctx->last_guard;
     return ctx->last_scan_path;
 }
+
+extern "C" int slgc_last_list_kernel(slgc_ctx *ctx) { return ctx ? ctx->last_list_kernel : SLGC_EINVAL; }
 
 extern "C" int slgc_synchronize(slgc_ctx *ctx)
 {

@@ -406,6 +406,233 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
     }
 }
 
+// ---- x-major: pass C', the scatter of slgc_cloud_dev that writes WHOLE 128-byte lines ----
+// What bounds k_xmajor_scatter is not the bytes but their shape: a tile's run of a column starts and ends on arbitrary 8-byte boundaries, and
+// MI355X takes lines that arrive in two pieces from two workgroups at 3.6 TB/s where whole aligned lines go at 5.2-5.7 TB/s, 8 interleaved
+// streams included (tools/ubench/write_patterns.hip, patterns H / I).  Here the unit of output is the GROUP = 16 consecutive records of the
+// x-major order, aligned on the ABSOLUTE record index: 128 bytes of cam_pts, of proj_pts and of each plane of Pts, 384 bytes of colours.
+//   A workgroup loads 64 rows of its 64 columns: its 32 NOMINAL rows (the tile of k_xmajor_scatter) and the 32 rows below (the next tile's).
+//   Per column it OWNS the groups whose first record (of that column) lies in its nominal rows and writes every record of them it can see
+//   -- the group that straddles the seam is completed from the rows below instead of being left half-written.  The records at the head of
+//   its nominal rows that belong to a group begun in the tile above are that tile's business (it sees them); only when the group began even
+//   earlier (fewer than 16 valid pixels in 32 rows: sparse columns) does a tile write its own records of a foreign group, as a partial line
+//   like before.  Every record is written exactly once, by a rule each tile evaluates from the same per-chunk prefix counts.
+//   A half-wave takes one column: ballots rank the valid pixels of the 64 rows, their row numbers go into a 64-byte list in LDS, and lane r
+//   of pass p handles record (first group start) + 32 p + r -- whichever row that is: the tile sits in LDS, any row is one read away.  So every
+//   store instruction covers an aligned window of the output, full except at column ends and in sparse columns.
+// Costs: the maps / white image / camera nodes are read twice (+ 0.16 GB at 4096x3000), the points are still triangulated once.
+constexpr int kLinesRows = 64, kLinesNominal = 32;
+static_assert(kLinesNominal == kChunkRows, "the nominal rows of a tile are one chunk of the prefix counts");
+
+template <bool NODES>
+__global__ void __launch_bounds__(kScatterThreads, 4)
+k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int W, int H, int proj_w, int proj_h, const uint8_t *__restrict__ white,
+               const unsigned *__restrict__ counts, const unsigned long long *__restrict__ colstart, float *__restrict__ cam, float *__restrict__ proj,
+               double *__restrict__ colors, double *__restrict__ pts, const unsigned long long *__restrict__ total, int tiles_x, const TriScatter ts,
+               int tiles_y, int order, int abl)
+{
+    constexpr int TC = 64, TR = kLinesRows, NR = kLinesNominal, WD = 3 * TC / 4, NN = 19;
+    constexpr int NMP = TR * TC / 2 / kScatterThreads;                  // column pairs of each map per thread (4)
+    constexpr int NW = TR * WD / kScatterThreads;                       // white dwords per thread (6)
+    constexpr int NQ = (TR * NN + kScatterThreads - 1) / kScatterThreads;
+    __shared__ unsigned s_hv[TR][TC + 1];
+    __shared__ unsigned s_white[TR][WD + 1];
+    __shared__ float2 s_cam[NODES ? TR : 1][NODES ? NN + 2 : 1];        // nodes x_tile / 4 - 1 .. + 17 of every row (21 float2 per row: rows 16 apart share banks)
+    __shared__ unsigned s_b0[TC], s_bprev[TC], s_cs[TC];               // record indices fit 32 bits (the launcher checks the image size)
+    __shared__ uint8_t s_list[TC][TR];                                  // per column: the rows of its valid pixels, in rank order
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t tile = blockIdx.x;
+    if (order == 2) tile = xcd_block(blockIdx.x, gridDim.x / 8u);
+    const int tx = order ? (int)(tile / (unsigned)tiles_y) : (int)(tile % (unsigned)tiles_x);
+    const int ty = order ? (int)(tile % (unsigned)tiles_y) : (int)(tile / (unsigned)tiles_x);
+    const int x_tile = tx * TC, y_tile = ty * NR;
+    const int cols = min(TC, W - x_tile);
+    const unsigned npix = (unsigned)W * (unsigned)H;
+    const unsigned M = (unsigned)*total;
+    // every address below = a workgroup-uniform base + a 32-bit byte offset (scalar base, one vector add per access)
+    const unsigned tile0 = (unsigned)y_tile * (unsigned)W + (unsigned)x_tile;                       // first pixel of the tile
+    const char *h_t = reinterpret_cast<const char *>(h + tile0), *v_t = reinterpret_cast<const char *>(v + tile0);
+    const char *w_t = reinterpret_cast<const char *>(white) + 3 * (size_t)tile0;
+    const int rows_in = H - 1 - y_tile;                                                              // last row of the image, relative to the tile
+
+    // Phase 1: every load unconditional on a clamped address and in flight before the first LDS store (W % 4 == 0: column pairs and the
+    // white bytes of a tile row are dword aligned)
+    unsigned hq[NMP], vq[NMP], wq[NW];
+    float2 cq[NODES ? NQ : 1];
+#pragma unroll
+    for (int q = 0; q < NMP; ++q) {
+        const int i = q * kScatterThreads + tid, row = i / (TC / 2), cp = i % (TC / 2);
+        const unsigned e = min((unsigned)min(row, rows_in) * (unsigned)W + 2u * cp, npix - 2u - tile0);
+        hq[q] = *reinterpret_cast<const unsigned *>(h_t + 2u * e);
+        vq[q] = *reinterpret_cast<const unsigned *>(v_t + 2u * e);
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) wq[q] = 0u;
+    if (colors) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int i = q * kScatterThreads + tid, row = i / WD, d = i % WD;
+            wq[q] = *reinterpret_cast<const unsigned *>(w_t + min(3u * (unsigned)min(row, rows_in) * (unsigned)W + 4u * d, 3u * (npix - tile0) - 4u));
+        }
+    }
+    if constexpr (NODES) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = min(q * kScatterThreads + tid, TR * NN - 1), row = i / NN, n = i % NN;
+            cq[q] = ts.cn.nodes[(unsigned)min(y_tile + row, H - 1) * ts.cn.ne + min((uint32_t)(x_tile / 4 + n), ts.cn.ne - 1u)];
+        }
+    }
+    unsigned b0 = 0, bprev = 0, cs = 0;
+    if (tid < TC) {
+        const unsigned xb = (unsigned)min(x_tile + tid, W - 1);
+        cs = (unsigned)colstart[xb];
+        b0 = cs + counts[(unsigned)ty * (unsigned)W + xb];
+        bprev = ty > 0 ? cs + counts[(unsigned)(ty - 1) * (unsigned)W + xb] : b0;
+    }
+#pragma unroll
+    for (int q = 0; q < NMP; ++q) {
+        const int i = q * kScatterThreads + tid, row = i / (TC / 2), cp = i % (TC / 2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = 2 * cp + k;
+            const int hv = (int)(short)(hq[q] >> (16 * k)), vv = (int)(short)(vq[q] >> (16 * k));
+            const bool ok = col < cols && y_tile + row < H && decodable(hv, vv);
+            const int pu = min(hv, proj_w - 1), pv = min(vv, proj_h - 1);                // triangulate.py:60-61
+            s_hv[row][col] = ok ? ((unsigned)pu & 0xffffu) | ((unsigned)pv << 16) : kInvalidHV;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const int i = q * kScatterThreads + tid;
+        s_white[i / WD][i % WD] = wq[q];
+    }
+    if constexpr (NODES) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = q * kScatterThreads + tid;
+            if (i < TR * NN) s_cam[i / NN][i % NN] = cq[q];
+        }
+    }
+    if (tid < TC) {
+        s_b0[tid] = b0;
+        s_bprev[tid] = bprev;
+        s_cs[tid] = cs;
+    }
+    __syncthreads();
+
+    // Phase 2
+    const int half = lane >> 5, r = lane & 31, hw = tid >> 5;
+    constexpr int CPH = TC / 16;                                   // columns of a half-wave: c = hw + 16 j
+    int rec_of[3], ch_of[3];                                       // colour double 32 q + r of a pass = channel ch_of[q] of its record rec_of[q]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        rec_of[q] = (32 * q + r) / 3;
+        ch_of[q] = (32 * q + r) % 3;
+    }
+    // (a) per column: rank the valid pixels of the 64 rows into the list, and which records [ka, kb) (as ranks inside that list; absolute
+    //     index = B0 + rank) this tile writes -- the rule above; kA = the 16-aligned start of the window the passes walk (may be negative)
+    int win[CPH];                                                  // (kA + 16) | ka << 8 | kb << 16
+#pragma unroll
+    for (int j = 0; j < CPH; ++j) {
+        const int c = hw + 16 * j;
+        const bool ok1 = s_hv[r][c] != kInvalidHV, ok2 = s_hv[NR + r][c] != kInvalidHV;
+        const unsigned long long m1 = __ballot(ok1), m2 = __ballot(ok2);
+        const unsigned mh1 = (unsigned)(half ? (m1 >> 32) : m1), mh2 = (unsigned)(half ? (m2 >> 32) : m2), below = (1u << r) - 1u;
+        const int n1 = __popc(mh1), n2 = __popc(mh2);
+        if (ok1) s_list[c][__popc(mh1 & below)] = (uint8_t)r;
+        if (ok2) s_list[c][n1 + __popc(mh2 & below)] = (uint8_t)(NR + r);
+        const unsigned B0 = s_b0[c], Bp = s_bprev[c], S = max(B0 & ~15u, s_cs[c]);                  // S = first record (of this column) of the group B0 is in
+        const int phase = (int)(B0 & 15u), to_next = 16 - phase;                                     // records left in that group
+        const int head_end = min(to_next, n1);
+        int ka = 0;
+        if (S != B0 && ty > 0 && S >= Bp) ka = head_end;           // the tile above began that group and sees these rows: its records
+        const bool owns = n1 > 0 && (S == B0 || to_next < n1);
+        const int kb = c >= cols ? ka : owns ? min(((phase + n1 - 1) & ~15) + 16 - phase, n1 + n2) : head_end;
+        const int kA = ((phase + ka) & ~15) - phase;
+        win[j] = (kA + 16) | (ka << 8) | (kb << 16);
+    }
+    wave_lds_sync();                                               // every list is written and read by one wave only
+    // (b) first pass of every column: whichever rows its records are, and their projector rays requested -- all CPH gathers in flight together
+    int rowk[CPH];
+    float2 prj[CPH];
+#pragma unroll
+    for (int j = 0; j < CPH; ++j) {
+        const int c = hw + 16 * j, k = (win[j] & 0xff) - 16 + r;
+        const bool act = k >= ((win[j] >> 8) & 0xff) && k < (win[j] >> 16);
+        const int row = s_list[c][min(max(k, 0), TR - 1)];
+        const unsigned hv = s_hv[row][c];
+        rowk[j] = act ? row : -1;
+        prj[j] = ts.proj_lut[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+    }
+    // (c) one record per lane and pass
+    char *const cam_b = reinterpret_cast<char *>(cam), *const proj_b = reinterpret_cast<char *>(proj), *const col_b = reinterpret_cast<char *>(colors);
+    char *const p0_b = reinterpret_cast<char *>(pts), *const p1_b = reinterpret_cast<char *>(pts + M), *const p2_b = reinterpret_cast<char *>(pts + 2 * (size_t)M);
+    auto emit = [&](int c, int kp, int ka, int kb, int row, float2 pr) {
+        const int x = x_tile + c;
+        const unsigned B0 = s_b0[c];
+        if (row >= 0) {
+            const unsigned o8 = (B0 + (unsigned)(kp + r)) * 8u;                                      // byte offset of the record in the 8-byte streams
+            const unsigned hv = s_hv[row][c];
+            const int pu = (int)(short)(hv & 0xffffu), pv = (int)(short)(hv >> 16);
+            const unsigned pix = (unsigned)(y_tile + row) * (unsigned)W + (unsigned)x;
+            float cxr, cyr;
+            if constexpr (NODES) {
+                const int g = c >> 2;
+                const float2 n0 = s_cam[row][g], n1_ = s_cam[row][g + 1], n2_ = s_cam[row][g + 2], n3 = s_cam[row][g + 3];
+                float fx[4], fy[4];
+                cam_rays_from_nodes(cam_v4f{n0.x, n0.y, n1_.x, n1_.y}, cam_v4f{n2_.x, n2_.y, n3.x, n3.y}, fx, fy);
+                cam_rays_exact_where_tiny(fx, fy, ts.cam_lut + (pix - (unsigned)(c & 3)));            // the group's decision, like the lane that owns it in the scan kernels
+                const int jj = c & 3;
+                cxr = jj == 0 ? fx[0] : jj == 1 ? fx[1] : jj == 2 ? fx[2] : fx[3];
+                cyr = jj == 0 ? fy[0] : jj == 1 ? fy[1] : jj == 2 ? fy[2] : fy[3];
+            } else {
+                const float2 cr = ts.cam_lut[pix];
+                cxr = cr.x;
+                cyr = cr.y;
+            }
+            if (cam && !LISTS_ABL(1)) {
+                *reinterpret_cast<float2 *>(cam_b + o8) = make_float2((float)x, (float)(y_tile + row));          // :59 [i, j] = (x, y)
+                *reinterpret_cast<float2 *>(proj_b + o8) = make_float2((float)pu, (float)pv);
+            }
+            const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix);
+            if (!LISTS_ABL(2)) {
+                *reinterpret_cast<double *>(p0_b + o8) = (double)r3.x;                                          // Pts (3,M) float64, :95
+                *reinterpret_cast<double *>(p1_b + o8) = (double)r3.y;
+                *reinterpret_cast<double *>(p2_b + o8) = (double)r3.z;
+            } else if (r3.x == 12345.678f) {
+                *reinterpret_cast<double *>(p0_b + o8) = 0.0;
+            }
+        }
+        if (colors && !LISTS_ABL(4)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int kc = kp + rec_of[q];
+                if (kc >= ka && kc < kb) {
+                    const int rowc = s_list[c][min(max(kc, 0), TR - 1)];
+                    const unsigned byte = reinterpret_cast<const uint8_t *>(&s_white[rowc][0])[3 * c + ch_of[q]];
+                    *reinterpret_cast<double *>(col_b + ((B0 + (unsigned)kp) * 24u + (unsigned)(32 * q + r) * 8u)) = unit_of_byte(byte);          // :64, :69
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < CPH; ++j) emit(hw + 16 * j, (win[j] & 0xff) - 16, (win[j] >> 8) & 0xff, win[j] >> 16, rowk[j], prj[j]);
+    // (d) the windows longer than 32 records (a column segment that owns three groups, or two behind a partial head): further passes
+#pragma unroll 1
+    for (int j = 0; j < CPH; ++j) {
+        const int c = hw + 16 * j, ka = (win[j] >> 8) & 0xff, kb = win[j] >> 16;
+#pragma unroll 1
+        for (int kp = (win[j] & 0xff) + 16; __any(kp < kb); kp += 32) {
+            const int k = kp + r;
+            const bool act = k >= ka && k < kb;
+            const int row = s_list[c][min(max(k, 0), TR - 1)];
+            const unsigned hv = s_hv[row][c];
+            const float2 pr = ts.proj_lut[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+            emit(c, kp, ka, kb, act ? row : -1, pr);
+        }
+    }
+}
+
 // ---- row-major stream compaction framework ----
 // Tile = 1024 consecutive elements per 256-thread workgroup (4 per lane, lane-interleaved so loads coalesce).
 constexpr int kTile = 1024;
@@ -609,6 +836,24 @@ int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int
         hipLaunchKernelGGL(k_xmajor_colprefix, dim3(groups_x), dim3(64 * kPrefixGroups), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
                            (unsigned long long *)colstart);
     hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
+    if constexpr (SRC == 2 && sizeof(MapT) == 2 && TC == 64) {
+        // slgc_cloud_dev's scatter in whole 128-byte lines (k_xmajor_lines) when the shape allows its dword loads; "lists_lines" 0 = the older kernel (A/B)
+        if (npix >= 4 && npix <= ((size_t)1 << 27) && ctx->tune_lists_lines && cam_w % 4 == 0 && (!d_colors || (uintptr_t)d_white % 4 == 0) && ((uintptr_t)d_h | (uintptr_t)d_v) % 4 == 0) {
+            const int tiles_x = (cam_w + 63) / 64, tiles_y = (cam_h + kLinesNominal - 1) / kLinesNominal;
+            if (ts.cn.nodes)
+                hipLaunchKernelGGL((k_xmajor_lines<true>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w, cam_h,
+                                   proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_colors, d_pts,
+                                   (const unsigned long long *)d_total, tiles_x, ts, tiles_y, ctx->tune_lists_order, lists_abl());
+            else
+                hipLaunchKernelGGL((k_xmajor_lines<false>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w, cam_h,
+                                   proj_w, proj_h, d_white, (const unsigned *)counts, (const unsigned long long *)colstart, d_cam, d_proj, d_colors, d_pts,
+                                   (const unsigned long long *)d_total, tiles_x, ts, tiles_y, ctx->tune_lists_order, lists_abl());
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->last_list_kernel = SLGC_LISTS_WHOLE_LINES;
+            return SLGC_OK;
+        }
+    }
+    ctx->last_list_kernel = SLGC_LISTS_TILE_RUNS;
     if (npix) {
         const int tiles_x = (cam_w + TC - 1) / TC, tiles_y = (cam_h + TR - 1) / TR;
         hipLaunchKernelGGL((k_xmajor_scatter<MapT, SRC, TC>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w,

@@ -57,6 +57,7 @@ struct slgc_ctx {
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel
     int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
+    int tune_lists_lines;   // slgc_cloud_dev's scatter: 1 = k_xmajor_lines (whole 128-byte lines, default), 0 = k_xmajor_scatter<.., 2, ..> (A/B)
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_image_rows;    // height of the whole image a band belongs to (0 = the band IS the image): the node-table decision (size and accuracy) is taken
@@ -66,6 +67,7 @@ struct slgc_ctx {
     int last_ns;            // frames-per-run specialisation of the decode / fused kernel (42 / 44 / 46), 0 = generic kernel
     int last_nodes;         // 1 = the triangulation read the camera node table, 0 = the per-pixel table (or evaluated the rays per pixel)
     int last_guard;         // 1 = float32 fast form with the flat-triangle guard, 0 = exact (acos / sin) mode, -1 = unguarded (diagnostic build only)
+    int last_list_kernel;   // SLGC_LISTS_*: which scatter the last x-major list build launched
     int last_ragged;        // 1 = a byte-wide / per-pixel fallback kernel took part (misaligned buffers, ragged tails)
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)

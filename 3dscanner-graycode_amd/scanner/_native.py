@@ -40,6 +40,7 @@ SIGNATURES = {
     "slgc_synchronize": (_i, [_vp]),
     "slgc_last_input_path": (_i, [_vp]),
     "slgc_last_scan_path": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "slgc_last_list_kernel": (_i, [_vp]),
     "slgc_tune": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_pci_bus_id": (_i, [_vp, C.c_char_p, _i]),
@@ -342,6 +343,15 @@ class Context:
         if rc < 0:
             self._ck(rc)
         return {"path": self.SCAN_PATHS.get(rc, str(rc)), "ns_frames": int(ns.value), "node_table": bool(nodes.value), "guard": guard.value == 1}
+
+    LIST_KERNELS = {0: "none", 1: "tile-runs", 2: "whole-lines"}
+
+    def last_list_kernel(self) -> str:
+        """Which scatter the last x-major list build launched (slgc_last_list_kernel): "tile-runs" | "whole-lines" | "none"."""
+        rc = lib().slgc_last_list_kernel(self._h)
+        if rc < 0:
+            self._ck(rc)
+        return self.LIST_KERNELS.get(rc, str(rc))
 
     def dev_memset(self, dptr: int, value: int, nbytes: int):
         self._ck(lib().slgc_dev_memset(self._h, dptr, int(value), int(nbytes)))

@@ -954,6 +954,7 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
     el_points = run(via_cloud_points)
     el = run(via_cloud)
     executed = ctx.last_scan_path()
+    list_kernel = ctx.last_list_kernel()
     M = lists.total()
     # the list stage alone: decode once, then K list builds back to back (maps stay in place)
     ctx.decode_dev(stacks[0].ptr, 1, N * plane, plane, N, rows, W, maps.at(0), maps.at(band_px * 2))
@@ -962,12 +963,13 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
         ctx.cloud_lists_dev(maps.at(0), maps.at(band_px * 2), None, white.ptr, W, rows, proj_size, lists)      # d_xyz = None: triangulate in-kernel
     ctx.event_record(3)
     stage_ms = ctx.event_elapsed_ms(2, 3) / K
-    # bytes of the list stage: maps read twice (count + scatter) 8, camera rays 2 (node table) or 8 (per-pixel table), white 3 per pixel
-    # in; 8 + 8 + 24 + 24 per valid pixel out
+    # ALGORITHMIC bytes of the list stage: maps read twice (count + scatter) 8, camera rays 2 (node table) or 8 (per-pixel table), white 3 per
+    # pixel in; 8 + 8 + 24 + 24 per valid pixel out.  (The whole-lines scatter reads every tile's maps / white bytes / nodes a second time as
+    # the halo of the tile above: not counted here.)
     ray_b = 2 if executed["node_table"] else 8
     stage_bytes = band_px * (8 + ray_b + 3) + M * 64
     out = {"value": round(band_px / 1e6 * K / el, 1), "unit": "Mpixels/s", "ms_per_scan": round(el / K * 1e3, 4), "steps": K, "points": int(M),
-           "executed": executed,
+           "executed": {**executed, "list_kernel": list_kernel},
            "list_stage_ms": round(stage_ms, 4), "list_stage_bytes": int(stage_bytes),
            "list_stage_roofline": {"bound": "hbm", "achieved": round(stage_bytes / (stage_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -977,7 +979,7 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
            "via_dense_xyz": {"value": round(band_px / 1e6 * K / el_dense, 1), "ms_per_scan": round(el_dense / K * 1e3, 4),
                              "note": "round 2's route: fused scan (writes 12 B/pixel of dense XYZ) + slgc_cloud_lists_dev (reads it back)"},
            "note": "slgc_cloud_dev: decode kernel + x-major list build (count, column prefix, LDS-transposed scatter that triangulates each valid "
-                   "pixel in-kernel and folds in the colour gather and the float64 (3,M) points); everything stays in HBM, no dense XYZ; "
+                   "pixel in-kernel, folds in the colour gather and the float64 (3,M) points and writes whole aligned 128-byte lines); everything stays in HBM, no dense XYZ; "
                    "list_stage_ms = the list build alone, mean of %d back-to-back builds" % K}
     white.free()
     lists.free()

@@ -399,6 +399,7 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, lists, d_h=maps.at(0), d_v=maps.at(voff))
     path = ctx.last_scan_path()
     assert path["path"] == "cloud" and path["node_table"] == (W * H * 8 > 64 << 20 and W % 4 == 0)
+    assert ctx.last_list_kernel() == ("whole-lines" if W % 4 == 0 else "tile-runs")
     cam, proj, pts, col = lists.download()
     h = maps.download((H, W), np.int16).astype(np.int64)
     v = maps.download((H, W), np.int16, voff).astype(np.int64)
@@ -438,3 +439,76 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
         b.free()
     lists.free()
     bare.free()
+
+
+LINE_CASES = [
+    # (W, H, how the validity mask is made)
+    (256, 200, "density 0.0"), (256, 200, "density 0.01"), (256, 200, "density 0.1"), (256, 200, "density 0.5"), (256, 200, "density 0.97"),
+    (256, 200, "density 1.0"), (128, 3000, "density 0.8"), (332, 77, "density 0.8"), (64, 33, "density 0.9"), (4, 1, "density 1.0"),
+    (256, 200, "rows 31 32"), (256, 200, "every 40th row"), (256, 200, "one column"), (256, 200, "checkerboard"), (256, 200, "bands"),
+    (1920, 1080, "density 0.85"),
+]
+
+
+@pytest.mark.parametrize("W,H,how", LINE_CASES)
+def test_list_build_in_whole_lines_equals_tile_runs(ctx, W, H, how):
+    """The x-major list build of slgc_cloud_dev exists twice: k_xmajor_scatter (a tile writes its own run of every column) and k_xmajor_lines
+    (a tile writes whole 16-record groups, completing the group that straddles the seam from the rows below; sparse columns fall back to
+    partial writes by a per-column rule).  Same four arrays bit for bit on hand-made maps of every density -- empty, a few pixels per
+    column (every record an orphan of a group begun tiles earlier), half, nearly all, all -- and on structured masks that put a column's
+    records exactly at tile seams; the lists against the oracle too, and nothing written past the M-th record."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((W, H, how)).encode()))
+    pw, ph = 300, 200
+    K = np.array([[300.0, 0, W / 2], [0, 300.0, H / 2], [0, 0, 1]])
+    _, cd, pk, pd, R, T = bench.calibration(1920, 1080, pw, ph)
+    ctx.set_calibration(K, cd, pk, pd, R, T)
+    ctx.tune("cam_nodes", 2 if W % 4 == 0 else 1)                              # node table wherever it is accurate: both kernel variants get exercised
+    yy, xx = np.mgrid[0:H, 0:W]
+    if how.startswith("density"):
+        mask = rng.random((H, W)) < float(how.split()[1])
+    elif how == "rows 31 32":
+        mask = (yy == 31) | (yy == 32)
+    elif how == "every 40th row":
+        mask = yy % 40 == 7
+    elif how == "one column":
+        mask = xx == 67
+    elif how == "checkerboard":
+        mask = (xx + yy) % 2 == 0
+    else:                                                                       # dense bands of 48 rows between empty bands of 30
+        mask = (yy % 78) < 48
+    h = np.where(mask, rng.integers(0, pw + 20, (H, W)), -1).astype(np.int16)   # a few codes past the projector: clamped (triangulate.py:60-61)
+    v = np.where(mask, rng.integers(0, ph + 20, (H, W)), -1).astype(np.int16)
+    half = rng.random((H, W)) < 0.02                                            # and pixels where only one map decoded
+    h[half & (xx % 2 == 0)] = -1
+    v[half & (xx % 2 == 1)] = -1
+    px = W * H
+    white_h = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    dh, dv, white = ctx.alloc(max(16, px * 2)).upload(h), ctx.alloc(max(16, px * 2)).upload(v), ctx.alloc(max(16, px * 3)).upload(white_h)
+    ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
+    got = {}
+    for lines in (0, 1):
+        ctx.tune("lists_lines", lines)
+        L = ctx.alloc_cloud_lists(px, colors=True)
+        for buf, nbytes in ((L.cam, px * 8), (L.proj, px * 8), (L.pts, px * 24), (L.colors, px * 24)):
+            ctx.dev_memset(buf.ptr, 0xA5, max(16, nbytes))
+        ctx.cloud_lists_dev(dh.ptr, dv.ptr, None, white.ptr, W, H, (pw, ph), L)
+        assert ctx.last_list_kernel() == ("whole-lines" if lines and W % 4 == 0 and px >= 4 else "tile-runs")
+        M = L.total()
+        raw = {"cam": L.cam.download((px, 2), np.float32), "proj": L.proj.download((px, 2), np.float32), "col": L.colors.download((px, 3), np.float64)}
+        for name, a in raw.items():
+            assert (a[M:].view(np.uint8) == 0xA5).all(), (lines, name)
+        planes = L.pts.download((3 * px,), np.float64)
+        assert (planes[3 * M:].view(np.uint8) == 0xA5).all(), lines
+        got[lines] = L.download()
+        L.free()
+    ctx.tune("lists_lines", 1)
+    rcam, rproj, rcol = oc.cam_proj_pts(h.astype(np.int64), v.astype(np.int64), (W, H), (pw, ph), white_h, order="x")
+    assert len(rcam) == int(((h != -1) & (v != -1)).sum())
+    for a, b, name in zip(got[1], got[0], ("cam", "proj", "pts", "colours")):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+    assert np.array_equal(got[1][0], rcam) and np.array_equal(got[1][1], rproj) and np.array_equal(got[1][3], rcol)
+    if len(rcam):
+        assert np.isfinite(got[1][2]).any() or how == "density 0.0"
+    for b in (dh, dv, white):
+        b.free()

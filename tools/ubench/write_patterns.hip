@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) k_walk(double *out, size_t nruns, size_t 
 }
 // H: G0 with NS output streams (like cam / proj / 3 point planes / colours): a half-wave walks down its column and, per segment, writes the
 // run of every stream (BURST = 1), or writes BURST consecutive segments of one stream before it turns to the next stream.
-template <int NS, int BURST>
+// ALIGNED: the runs start on multiples of their own length (phase 0: what a scatter that buffers whole lines per column would write)
+template <int NS, int BURST, bool ALIGNED = false>
 __global__ void __launch_bounds__(256) k_walk_streams(double *out, size_t nruns, size_t cols, int lanes_on)
 {
     const int hw = threadIdx.x >> 5, r = threadIdx.x & 31;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_walk_streams(double *out, size_t nruns,
         for (int st = 0; st < NS; ++st)
 #pragma unroll
             for (int k = 0; k < BURST; ++k)
-                if (r < lanes_on) out[st * stream_elems + col * per_col * 32 + (seg0 + k) * lanes_on + (col % 16) + r] = (double)seg0;
+                if (r < lanes_on) out[st * stream_elems + col * per_col * 32 + (seg0 + k) * lanes_on + (ALIGNED ? 0 : col % 16) + r] = (double)seg0;
 }
 __global__ void __launch_bounds__(256) k_runs4(float *out, size_t nruns, size_t cols)
 {
@@ -149,6 +150,10 @@ int main()
     timeit("H  as G0 with 8 streams, bursts of 4 segments (26 lanes)", TOTAL * 26 / 32, [&] { hipLaunchKernelGGL((k_walk_streams<8, 4>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 26); });
     timeit("H  as G0 with 1 stream (26 lanes)", TOTAL * 26 / 32, [&] { hipLaunchKernelGGL((k_walk_streams<1, 1>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 26); });
     timeit("H  as G0 with 8 streams, segment by segment (32 lanes)", TOTAL, [&] { hipLaunchKernelGGL((k_walk_streams<8, 1>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 32); });
+    timeit("I  as H, 8 streams, ALIGNED 256-B runs (32 lanes)", TOTAL, [&] { hipLaunchKernelGGL((k_walk_streams<8, 1, true>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 32); });
+    timeit("I  as H, 8 streams, ALIGNED 128-B runs (16 lanes)", TOTAL / 2, [&] { hipLaunchKernelGGL((k_walk_streams<8, 1, true>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 16); });
+    timeit("I  as H, 1 stream, ALIGNED 256-B runs (32 lanes)", TOTAL, [&] { hipLaunchKernelGGL((k_walk_streams<1, 1, true>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 32); });
+    timeit("I  as H, 8 streams, ALIGNED 256-B runs, bursts of 4", TOTAL, [&] { hipLaunchKernelGGL((k_walk_streams<8, 4, true>), dim3(grid), dim3(256), 0, 0, (double *)buf, nruns, 4096ul, 32); });
     timeit("F  4 B/lane, aligned 128-B runs, 4096 columns", TOTAL / 2, [&] { hipLaunchKernelGGL(k_runs4, dim3(grid), dim3(256), 0, 0, (float *)buf, nruns, 4096ul); });
     CK(hipFree(buf));
     return 0;
