@@ -421,7 +421,9 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
 //   of pass p handles record (first group start) + 32 p + r -- whichever row that is: the tile sits in LDS, any row is one read away.  So every
 //   store instruction covers an aligned window of the output, full except at column ends and in sparse columns.
 // Costs: the maps / white image / camera nodes are read twice (+ 0.16 GB at 4096x3000), the points are still triangulated once.
-constexpr int kLinesRows = 64, kLinesNominal = 32;
+constexpr int kLinesRows = 64, kLinesNominal = 32;                   // rows loaded (nominal + halo), nominal rows
+static_assert(kLinesRows == 2 * kLinesNominal, "the ownership rule needs a tile to see ALL nominal rows of the tile below (a shorter halo gave 4 workgroups "
+                                               "per CU instead of 3 and the same time, 218 us, with wrong seams)");
 static_assert(kLinesNominal == kChunkRows, "the nominal rows of a tile are one chunk of the prefix counts");
 
 template <bool NODES>
@@ -432,8 +434,8 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
                int tiles_y, int order, int abl)
 {
     constexpr int TC = 64, TR = kLinesRows, NR = kLinesNominal, WD = 3 * TC / 4, NN = 19;
-    constexpr int NMP = TR * TC / 2 / kScatterThreads;                  // column pairs of each map per thread (4)
-    constexpr int NW = TR * WD / kScatterThreads;                       // white dwords per thread (6)
+    constexpr int NMP = (TR * TC / 2 + kScatterThreads - 1) / kScatterThreads;                  // column pairs of each map per thread (4)
+    constexpr int NW = (TR * WD + kScatterThreads - 1) / kScatterThreads;                       // white dwords per thread (6)
     constexpr int NQ = (TR * NN + kScatterThreads - 1) / kScatterThreads;
     __shared__ unsigned s_hv[TR][TC + 1];
     __shared__ unsigned s_white[TR][WD + 1];
@@ -443,6 +445,10 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t tile = blockIdx.x;
     if (order == 2) tile = xcd_block(blockIdx.x, gridDim.x / 8u);
+    if (order >= 3) {                                    // column-major, runs of `order` consecutive tiles on one XCD (workgroup ids go round-robin over the 8 XCDs):
+        const uint32_t R = (uint32_t)order, span = 8u * R, g = tile / span;             // a tile and the tile below it -- whose rows it also reads -- share an L2
+        if ((g + 1u) * span <= gridDim.x) tile = g * span + (tile % 8u) * R + (tile / 8u) % R;
+    }
     const int tx = order ? (int)(tile / (unsigned)tiles_y) : (int)(tile % (unsigned)tiles_x);
     const int ty = order ? (int)(tile % (unsigned)tiles_y) : (int)(tile / (unsigned)tiles_x);
     const int x_tile = tx * TC, y_tile = ty * NR;
@@ -461,7 +467,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
     float2 cq[NODES ? NQ : 1];
 #pragma unroll
     for (int q = 0; q < NMP; ++q) {
-        const int i = q * kScatterThreads + tid, row = i / (TC / 2), cp = i % (TC / 2);
+        const int i = min(q * kScatterThreads + tid, TR * TC / 2 - 1), row = i / (TC / 2), cp = i % (TC / 2);
         const unsigned e = min((unsigned)min(row, rows_in) * (unsigned)W + 2u * cp, npix - 2u - tile0);
         hq[q] = *reinterpret_cast<const unsigned *>(h_t + 2u * e);
         vq[q] = *reinterpret_cast<const unsigned *>(v_t + 2u * e);
@@ -471,7 +477,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
     if (colors) {
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
-            const int i = q * kScatterThreads + tid, row = i / WD, d = i % WD;
+            const int i = min(q * kScatterThreads + tid, TR * WD - 1), row = i / WD, d = i % WD;
             wq[q] = *reinterpret_cast<const unsigned *>(w_t + min(3u * (unsigned)min(row, rows_in) * (unsigned)W + 4u * d, 3u * (npix - tile0) - 4u));
         }
     }
@@ -492,6 +498,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
 #pragma unroll
     for (int q = 0; q < NMP; ++q) {
         const int i = q * kScatterThreads + tid, row = i / (TC / 2), cp = i % (TC / 2);
+        if (i < TR * TC / 2)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int col = 2 * cp + k;
@@ -504,7 +511,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const int i = q * kScatterThreads + tid;
-        s_white[i / WD][i % WD] = wq[q];
+        if (i < TR * WD) s_white[i / WD][i % WD] = wq[q];
     }
     if constexpr (NODES) {
 #pragma unroll
@@ -535,7 +542,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
 #pragma unroll
     for (int j = 0; j < CPH; ++j) {
         const int c = hw + 16 * j;
-        const bool ok1 = s_hv[r][c] != kInvalidHV, ok2 = s_hv[NR + r][c] != kInvalidHV;
+        const bool ok1 = s_hv[r][c] != kInvalidHV, ok2 = NR + r < TR && s_hv[min(NR + r, TR - 1)][c] != kInvalidHV;
         const unsigned long long m1 = __ballot(ok1), m2 = __ballot(ok2);
         const unsigned mh1 = (unsigned)(half ? (m1 >> 32) : m1), mh2 = (unsigned)(half ? (m2 >> 32) : m2), below = (1u << r) - 1u;
         const int n1 = __popc(mh1), n2 = __popc(mh2);
