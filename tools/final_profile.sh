@@ -24,8 +24,10 @@ python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '
 python3 bench.py --force-sharded --exchange records --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
 # the "next" rows, the list stage and the whole reference-shaped product under the kernel trace, the store-pattern microbenchmark
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_next" -- python3 tools/time_next_rows.py > "$out/next_rows.log" 2>&1
-LISTS_ROUTE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs lists_order=1 > "$out/lists.log" 2>&1
+LISTS_ROUTE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs lists_lines=1 > "$out/lists.log" 2>&1
 python3 tools/time_lists.py --knobs route=0,1 2>/dev/null | grep "list stage" > "$out/lists_plain.log"
+LISTS_ROUTE=1 python3 tools/time_lists.py --knobs lists_lines=0,1 2>/dev/null | grep "list stage" >> "$out/lists_plain.log"
+bash tools/jobs/pmc_lists.sh "$out/pmc_lists" > "$out/pmc_lists.log" 2>&1
 for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_cloud.py --workload $w 2>/dev/null | grep "per scan"; done > "$out/cloud.log"
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
 python3 tools/time_dropin.py 2>/dev/null | grep -E "^pass|^c3|^  " > "$out/dropin.log"

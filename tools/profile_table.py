@@ -34,9 +34,9 @@ print(f"fused 1920x1080x44 (physical): events avg {r2['avg_launch_ms'] * 1e3:.2f
 rp = j["reference_product"]
 ls = {x["Name"]: x for x in csv.DictReader(open(P("kernel_stats_list_stage.csv")))}
 find = lambda d, key: next(v for k, v in d.items() if key in k)   # noqa: E731
-sc, ct, pf, cs = find(ls, "xmajor_scatter"), find(ls, "xmajor_count"), find(ls, "colprefix"), find(ls, "colscan")
+sc, ct, pf, cs = find(ls, "xmajor_lines" if any("xmajor_lines" in k for k in ls) else "xmajor_scatter"), find(ls, "xmajor_count"), find(ls, "colprefix"), find(ls, "colscan")
 print(f"reference product: {rp['ms_per_scan']:.3f} ms per scan = {rp['value']:.0f} Mpix/s (dense route {rp['via_dense_xyz']['ms_per_scan']:.3f} ms); list stage {rp['list_stage_ms']:.3f} ms, "
-      f"{rp['list_stage_bytes'] / 1e6:.0f} MB -> {rp['list_stage_roofline']['frac']:.2f} | rocprof scatter {us(sc):.1f} (min {us(sc, 'MinNs'):.1f}) count {us(ct):.1f} prefix {us(pf):.1f} scan {us(cs):.1f} us ({sc['Calls']} builds)")
+      f"{rp['list_stage_bytes'] / 1e6:.0f} MB -> {rp['list_stage_roofline']['frac']:.2f}, {rp['executed'].get('list_kernel')} | rocprof scatter {us(sc):.1f} (min {us(sc, 'MinNs'):.1f}) count {us(ct):.1f} prefix {us(pf):.1f} scan {us(cs):.1f} us ({sc['Calls']} builds)")
 nx = {x["Name"]: x for x in csv.DictReader(open(P("kernel_stats_next_rows.csv")))}
 fd, bg = find(nx, "frame_diff"), find(nx, "bgr")
 print(f"next rows: k_frame_diff_u8x16 {us(fd):.1f} us ({541e6 / float(fd['AverageNs']) * 1e9 / 8e12:.2f}), k_bgr_to_gray {us(bg):.1f} us ({196.6e6 / float(bg['AverageNs']) * 1e9 / 8e12:.2f})")
