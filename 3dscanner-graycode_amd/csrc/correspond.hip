@@ -844,8 +844,11 @@ int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int
                            (unsigned long long *)colstart);
     hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
     if constexpr (SRC == 2 && sizeof(MapT) == 2 && TC == 64) {
-        // slgc_cloud_dev's scatter in whole 128-byte lines (k_xmajor_lines) when the shape allows its dword loads; "lists_lines" 0 = the older kernel (A/B)
-        if (npix >= 4 && npix <= ((size_t)1 << 27) && ctx->tune_lists_lines && cam_w % 4 == 0 && (!d_colors || (uintptr_t)d_white % 4 == 0) && ((uintptr_t)d_h | (uintptr_t)d_v) % 4 == 0) {
+        // slgc_cloud_dev's scatter in whole 128-byte lines (k_xmajor_lines) when the shape allows its dword loads; "lists_lines" 0 = the tile-run kernel (A/B)
+        // ("lists_lines" 1 = where it pays: the tile-run kernel is the faster one while the image is only one or two rounds of resident workgroups --
+        //  1280x720: 35.5 vs 41.0 us per scan, 1920x1080: 58.5 vs 61.8, 4096x3000: 383 vs 306; 2 = wherever the shape allows)
+        const bool big = (size_t)((cam_w + 63) / 64) * (size_t)((cam_h + kLinesNominal - 1) / kLinesNominal) >= 2048;
+        if (npix >= 4 && npix <= ((size_t)1 << 27) && (ctx->tune_lists_lines == 2 || (ctx->tune_lists_lines == 1 && big)) && cam_w % 4 == 0 && (!d_colors || (uintptr_t)d_white % 4 == 0) && ((uintptr_t)d_h | (uintptr_t)d_v) % 4 == 0) {
             const int tiles_x = (cam_w + 63) / 64, tiles_y = (cam_h + kLinesNominal - 1) / kLinesNominal;
             if (ts.cn.nodes)
                 hipLaunchKernelGGL((k_xmajor_lines<true>), dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(kScatterThreads), 0, ctx->stream, d_h, d_v, cam_w, cam_h,

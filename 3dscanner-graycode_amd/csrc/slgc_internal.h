@@ -57,7 +57,7 @@ struct slgc_ctx {
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel
     int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
-    int tune_lists_lines;   // slgc_cloud_dev's scatter: 1 = k_xmajor_lines (whole 128-byte lines, default), 0 = k_xmajor_scatter<.., 2, ..> (A/B)
+    int tune_lists_lines;   // slgc_cloud_dev's scatter: 1 = k_xmajor_lines (whole 128-byte lines) for images of >= 2048 tiles (default), 2 = wherever the shape allows, 0 = k_xmajor_scatter<.., 2, ..>
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_image_rows;    // height of the whole image a band belongs to (0 = the band IS the image): the node-table decision (size and accuracy) is taken

@@ -75,7 +75,8 @@ int slgc_synchronize(slgc_ctx *ctx);
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
  * "lists_order" = workgroup -> tile order of the x-major list build: 1 column-major (default: a column's run continues in the tile below, so
  * the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000), 0 row-major, 2 column-major inside each XCD (no better).
- * "lists_lines" 1 (default) = slgc_cloud_dev's list build writes whole aligned 128-byte lines (k_xmajor_lines; see slgc_last_list_kernel) / 0 = tile runs (A/B).
+ * "lists_lines" 1 (default) = slgc_cloud_dev's list build writes whole aligned 128-byte lines (k_xmajor_lines; see slgc_last_list_kernel) for images of at
+ * least 2048 tiles of 64 x 32 pixels (below that the tile-run kernel is the faster one) / 2 = wherever the shape allows / 0 = tile runs (A/B).
  * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
  * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
  * scan its bands (0, the default: the band is the image).
@@ -106,7 +107,7 @@ int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *gua
 /* Which scatter kernel the last x-major list build on this context (slgc_cloud_dev, slgc_cloud_lists_dev, slgc_correspond with
  * SLGC_ORDER_X) launched: SLGC_LISTS_TILE_RUNS = a tile writes its own run of every column (any shape, any map type);
  * SLGC_LISTS_WHOLE_LINES = slgc_cloud_dev's form that writes whole 16-record groups = aligned 128-byte lines (int16 maps, W % 4 == 0,
- * 4-byte aligned maps and white image, at most 2^27 pixels; slgc_tune "lists_lines" 0 switches it off).  Same arrays either way. */
+ * 4-byte aligned maps and white image, 2048 tiles ... 2^27 pixels; slgc_tune "lists_lines").  Same arrays either way. */
 enum { SLGC_LISTS_NONE = 0, SLGC_LISTS_TILE_RUNS = 1, SLGC_LISTS_WHOLE_LINES = 2 };
 int slgc_last_list_kernel(slgc_ctx *ctx);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);

@@ -399,7 +399,7 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, lists, d_h=maps.at(0), d_v=maps.at(voff))
     path = ctx.last_scan_path()
     assert path["path"] == "cloud" and path["node_table"] == (W * H * 8 > 64 << 20 and W % 4 == 0)
-    assert ctx.last_list_kernel() == ("whole-lines" if W % 4 == 0 else "tile-runs")
+    assert ctx.last_list_kernel() == ("whole-lines" if W * H >= 4 << 20 else "tile-runs")           # the library's own choice: whole lines where they pay
     cam, proj, pts, col = lists.download()
     h = maps.download((H, W), np.int16).astype(np.int64)
     v = maps.download((H, W), np.int16, voff).astype(np.int64)
@@ -488,7 +488,7 @@ def test_list_build_in_whole_lines_equals_tile_runs(ctx, W, H, how):
     ctx.build_ray_tables_dev(H, W, 0, (pw, ph))
     got = {}
     for lines in (0, 1):
-        ctx.tune("lists_lines", lines)
+        ctx.tune("lists_lines", 2 * lines)                                      # 2 = wherever the shape allows (1 = only images of >= 2048 tiles)
         L = ctx.alloc_cloud_lists(px, colors=True)
         for buf, nbytes in ((L.cam, px * 8), (L.proj, px * 8), (L.pts, px * 24), (L.colors, px * 24)):
             ctx.dev_memset(buf.ptr, 0xA5, max(16, nbytes))
