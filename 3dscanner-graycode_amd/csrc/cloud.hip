@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts,
                 if (d < best[K - 1]) {
 #pragma unroll
                     for (int j = 0; j < K; ++j) {          // static insertion network: best[] stays sorted ascending
-                        const double lo = d < best[j] ? d : best[j], hi = d < best[j] ? best[j] : d;
+                        double lo, hi;                                         // one v_min_f64 + one v_max_f64 per step (fmin / fmax would add a quieting
+                        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(d), "v"(best[j]));       // v_max_f64 x, x per step; nothing here is NaN: the guard above)
+                        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(d), "v"(best[j]));
                         best[j] = lo;
                         d = hi;
                     }
