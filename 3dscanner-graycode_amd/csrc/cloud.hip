@@ -214,6 +214,83 @@ __global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts,
     }
 }
 
+// The stragglers of the first round (k-th neighbour farther than one cell edge: sparse regions, the outliers this routine exists to find) are
+// retried on the SAME grid with a wider block, (2R + 1)^3 cells, exact when the k-th distance <= R s.  They are few, scattered and their
+// candidate lists long and uneven, so here G = 16 lanes share one query: each lane scans every 16th candidate of every x-run into its own
+// sorted top-K, then the group merges the 16 lists by popping the smallest head k times (a 16-lane min per pop; the lane that held it shifts
+// its list).  Four queries ride in a wave and share the merge's instruction stream.
+template <int K, int G>
+__global__ void __launch_bounds__(256) k_knn_mean_group(const float *__restrict__ pts, const unsigned *__restrict__ queries, size_t nq, Grid g, float reach, int R,
+                                                        const unsigned *__restrict__ cell_start, const unsigned *__restrict__ cell_end,
+                                                        const float4 *__restrict__ sorted, int k, double *__restrict__ mean_dist,
+                                                        unsigned *__restrict__ unresolved, unsigned *__restrict__ n_unresolved)
+{
+    static_assert(G == 16, "the group is one DPP row of 16 lanes");
+    const size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int sub = (int)(threadIdx.x % G), lane = (int)(threadIdx.x & 63), group_base = lane & ~(G - 1);
+    const bool live = t < nq;
+    const unsigned i = live ? queries[t] : 0u;
+    const double qx = pts[3 * (size_t)i], qy = pts[3 * (size_t)i + 1], qz = pts[3 * (size_t)i + 2];
+    const int cx = cell_coord((float)qx, g.ox, g.inv_s, g.nx), cy = cell_coord((float)qy, g.oy, g.inv_s, g.ny),
+              cz = cell_coord((float)qz, g.oz, g.inv_s, g.nz);
+    double best[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = 1e300;
+    if (live) {
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+        for (int z = max(cz - R, 0); z <= min(cz + R, g.nz - 1); ++z)
+            for (int y = max(cy - R, 0); y <= min(cy + R, g.ny - 1); ++y) {
+                const unsigned row = ((unsigned)z * g.ny + y) * g.nx;
+                const unsigned b = cell_start[row + x0], e = cell_end[row + x1];
+                for (unsigned p = b + (unsigned)sub; p < e; p += G) {
+                    const float4 c = sorted[p];
+                    const double ddx = (double)c.x - qx, ddy = (double)c.y - qy, ddz = (double)c.z - qz;
+                    double d = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (d < best[K - 1]) {
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            double lo, hi;
+                            asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(d), "v"(best[j]));
+                            asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(d), "v"(best[j]));
+                            best[j] = lo;
+                            d = hi;
+                        }
+                    }
+                }
+            }
+    }
+    double sum = 0.0, kth = 0.0;
+    for (int j = 0; j < k; ++j) {                       // k <= K pops
+        double m = best[0];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const double other = __shfl_xor(m, o, G);
+            m = other < m ? other : m;
+        }
+        const unsigned long long holders = __ballot(best[0] == m);
+        const unsigned mine = (unsigned)(holders >> group_base) & ((1u << G) - 1u);
+        if (sub == __builtin_ctz(mine | (1u << G))) {  // the first lane of the group that holds it gives it up (equal distances of distinct points pop one by one)
+#pragma unroll
+            for (int q = 0; q + 1 < K; ++q) best[q] = best[q + 1];
+            best[K - 1] = 1e300;
+        }
+        sum += sqrt(m);
+        kth = m;
+    }
+    if (live && sub == 0) {
+        if (kth <= (double)reach * (double)reach) mean_dist[i] = sum / (double)k;
+        else unresolved[atomicAdd(n_unresolved, 1u)] = i;
+    }
+}
+
+template <int K>
+void launch_knn_group(slgc_ctx *ctx, const float *d_pts, const unsigned *d_q, size_t nq, const Grid &g, float reach, int R, const unsigned *cs, const unsigned *ce,
+                      const float4 *sorted, int k, double *d_mean, unsigned *d_unres, unsigned *d_nun)
+{
+    hipLaunchKernelGGL((k_knn_mean_group<K, 16>), dim3((unsigned)((nq * 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_pts, d_q, nq, g, reach, R, cs, ce, sorted, k,
+                       d_mean, d_unres, d_nun);
+}
+
 template <int K>
 void launch_knn(slgc_ctx *ctx, const float *d_pts, const unsigned *d_q, size_t nq, const Grid &g, float s, const unsigned *cs, const unsigned *ce,
                 const float4 *sorted, int k, double *d_mean, unsigned *d_unres, unsigned *d_nun)
@@ -347,7 +424,23 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
         d_q = d_out;
         cur ^= 1;
         if (one_cell && nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN: %zu queries unresolved on a single-cell grid (internal error)", nq);
-        s *= round == 0 ? 2.0 : 4.0;                   // the stragglers are few: fewer rebuilds of the grid matter more than their candidate lists
+        // the stragglers: same grid, blocks of (2R + 1)^3 cells, R = 2, 4, 8, ... (k_knn_mean_group); a block that spans the grid is exhaustive
+        for (int R = 2; nq; R *= 2) {
+            const bool whole = R >= g.nx && R >= g.ny && R >= g.nz;
+            const float reach = whole ? __builtin_huge_valf() : (float)(0.999 * (double)R / (double)g.inv_s);
+            unsigned *d_out2 = (unsigned *)d_unres[cur];
+            HIP_TRY(ctx, hipMemsetAsync(d_nun, 0, 4, ctx->stream));
+            if (k <= 20) launch_knn_group<20>(ctx, (const float *)d_pts, d_q, nq, g, reach, R, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out2, (unsigned *)d_nun);
+            else if (k <= 32) launch_knn_group<32>(ctx, (const float *)d_pts, d_q, nq, g, reach, R, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out2, (unsigned *)d_nun);
+            else launch_knn_group<64>(ctx, (const float *)d_pts, d_q, nq, g, reach, R, cs, ce, (const float4 *)d_sorted, k, (double *)d_mean, d_out2, (unsigned *)d_nun);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(&nun, d_nun, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (whole && nun) return slgc_fail(ctx, SLGC_EHIP, "k-NN: %u queries unresolved by an exhaustive scan (internal error)", nun);
+            nq = nun;
+            d_q = d_out2;
+            cur ^= 1;
+        }
     }
     if (nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN left %zu points unresolved", nq);
     HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
