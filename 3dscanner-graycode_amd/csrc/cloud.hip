@@ -147,6 +147,49 @@ __global__ void __launch_bounds__(256) k_count_nonzero(const unsigned *__restric
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// bounding box + finiteness of the cloud, on the device the points are uploaded to anyway (the host loop over 15 M floats took longer than the
+// first k-NN pass): every workgroup writes {lo[3], hi[3], non-finite count} of its strided share; the host folds the <= 1024 partial rows
+__global__ void __launch_bounds__(256) k_bbox(const float *__restrict__ pts, size_t M, float *__restrict__ partial)
+{
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (size_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[3 * i + c];
+            bad += (!(v == v) || v > 3e38f || v < -3e38f) ? 1u : 0u;
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    __shared__ unsigned s_bad[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], __shfl_down(lo[c], o, 64));
+            hi[c] = fmaxf(hi[c], __shfl_down(hi[c], o, 64));
+        }
+        bad += __shfl_down(bad, o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int c = 0; c < 3; ++c) { s_lo[wave][c] = lo[c]; s_hi[wave][c] = hi[c]; }
+        s_bad[wave] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *out = partial + 8 * (size_t)blockIdx.x;
+        for (int c = 0; c < 3; ++c) {
+            out[c] = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+            out[3 + c] = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+        }
+        out[6] = __uint_as_float(s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3]);
+        out[7] = 0.f;
+    }
+}
+
 // queries: indices of the points still to be resolved (nullptr = all points 0..nq-1)
 template <int K>
 __global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts, const unsigned *__restrict__ queries, size_t nq, Grid g,
@@ -310,15 +353,40 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     if (M == 0) return SLGC_OK;
     if (M > 0x7fffffffll) return slgc_fail(ctx, SLGC_EINVAL, "too many points");
     if ((int64_t)k > M) return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
-    // bounding box on the host (the points come from the host anyway)
-    float lo[3] = {pts[0], pts[1], pts[2]}, hi[3] = {pts[0], pts[1], pts[2]};
-    for (int64_t i = 0; i < M; ++i)
-        for (int c = 0; c < 3; ++c) {
-            const float v = pts[3 * i + c];
-            if (!(v == v) || v > 3e38f || v < -3e38f) return slgc_fail(ctx, SLGC_EINVAL, "non-finite coordinate at point %lld", (long long)i);
-            lo[c] = v < lo[c] ? v : lo[c];
-            hi[c] = v > hi[c] ? v : hi[c];
+    // the points go up first; bounding box and the finiteness check run on the device behind the copy
+    void *d_pts;
+    int rc;
+    if ((rc = slgc_ws(ctx, 0, (size_t)M * 12, &d_pts))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts, (size_t)M * 12, hipMemcpyHostToDevice, ctx->stream));
+    float lo[3], hi[3];
+    {
+        void *d_part;
+        const unsigned nb = (unsigned)std::min<int64_t>((M + 255) / 256, 1024);
+        if ((rc = slgc_ws(ctx, 7, (size_t)nb * 32 + 64, &d_part))) return rc;
+        hipLaunchKernelGGL(k_bbox, dim3(nb), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, (float *)d_part);
+        std::vector<float> part((size_t)nb * 8);
+        HIP_TRY(ctx, hipMemcpyAsync(part.data(), d_part, (size_t)nb * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long bad = 0;
+        for (int c = 0; c < 3; ++c) { lo[c] = part[c]; hi[c] = part[3 + c]; }
+        for (unsigned b = 0; b < nb; ++b) {
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = std::min(lo[c], part[8 * (size_t)b + c]);
+                hi[c] = std::max(hi[c], part[8 * (size_t)b + 3 + c]);
+            }
+            unsigned u;
+            memcpy(&u, &part[8 * (size_t)b + 6], 4);
+            bad += u;
         }
+        if (bad) {
+            for (int64_t i = 0; i < M; ++i)             // name the first one (error path only)
+                for (int c = 0; c < 3; ++c) {
+                    const float v = pts[3 * i + c];
+                    if (!(v == v) || v > 3e38f || v < -3e38f) return slgc_fail(ctx, SLGC_EINVAL, "non-finite coordinate at point %lld", (long long)i);
+                }
+            return slgc_fail(ctx, SLGC_EINVAL, "non-finite coordinates");
+        }
+    }
     // robust box: per-axis 0.5 % / 99.5 % quantiles of a sample of <= 65 536 points, widened by 5 %, inside the true box
     {
         const int64_t stride = M > 65536 ? M / 65536 : 1;
@@ -348,16 +416,13 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     double s = 1.25 * sqrt((double)k / (3.141592653589793 * ((double)M / area)));
     if (!(s > 0)) s = 1e-6;
 
-    void *d_pts, *d_mean, *d_sorted, *d_cellof, *d_unres[2], *d_nun;
-    int rc;
-    if ((rc = slgc_ws(ctx, 0, (size_t)M * 12, &d_pts))) return rc;
+    void *d_mean, *d_sorted, *d_cellof, *d_unres[2], *d_nun;
     if ((rc = slgc_ws(ctx, 1, (size_t)M * 8, &d_mean))) return rc;
     if ((rc = slgc_ws(ctx, 2, (size_t)M * 16, &d_sorted))) return rc;
     if ((rc = slgc_ws(ctx, 3, (size_t)M * 4, &d_cellof))) return rc;
     if ((rc = slgc_ws(ctx, 8, (size_t)M * 4, &d_unres[0]))) return rc;
     if ((rc = slgc_ws(ctx, 9, (size_t)M * 4, &d_unres[1]))) return rc;
-    if ((rc = slgc_ws(ctx, 7, 64, &d_nun))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts, (size_t)M * 12, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = slgc_ws(ctx, 10, 64, &d_nun))) return rc;
 
     size_t nq = (size_t)M;
     const unsigned *d_q = nullptr;
