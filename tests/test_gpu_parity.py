@@ -1145,6 +1145,18 @@ def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
     big = rng.uniform(0, 1, (300_000, 3)).astype(np.float32) * np.array([1.0, 1.0, 1e-3], np.float32)
     np.testing.assert_allclose(ctx.knn_mean_distance(big, 4), onp.knn_mean_distance(big, 4), rtol=1e-12, atol=1e-15)
     assert ctx.knn_mean_distance(np.zeros((0, 3), np.float32), 20).shape == (0,)
+    # a non-finite coordinate is refused, and named (the check runs on the device behind the upload)
+    for bad_value in (np.nan, np.inf, -np.inf):
+        poisoned = big[:50_000].copy()
+        poisoned[31_337, 1] = bad_value
+        with pytest.raises(Exception, match="non-finite coordinate at point 31337"):
+            ctx.knn_mean_distance(poisoned, 4)
+    # outliers far from a dense sheet and k = 33 / 64: the stragglers' pass (16 lanes per query, wider blocks of the same grid), every K
+    sheet = rng.uniform(0, 1, (60_000, 3)).astype(np.float32) * np.array([1.0, 1.0, 2e-3], np.float32)
+    far = rng.uniform(-3, 4, (300, 3)).astype(np.float32)
+    mixed = np.concatenate([sheet, far, far[:40] + np.float32(1e-4)])
+    for k in (20, 33, 64):
+        np.testing.assert_allclose(ctx.knn_mean_distance(mixed, k), onp.knn_mean_distance(mixed, k), rtol=1e-12, atol=1e-15)
 
 
 def test_decode_randomised_configurations(ctx):
