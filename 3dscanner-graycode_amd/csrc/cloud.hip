@@ -216,10 +216,13 @@ __global__ void __launch_bounds__(128) k_knn_mean(const float *__restrict__ pts,
     double best[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = 1e300;
-    for (int dz = -1; dz <= 1; ++dz) {
+    // the nine x-runs of the block, nearest first (the query's own row of cells, then the four that share a face with it, then the corners):
+    // the k-th best distance tightens early and fewer of the later candidates enter the insertion network
+    for (int run = 0; run < 9; ++run) {
+        const int dz = (0x28215 >> (2 * run) & 3) - 1, dy = (0x22161 >> (2 * run) & 3) - 1;      // (dz, dy) = (0,0) (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1)
         const int z = cz + dz;
         if (z < 0 || z >= g.nz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
+        {
             const int y = cy + dy;
             if (y < 0 || y >= g.ny) continue;
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
