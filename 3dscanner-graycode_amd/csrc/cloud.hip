@@ -347,20 +347,24 @@ void launch_knn(slgc_ctx *ctx, const float *d_pts, const unsigned *d_q, size_t n
 
 }  // namespace
 
-// mean distance of every point to its k nearest points (itself included).  pts: host float32 [M][3]; mean: host float64 [M].
-extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, double *mean)
+namespace {
+
+// every stride-th point, packed (the robust box's sample when the cloud only exists in HBM)
+__global__ void __launch_bounds__(256) k_sample_points(const float *__restrict__ pts, size_t M, size_t stride, size_t n, float *__restrict__ out)
 {
-    if (!ctx) return SLGC_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "hipSetDevice failed");
-    if (M < 0 || k < 1 || k > 64 || (M && (!pts || !mean))) return slgc_fail(ctx, SLGC_EINVAL, "bad arguments (1 <= k <= 64)");
-    if (M == 0) return SLGC_OK;
-    if (M > 0x7fffffffll) return slgc_fail(ctx, SLGC_EINVAL, "too many points");
-    if ((int64_t)k > M) return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
-    // the points go up first; bounding box and the finiteness check run on the device behind the copy
-    void *d_pts;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const size_t i = j * stride;
+    out[3 * j] = pts[3 * i];
+    out[3 * j + 1] = pts[3 * i + 1];
+    out[3 * j + 2] = pts[3 * i + 2];
+}
+
+// d_pts: float32 [M][3] in HBM (already there, or uploaded by the caller on ctx->stream); pts: the same points on the host, or nullptr;
+// d_mean: float64 [M] in HBM.  Synchronises the stream (the grid is sized from statistics of the cloud).
+int knn_mean_core(slgc_ctx *ctx, const void *d_pts, const float *pts, int64_t M, int k, void *d_mean)
+{
     int rc;
-    if ((rc = slgc_ws(ctx, 0, (size_t)M * 12, &d_pts))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts, (size_t)M * 12, hipMemcpyHostToDevice, ctx->stream));
     float lo[3], hi[3];
     {
         void *d_part;
@@ -381,6 +385,7 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
             memcpy(&u, &part[8 * (size_t)b + 6], 4);
             bad += u;
         }
+        if (bad && !pts) return slgc_fail(ctx, SLGC_EINVAL, "%llu non-finite coordinates in the cloud", bad);
         if (bad) {
             for (int64_t i = 0; i < M; ++i)             // name the first one (error path only)
                 for (int c = 0; c < 3; ++c) {
@@ -393,11 +398,22 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     // robust box: per-axis 0.5 % / 99.5 % quantiles of a sample of <= 65 536 points, widened by 5 %, inside the true box
     {
         const int64_t stride = M > 65536 ? M / 65536 : 1;
+        const size_t ns = (size_t)((M + stride - 1) / stride);
+        std::vector<float> sample;                      // the same points either way: every stride-th one
+        if (!pts) {
+            void *d_s;
+            if ((rc = slgc_ws(ctx, 7, ns * 12 + 64, &d_s))) return rc;
+            hipLaunchKernelGGL(k_sample_points, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_pts, (size_t)M, (size_t)stride, ns, (float *)d_s);
+            sample.resize(ns * 3);
+            HIP_TRY(ctx, hipMemcpyAsync(sample.data(), d_s, ns * 12, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         std::vector<float> col;
-        col.reserve((size_t)(M / stride) + 1);
+        col.reserve(ns + 1);
         for (int c = 0; c < 3; ++c) {
             col.clear();
-            for (int64_t i = 0; i < M; i += stride) col.push_back(pts[3 * i + c]);
+            if (pts) for (int64_t i = 0; i < M; i += stride) col.push_back(pts[3 * i + c]);
+            else for (size_t j = 0; j < ns; ++j) col.push_back(sample[3 * j + c]);
             const size_t n = col.size(), a = (size_t)(0.005 * (double)(n - 1)), b = (size_t)(0.995 * (double)(n - 1));
             std::nth_element(col.begin(), col.begin() + a, col.end());
             const float qa = col[a];
@@ -419,8 +435,7 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
     double s = 1.25 * sqrt((double)k / (3.141592653589793 * ((double)M / area)));
     if (!(s > 0)) s = 1e-6;
 
-    void *d_mean, *d_sorted, *d_cellof, *d_unres[2], *d_nun;
-    if ((rc = slgc_ws(ctx, 1, (size_t)M * 8, &d_mean))) return rc;
+    void *d_sorted, *d_cellof, *d_unres[2], *d_nun;
     if ((rc = slgc_ws(ctx, 2, (size_t)M * 16, &d_sorted))) return rc;
     if ((rc = slgc_ws(ctx, 3, (size_t)M * 4, &d_cellof))) return rc;
     if ((rc = slgc_ws(ctx, 8, (size_t)M * 4, &d_unres[0]))) return rc;
@@ -511,8 +526,44 @@ extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M
         }
     }
     if (nq) return slgc_fail(ctx, SLGC_EHIP, "k-NN left %zu points unresolved", nq);
-    HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pend_M = ctx->filt_M = ctx->pipe_M = -1;   // workspace slots were reused
     return SLGC_OK;
+}
+
+int knn_check(slgc_ctx *ctx, const void *pts, int64_t M, int k, const void *mean)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return slgc_fail(ctx, SLGC_EHIP, "hipSetDevice failed");
+    if (M < 0 || k < 1 || k > 64 || (M && (!pts || !mean))) return slgc_fail(ctx, SLGC_EINVAL, "bad arguments (1 <= k <= 64)");
+    if (M > 0x7fffffffll) return slgc_fail(ctx, SLGC_EINVAL, "too many points");
+    if (M && (int64_t)k > M) return slgc_fail(ctx, SLGC_EINVAL, "k = %d exceeds the number of points %lld", k, (long long)M);
+    return SLGC_OK;
+}
+
+}  // namespace
+
+// mean distance of every point to its k nearest points (itself included).  pts: host float32 [M][3]; mean: host float64 [M].
+extern "C" int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, double *mean)
+{
+    int rc = knn_check(ctx, pts, M, k, mean);
+    if (rc || M == 0) return rc;
+    // the points go up first; bounding box and the finiteness check run on the device behind the copy
+    void *d_pts, *d_mean;
+    if ((rc = slgc_ws(ctx, 0, (size_t)M * 12, &d_pts))) return rc;
+    if ((rc = slgc_ws(ctx, 1, (size_t)M * 8, &d_mean))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_pts, pts, (size_t)M * 12, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = knn_mean_core(ctx, d_pts, pts, M, k, d_mean))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(mean, d_mean, (size_t)M * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SLGC_OK;
+}
+
+// The same on a cloud that already sits in HBM: d_pts float32 [M][3], d_mean float64 [M] (both device; not the context's workspace).
+// Work enqueued on the context's stream before the call is waited for (the grid is sized from statistics of the cloud); on return the
+// last kernel is enqueued, not finished.
+extern "C" int slgc_knn_mean_distance_dev(slgc_ctx *ctx, const float *d_pts, int64_t M, int k, double *d_mean)
+{
+    const int rc = knn_check(ctx, d_pts, M, k, d_mean);
+    if (rc || M == 0) return rc;
+    return knn_mean_core(ctx, d_pts, nullptr, M, k, d_mean);
 }

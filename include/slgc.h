@@ -187,6 +187,10 @@ int slgc_frame_diff_counts_dev(slgc_ctx *ctx, const void *d_frames, int dtype, i
  * included -- the arithmetic of Open3D's remove_statistical_outlier as called at scanner/utils/visualize.py:104 (exact k-NN on
  * a uniform grid; Open3D itself is absent from the build container, parity with it is UNPINNED).  pts float32 [M][3], 1<=k<=64. */
 int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, double *mean);
+/* The same on a cloud that already sits in HBM (d_pts float32 [M][3], d_mean float64 [M], both device memory of the caller).  Waits for the
+ * work enqueued on the context's stream before it (the search grid is sized from statistics of the cloud); on return the last kernel is
+ * enqueued, not finished (slgc_synchronize / slgc_d2h). */
+int slgc_knn_mean_distance_dev(slgc_ctx *ctx, const float *d_pts, int64_t M, int k, double *d_mean);
 
 /* ------------------------------------------------------------------ whole pipeline, one upload */
 

@@ -1145,6 +1145,16 @@ def test_statistical_outlier_removal_and_ply(ctx, tmp_path):
     big = rng.uniform(0, 1, (300_000, 3)).astype(np.float32) * np.array([1.0, 1.0, 1e-3], np.float32)
     np.testing.assert_allclose(ctx.knn_mean_distance(big, 4), onp.knn_mean_distance(big, 4), rtol=1e-12, atol=1e-15)
     assert ctx.knn_mean_distance(np.zeros((0, 3), np.float32), 20).shape == (0,)
+    # the device-resident entry: the same numbers bit for bit on a cloud that already sits in HBM; a non-finite coordinate there is refused too
+    d_pts, d_mean = ctx.alloc(mixed_bytes := len(big) * 12).upload(big), ctx.alloc(len(big) * 8)
+    ctx.knn_mean_distance_dev(d_pts.ptr, len(big), 4, d_mean.ptr)
+    ctx.synchronize()
+    assert np.array_equal(d_mean.download((len(big),), np.float64), ctx.knn_mean_distance(big, 4)) and mixed_bytes
+    ctx.dev_memset(d_pts.ptr + 12 * 777 + 4, 0xff, 4)                              # 0xffffffff = a NaN
+    with pytest.raises(Exception, match="non-finite"):
+        ctx.knn_mean_distance_dev(d_pts.ptr, len(big), 4, d_mean.ptr)
+    d_pts.free()
+    d_mean.free()
     # a non-finite coordinate is refused, and named (the check runs on the device behind the upload)
     for bad_value in (np.nan, np.inf, -np.inf):
         poisoned = big[:50_000].copy()
