@@ -139,12 +139,16 @@ __global__ void __launch_bounds__(256) k_cell_fill(const float *__restrict__ pts
     sorted[slot] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __uint_as_float((unsigned)i));   // .w = where the point came from
 }
 
-__global__ void __launch_bounds__(256) k_count_nonzero(const unsigned *__restrict__ v, size_t n, unsigned *__restrict__ out)
+// non-empty cells: one partial count per workgroup, folded on the host (16 K waves adding to ONE word took 0.38 ms of same-address atomics)
+__global__ void __launch_bounds__(256) k_count_nonzero(const unsigned *__restrict__ v, size_t n, unsigned *__restrict__ partial)
 {
     unsigned c = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += v[i] ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    __shared__ unsigned w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
 }
 
 // bounding box + finiteness of the cloud, on the device the points are uploaded to anyway (the host loop over 15 M floats took longer than the
@@ -474,12 +478,17 @@ int knn_mean_core(slgc_ctx *ctx, const void *d_pts, const float *pts, int64_t M,
             if (round != 0 || tune_left <= 0 || ncell == 1) break;
             // first round only: steer the population of the non-empty cells to the target (a surface: population ~ s^2)
             --tune_left;
-            unsigned nonempty = 0;
-            HIP_TRY(ctx, hipMemsetAsync(d_nun, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)std::min<size_t>((ncell + 2047) / 2048, 4096)), dim3(256), 0, ctx->stream,
-                               (const unsigned *)d_counts, ncell, (unsigned *)d_nun);
-            HIP_TRY(ctx, hipMemcpyAsync(&nonempty, d_nun, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            unsigned long long nonempty = 0;
+            {
+                const unsigned nb = (unsigned)std::min<size_t>((ncell + 2047) / 2048, 4096);
+                void *d_nz;
+                if ((rc = slgc_ws(ctx, 7, (size_t)nb * 4 + 64, &d_nz))) return rc;
+                hipLaunchKernelGGL(k_count_nonzero, dim3(nb), dim3(256), 0, ctx->stream, (const unsigned *)d_counts, ncell, (unsigned *)d_nz);
+                std::vector<unsigned> nz(nb);
+                HIP_TRY(ctx, hipMemcpyAsync(nz.data(), d_nz, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                for (unsigned b = 0; b < nb; ++b) nonempty += nz[b];
+            }
             const double occ = (double)M / (double)(nonempty ? nonempty : 1);
             if (occ > occ_target / 1.3 && occ < occ_target * 1.3) break;
             s *= std::min(8.0, std::max(0.125, sqrt(occ_target / occ)));
