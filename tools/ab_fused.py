@@ -54,14 +54,20 @@ mode = _native.TRI_ALGEBRAIC | (_native.TRI_SPLIT if args.pipeline == "split" el
 def launch(i):
     s = stacks[i % len(stacks)]
     if args.pipeline == "decode":
-        ctx.decode_dev(s.ptr, 1, N * px, px, N, H, W, maps.at(0), maps.at(px * 2))
+        ctx.decode_dev(s.ptr, 1, N * px, px, N, H, W, maps.at(0), maps.at(px * 2), variant=VARIANT[0])
     else:
         ctx.scan_dev(s.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
 
 
+VARIANT = [0]          # pseudo-knob "variant" (decode pipeline only): slgc_decode_dev's kernel variant code (0 = the library's choice), e.g. 1108128 = 8 pixels per lane
+
+
 def apply(cfg):
     for k, v in zip(names, cfg):
-        ctx.tune(k, v)
+        if k == "variant":
+            VARIANT[0] = v
+        else:
+            ctx.tune(k, v)
 
 
 t_end = __import__("time").perf_counter() + args.preheat          # pre-heat

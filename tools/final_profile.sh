@@ -32,6 +32,7 @@ for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_c
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
 python3 tools/time_dropin.py 2>/dev/null | grep -E "^pass|^c3|^  " > "$out/dropin.log"
 [ -x tools/ubench/write_patterns ] && tools/ubench/write_patterns > "$out/write_patterns.txt" 2>&1
+[ -x tools/ubench/stream_rates ] && tools/ubench/stream_rates > "$out/stream_rates.txt" 2>&1
 python3 - <<PY
 import json, glob, os
 for f in sorted(glob.glob("$out/bench_*.json")):
