@@ -8,7 +8,7 @@
 //   D8 / D16 / Dp   D with 8 / 16 bytes per lane and plane, or lane pairs splitting two planes: the width of the loads does not matter
 //   S / Sp          D in the decode kernel's real schedule (14 threshold planes, then steps of 4 behind a ring of DEPTH steps, with and
 //                   without dependent arithmetic), singly or in plane pairs: neither depth, arithmetic nor pairing moves it
-// One box (round 3): R 6.9 TB/s, W 3.9, C 5.3; D 101 us (the decode kernel: 93-103 us); Ft 123 us (the fused kernel, which also gathers its
+// One box (round 3): R 6.9 TB/s, W 3.9 (4.2 with ordinary stores), C 5.3-5.6; D 101 us (the decode kernel: 93-103 us); Ft 123 us (the fused kernel, which also gathers its
 // ray tables: 122-128 us); Ft' 113 us (fused kernel without map buffers: 118 us); F 163 us (what skipping the transpose would cost).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -58,6 +58,10 @@ __global__ void __launch_bounds__(256) k_write(v4u *out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         __builtin_nontemporal_store(v4u{(unsigned)i, 1u, 2u, 3u}, out + i);
+}
+__global__ void __launch_bounds__(256) k_write_plain(v4u *out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v4u{(unsigned)i, 1u, 2u, 3u};
 }
 __global__ void __launch_bounds__(256) k_copy(const v4u *in, v4u *out, size_t n)
 {
@@ -246,6 +250,7 @@ int main()
     const int grid = 256 * 16;
     timeit("R  read only, 541 MB", (double)big, [&] { flip ^= 1; hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const v4u *)((char *)a + flip * big), big / 16, (unsigned *)sink); });
     timeit("W  write only, 541 MB", (double)big, [&] { hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
+    timeit("W'  write only, ordinary (cacheable) stores", (double)big, [&] { hipLaunchKernelGGL(k_write_plain, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
     timeit("C  copy, 541 MB read + 541 MB written", 2.0 * big, [&] { flip ^= 1; hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const v4u *)((char *)a + flip * big), (v4u *)b, big / 16); });
     const unsigned blocks = (unsigned)((npix4 + 127) / 128);
     timeit("D  decode mix: 44 planes read, 4 B/px written (N + 4 = 48 B/px: 590 MB)", 48.0 * npix, [&] { flip ^= 1; hipLaunchKernelGGL((k_planes<44, 4>), dim3(blocks), dim3(128), 0, 0, (const unsigned *)((char *)a + flip * big), npix4, (unsigned *)b); });
