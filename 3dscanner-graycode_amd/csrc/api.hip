@@ -1302,6 +1302,18 @@ extern "C" int slgc_compact_records_dev(slgc_ctx *ctx, const float *d_xyz, int r
     return launch_compact_records(ctx, d_xyz, rows, W, row0, d_records, d_count);
 }
 
+extern "C" int slgc_move_only_dev(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_stack || (d_h == nullptr) != (d_v == nullptr)) return slgc_fail(ctx, SLGC_EINVAL, "null stack / d_h and d_v go together");
+    if (N != 42 && N != 44 && N != 46) return slgc_fail(ctx, SLGC_EINVAL, "the movement yardstick is built for 42, 44 and 46 frames");
+    if (npix % 256 || plane_stride % 4 || plane_stride < npix || ((uintptr_t)d_stack | (uintptr_t)d_h | (uintptr_t)d_v) % 8 || (uintptr_t)d_xyz % 16 ||
+        npix >= ((size_t)1 << 32))
+        return slgc_fail(ctx, SLGC_EINVAL, "npix must be a multiple of 256, planes 4-byte, maps 8-byte and XYZ 16-byte aligned");
+    return launch_move_only(ctx, d_stack, plane_stride, N, npix, d_h, d_v, d_xyz);
+}
+
 extern "C" int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                                     uint32_t seed, int noise, int shadow)
 {

@@ -175,6 +175,7 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
 // synth.hip
 int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed,
                  int noise, int shadow);
+int launch_move_only(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz);
 int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
                           uint32_t seed, int noise, int16_t *d_h, int16_t *d_v, float *d_truth);
 // ingest.hip

@@ -187,7 +187,54 @@ __global__ void __launch_bounds__(256) k_synth_render(const SynthArgs a, const i
     else for (size_t j = 0; j < (left < 4 ? left : 4); ++j) dst[j] = (uint8_t)(word >> (8 * j));
 }
 
+// ---- the yardstick of the roofline fractions: a kernel that ONLY moves a scan's bytes -------------------------------------------------
+// N frame planes read 4 bytes per lane and plane (the scan kernels' loads), folded with one rotate-xor each so that no load can be dropped;
+// written: the two int16 maps 8 bytes per lane each (if asked for) and 48 bytes of "XYZ" per 4 pixels laid out wave-contiguously, 16 bytes
+// per lane and store, as the fused kernel's LDS transpose leaves them (if asked for).  bench.py times it beside the kernel it grades.
+template <int NP>
+__global__ void __launch_bounds__(128) k_move_only(const uint32_t *__restrict__ stack, uint32_t plane_stride4, uint32_t npix4, uint32_t *__restrict__ h,
+                                                   uint32_t *__restrict__ v, uint32_t *__restrict__ xyz)
+{
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint32_t g = blockIdx.x * 128u + threadIdx.x;
+    if (g >= npix4) return;
+    uint32_t w[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) w[p] = __builtin_nontemporal_load(stack + (size_t)p * plane_stride4 + g);
+    uint32_t x = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) x = ((x << 1) | (x >> 31)) ^ w[p];
+    if (h) {
+        __builtin_nontemporal_store(v2{x, x + 1u}, reinterpret_cast<v2 *>(h) + g);
+        __builtin_nontemporal_store(v2{x + 2u, x + 3u}, reinterpret_cast<v2 *>(v) + g);
+    }
+    if (xyz) {
+        const uint32_t wave0 = g & ~63u, lane = g & 63u;
+        v4 *dst = reinterpret_cast<v4 *>(xyz) + 3 * (size_t)wave0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            __builtin_nontemporal_store(v4{x, x + (uint32_t)k, x + 5u, x + 7u}, dst + 64 * k + lane);
+    }
+}
+
 }  // namespace
+
+// Moves the bytes of one single-run scan of N frames and nothing else (results are meaningless).  d_h / d_v (both or neither) and d_xyz may be
+// NULL; npix a multiple of 256 (whole waves: the XYZ of a wave is written as one block), 4-byte aligned planes.
+int launch_move_only(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz)
+{
+    const uint32_t npix4 = (uint32_t)(npix / 4), blocks = (npix4 + 127u) / 128u;
+    if (!blocks) return SLGC_OK;
+#define SLGC_MOVE(NPV)                                                                                                                        \
+    if (N == NPV)                                                                                                                             \
+        hipLaunchKernelGGL((k_move_only<NPV>), dim3(blocks), dim3(128), 0, ctx->stream, (const uint32_t *)d_stack, (uint32_t)(plane_stride / 4), npix4,  \
+                           (uint32_t *)d_h, (uint32_t *)d_v, (uint32_t *)d_xyz);
+    SLGC_MOVE(42) SLGC_MOVE(44) SLGC_MOVE(46)
+#undef SLGC_MOVE
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
 
 int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
                           uint32_t seed, int noise, int16_t *d_h, int16_t *d_v, float *d_truth)

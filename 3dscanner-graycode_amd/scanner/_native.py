@@ -62,6 +62,7 @@ SIGNATURES = {
     "slgc_frame_diff_counts_dev": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
     "slgc_knn_mean_distance": (_i, [_vp, _vp, _i64, _i, _vp]),
     "slgc_knn_mean_distance_dev": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "slgc_move_only_dev": (_i, [_vp, _vp, C.c_size_t, _i, C.c_size_t, _vp, _vp, _vp]),
     "slgc_pipeline_count": (_i, [_vp, C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64)]),
     "slgc_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp]),
     "slgc_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
@@ -531,6 +532,10 @@ class Context:
         out = _out(len(p), np.float64)
         self._ck(lib().slgc_knn_mean_distance(self._h, _ptr(p), len(p), int(k), _ptr(out)))
         return out
+
+    def move_only_dev(self, d_stack: int, plane_stride: int, N: int, npix: int, d_h=None, d_v=None, d_xyz=None):
+        """The movement yardstick (slgc_move_only_dev): a kernel that only moves one scan's bytes -- N planes in, maps / 12 B per pixel out."""
+        self._ck(lib().slgc_move_only_dev(self._h, d_stack, int(plane_stride), int(N), int(npix), d_h, d_v, d_xyz))
 
     def knn_mean_distance_dev(self, d_pts: int, M: int, k: int, d_mean: int):
         """The same for a cloud already in HBM: d_pts float32 [M][3], d_mean float64 [M] (device pointers; enqueued, not finished, on return)."""

@@ -583,6 +583,25 @@ def run_rank(args, rank, local_rank, world):
         dec_alone = ctx.prof_end() + (ctx.prof_samples(),)
         dec_alone_exec = ctx.last_scan_path()
 
+    movement = None
+    if extras and N in (42, 44, 46) and band_px % 256 == 0 and plane % 4 == 0:
+        # the yardstick: a kernel that ONLY moves the bytes of this scan (slgc_move_only_dev) -- N planes in; maps + 12 B/px, 12 B/px alone, or the
+        # maps alone out -- launched back to back over the same rotated stacks, timed with HIP events around the batch
+        def move(K, **out_ptrs):
+            for i in range(3):
+                ctx.move_only_dev(stacks[i % len(stacks)].ptr, plane, N, band_px, **out_ptrs)
+            ctx.synchronize()
+            ctx.event_record(2)
+            for i in range(K):
+                ctx.move_only_dev(stacks[i % len(stacks)].ptr, plane, N, band_px, **out_ptrs)
+            ctx.event_record(3)
+            ctx.synchronize()
+            return ctx.event_elapsed_ms(2, 3) / K
+        K_mv = max(10, args.steps)
+        movement = {"fused_with_maps_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2), d_xyz=xyz.ptr),
+                    "fused_xyz_only_ms": move(K_mv, d_xyz=xyz.ptr),
+                    "decode_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2))}
+
     ref_product = None
     if extras and row0 == 0:
         ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
@@ -703,19 +722,33 @@ def run_rank(args, rank, local_rank, world):
                                          "executed": other_executed,
                                          "roofline": kernel_roofline("fused" if other_executed["path"] == "fused" else "split", o_kms, o_kn, o_samples, other_executed),
                                          "note": "same scan, same run, timed right after the main region"}
+        if movement is not None:
+            def beside(roof, key):
+                mv = movement[key]
+                roof["movement_only"] = {"avg_launch_ms": round(mv, 5), "kernel_over_movement": round(roof["avg_launch_ms"] / mv, 3),
+                                         "frac": round(roof["algorithmic_bytes_per_launch"] / (mv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "slgc_move_only_dev in the same run: a kernel that only moves this scan's bytes (N planes read 4 B per lane "
+                                                 "and plane; the same outputs in the same store shapes); frac = what IT reaches on the same algorithmic bytes"}
+            if main_pipeline == "fused":
+                beside(out["roofline"], "fused_with_maps_ms")
         if xyz_only is not None:
             x_el, x_kms, x_kn, _, x_samples = xyz_only
             xr = kernel_roofline("fused" if xyz_only_executed["path"] == "fused" else "split", x_kms, x_kn, x_samples, xyz_only_executed)
             xr.pop("frac_incl_maps", None), xr.pop("frac_incl_maps_note", None)
             xr["traffic"] = None                              # the committed counters are of the kernel that also stores the maps
             xr.pop("traffic_source", None), xr.pop("traffic_scene", None)
+            if movement is not None and xyz_only_executed["path"] == "fused":
+                beside(xr, "fused_xyz_only_ms")
             out["xyz_only"] = {"value": round(mpix_per_step * args.steps / x_el, 1), "unit": "Mpixels/s", "ms_per_step": round(x_el / args.steps * 1e3, 4),
                                "steps": args.steps, "executed": xyz_only_executed, "roofline": xr,
                                "note": "the headline scan with d_h = d_v = NULL (cloud wanted, maps not): same kernel, the two int16 map stores "
                                        "skipped; XYZ bit-identical (tests/test_gpu_fullsize.py).  NOT the headline: the reference's decode script "
                                        "keeps the maps, so `value` is measured with them stored"}
         if dec_alone is not None:
-            out["decode_kernel_alone"] = {"roofline": kernel_roofline("split", *dec_alone, ex=dec_alone_exec), "scene": "s-scene",
+            dr = kernel_roofline("split", *dec_alone, ex=dec_alone_exec)
+            if movement is not None:
+                beside(dr, "decode_ms")
+            out["decode_kernel_alone"] = {"roofline": dr, "scene": "s-scene",
                                           "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "
                                                   "kernel's heavier input), same run (the north star's >= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
         if ref_product is not None:

@@ -316,6 +316,12 @@ int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, in
 int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
                          uint32_t seed, int noise, int shadow);
 
+/* Measurement yardstick, not a product: moves the bytes of one single-run scan of N = 42 / 44 / 46 frames and does nothing else -- N planes
+ * read 4 bytes per lane and plane like the scan kernels read them, the two int16 maps (d_h / d_v, both or neither) and 12 bytes per pixel
+ * at d_xyz (may be NULL) written in the scan kernels' store shapes; what lands there is meaningless.  bench.py times it beside the kernel it
+ * grades: on MI355X the scan kernels take what this takes (tools/ubench/stream_rates.hip is the longer study).  npix % 256 == 0. */
+int slgc_move_only_dev(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz);
+
 /* Physically consistent synthetic capture (needs slgc_set_calibration): every camera pixel's ray is cast into a fixed scene (a tilted plane
  * with a sphere in front, 0.4 - 0.65 m away), the hit point goes through the stereo pose and the projector's forward lens model to the
  * projector pixel that lights it, and the frames encode THAT pixel -- one surface seen by camera and projector, which is what

@@ -512,3 +512,31 @@ def test_list_build_in_whole_lines_equals_tile_runs(ctx, W, H, how):
         assert np.isfinite(got[1][2]).any() or how == "density 0.0"
     for b in (dh, dv, white):
         b.free()
+
+
+def test_movement_yardstick_runs_and_refuses_bad_shapes(ctx):
+    """slgc_move_only_dev (the kernel bench.py times beside the graded one: it only moves a scan's bytes) -- it runs on the three frame counts,
+    touches exactly the output buffers it is given, and refuses the shapes it is not built for."""
+    W, H, N = 1920, 1080, 44
+    px = W * H
+    stack, maps, xyz = ctx.alloc(46 * px), ctx.alloc(px * 4 + 64), ctx.alloc(px * 12 + 64)
+    ctx.dev_memset(stack.ptr, 7, 46 * px)
+    for n in (42, 44, 46):
+        ctx.dev_memset(maps.ptr, 0xA5, px * 4 + 64)
+        ctx.dev_memset(xyz.ptr, 0xA5, px * 12 + 64)
+        ctx.move_only_dev(stack.ptr, px, n, px, d_xyz=xyz.ptr)
+        ctx.synchronize()
+        assert (maps.download((px * 4 + 64,), np.uint8) == 0xA5).all()                       # no map buffers given: none written
+        got = xyz.download((px * 12 + 64,), np.uint8)
+        assert (got[:px * 12] != 0xA5).any() and (got[px * 12:] == 0xA5).all()
+        ctx.move_only_dev(stack.ptr, px, n, px, d_h=maps.at(0), d_v=maps.at(px * 2), d_xyz=xyz.ptr)
+        ctx.synchronize()
+        got = maps.download((px * 4 + 64,), np.uint8)
+        assert (got[:px * 4] != 0xA5).any() and (got[px * 4:] == 0xA5).all()
+    for bad in (dict(N=43), dict(npix=px - 4), dict(d_h=maps.at(0))):
+        kw = dict(N=N, npix=px, d_h=None, d_v=None, d_xyz=xyz.ptr)
+        kw.update(bad)
+        with pytest.raises(Exception):
+            ctx.move_only_dev(stack.ptr, px, kw["N"], kw["npix"], d_h=kw["d_h"], d_v=kw["d_v"], d_xyz=kw["d_xyz"])
+    for b in (stack, maps, xyz):
+        b.free()
