@@ -280,7 +280,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->device = device;
     ctx->tune_fuse_tail = xcd_env("SLGC_FUSE_TAIL", 1);
     ctx->tune_proj_tile = xcd_env("SLGC_PROJ_TILE", 1);
-    ctx->tune_fuse_nt = xcd_env("SLGC_FUSE_NT", 3);
+    ctx->tune_fuse_nt = xcd_env("SLGC_FUSE_NT", -1);           // -1 = by image size (launch_scan_fused)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
@@ -337,7 +337,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return SLGC_EINVAL;
     if (!strcmp(name, "fuse_tail")) ctx->tune_fuse_tail = value != 0;
     else if (!strcmp(name, "proj_tile")) ctx->tune_proj_tile = value != 0;      // the projector table is rebuilt on the next use
-    else if (!strcmp(name, "fuse_nt")) ctx->tune_fuse_nt = value & 3;
+    else if (!strcmp(name, "fuse_nt")) ctx->tune_fuse_nt = value < 0 ? -1 : (value & 3);
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
