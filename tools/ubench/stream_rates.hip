@@ -1,7 +1,7 @@
 // stream_rates.hip -- what one MI355X sustains for the byte mixes of the scan kernels when a kernel does NOTHING but move those bytes, measured
 // on the box at hand: the bar the roofline fractions in DESIGN.md are held against.
 //   hipcc --offload-arch=gfx950 -O3 -o stream_rates stream_rates.hip && ./stream_rates
-//   R    read only  (16 B / lane, non-temporal)            W   write only            C   copy
+//   R    read only  (16 B / lane, non-temporal)            W / W' / Wa   write only (non-temporal / ordinary / every sc0-nt-sc1 policy: 3.9-4.25 TB/s, no magic bit)            C   copy
 //   D    the decode kernel's mix: 44 planes of 4 B / lane read, the two int16 maps written as 8 B / lane each       (N + 4  B/px)
 //   F    the fused scan kernel's mix with the XYZ stored as a lane holds it (48 B per lane, 16 B at a time)           (N + 16 B/px)
 //   Ft   ... with the XYZ stored wave-contiguously, as the fused kernel's LDS transpose leaves it; Ft' without the maps (N + 12 B/px)
@@ -62,6 +62,14 @@ __global__ void __launch_bounds__(256) k_write(v4u *out, size_t n)
 __global__ void __launch_bounds__(256) k_write_plain(v4u *out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v4u{(unsigned)i, 1u, 2u, 3u};
+}
+// write only through a buffer descriptor with the cache-policy bits spelled out (aux: 1 = sc0, 2 = nt, 16 = sc1 on gfx94x / gfx950)
+template <int AUX>
+__global__ void __launch_bounds__(256) k_write_aux(v4u *out, size_t n)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)(n * 16 > 0x7fffffffu ? 0x7fffffffu : n * 16), 0x00020000);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)i, 1u, 2u, 3u}, rs, (unsigned)(i * 16), 0, AUX);
 }
 __global__ void __launch_bounds__(256) k_copy(const v4u *in, v4u *out, size_t n)
 {
@@ -251,6 +259,8 @@ int main()
     timeit("R  read only, 541 MB", (double)big, [&] { flip ^= 1; hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const v4u *)((char *)a + flip * big), big / 16, (unsigned *)sink); });
     timeit("W  write only, 541 MB", (double)big, [&] { hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
     timeit("W'  write only, ordinary (cacheable) stores", (double)big, [&] { hipLaunchKernelGGL(k_write_plain, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
+#define WAUX(A) timeit("Wa write only, buffer stores, aux = " #A, (double)big, [&] { hipLaunchKernelGGL((k_write_aux<A>), dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
+    WAUX(0) WAUX(1) WAUX(2) WAUX(3) WAUX(16) WAUX(17) WAUX(18) WAUX(19)
     timeit("C  copy, 541 MB read + 541 MB written", 2.0 * big, [&] { flip ^= 1; hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, (const v4u *)((char *)a + flip * big), (v4u *)b, big / 16); });
     const unsigned blocks = (unsigned)((npix4 + 127) / 128);
     timeit("D  decode mix: 44 planes read, 4 B/px written (N + 4 = 48 B/px: 590 MB)", 48.0 * npix, [&] { flip ^= 1; hipLaunchKernelGGL((k_planes<44, 4>), dim3(blocks), dim3(128), 0, 0, (const unsigned *)((char *)a + flip * big), npix4, (unsigned *)b); });
