@@ -991,9 +991,9 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const int lut_w = ctx->lut_cam_W;
     b.f.cn = SLGC_CAM_NODES_FOR(ctx, lut_w, cam_lut == ctx->lut_cam && npix4 / 4 < (1u << 24));
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
-    // store policy of the products: XYZ always non-temporal; the maps non-temporal on small images (1920x1080: 23.7 vs 24.1 us), cacheable from
-    // ~6 Mpixels up (4096x3000: 119.6 vs 124.8 us physical scene, 122.8 vs 128.1 us S-scene, 127.9 vs 133.6 us at 46 frames -- interleaved A/B)
-    const int nt_policy = ctx->tune_fuse_nt >= 0 ? (ctx->tune_fuse_nt & 3) : (npix4 * (size_t)(n_batch > 1 ? n_batch : 1) >= (6u << 20) ? 1 : 3);
+    // store policy of the products: XYZ always non-temporal; the maps non-temporal on small images (1920x1080: 23.7 vs 24.1 us; 4096x750: no
+    // difference), cacheable from 4 Mpixels up (4096x1500: 64.0 vs 65.4 us; 4096x3000: 119.6 vs 124.8 us physical scene, 122.8 vs 128.1 us S-scene, 127.9 vs 133.6 us at 46 frames -- interleaved A/B)
+    const int nt_policy = ctx->tune_fuse_nt >= 0 ? (ctx->tune_fuse_nt & 3) : (npix4 * (size_t)(n_batch > 1 ? n_batch : 1) >= (4u << 20) ? 1 : 3);
     b.f.nt_store = nt_policy | ((d_h == nullptr || d_v == nullptr) ? 4 : 0);
     b.f.wave_tail = ctx->tune_fuse_tail;
     b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};

@@ -52,7 +52,7 @@ struct slgc_ctx {
     // tuning knobs (slgc_tune): every setting gives the same results, they exist for same-process A/B timing
     int tune_fuse_tail;     // fused scan tail: 1 = wave-local LDS exchange (no workgroup barriers), 0 = workgroup-wide exchange
     int tune_proj_tile;     // projector ray table tiles: 0 = 8x8 pixels (512 B), 1 = 16x8 pixels (one 128-byte line per tile row)
-    int tune_fuse_nt;       // fused scan: bit 0 XYZ, bit 1 maps leave with non-temporal stores; -1 (default) = 1 from ~6 Mpixels per launch up, 3 below
+    int tune_fuse_nt;       // fused scan: bit 0 XYZ, bit 1 maps leave with non-temporal stores; -1 (default) = 1 from 4 Mpixels per launch up, 3 below
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel

@@ -66,7 +66,7 @@ int slgc_synchronize(slgc_ctx *ctx);
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
  * "park" 1 = at 42 / 44 / 46 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
  * 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte wire format / 0 = int16 (default;
- * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default -1: 1 from ~6 Mpixels per launch up, 3 below);
+ * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default -1: 1 from 4 Mpixels per launch up, 3 below);
  * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1), "fuse_xcd" the same for the fused scan kernel (0 = off,
  * the default: 1 = one band of rows per XCD takes the kernel's traffic from 823 to 773 MB and its time from 127 to 137 us at
  * 4096x3000x44; n >= 2 = n consecutive tiles per XCD inside groups of 8 n: 782 MB and +2 % at n = 512).  The one knob that is NOT bit-neutral: "cam_nodes"
