@@ -120,7 +120,7 @@ CASES = [
 @pytest.mark.parametrize("nranks,workload,extra", CASES, ids=[f"{n}x-{w.split('_')[1]}-{'-'.join(e).replace('--', '')}" for n, w, e in CASES])
 def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
     r, j = run_bench("--gpus", str(nranks), "--steps", "9", "--warmup", "2", "--no-extras", "--scene", "s-scene", "--workload", workload, *extra,
-                     timeout=100, ranks_as_hosts=True, attempts=2)
+                     timeout=75, ranks_as_hosts=True, attempts=3)                   # a healthy run takes 3-10 s
     _skip_if_transport_unavailable(r, j)
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     assert j["n_gpus"] == nranks and j["sharded"]["rccl_nranks"] == nranks and j["valid_pixels_per_scan"] > 1000
@@ -136,7 +136,7 @@ def test_rccl_configs3_full_size_on_one_gpu_over_loopback(nranks, extra):
     """BASELINE.json configs[3] -- 4096x3000x44 row-sharded over 2 / 8 / (ragged) 7 ranks -- through the real RCCL exchange (loopback socket
     transport, all ranks on the one GPU), pipelined, self-verified bit for bit on every rank."""
     r, j = run_bench("--gpus", str(nranks), "--steps", "5", "--warmup", "1", "--no-extras", "--workload", "c3_4096x3000x44", *extra,
-                     timeout=150, ranks_as_hosts=True, attempts=2)
+                     timeout=90, ranks_as_hosts=True, attempts=3)                   # a healthy run takes 5-10 s
     _skip_if_transport_unavailable(r, j)
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     v = j["verify"]
@@ -150,11 +150,22 @@ def test_driver_launcher_two_ranks_on_one_gpu():
     default N > 1 run behind it (main strategy, compute-only leg, self-verification, throughput mode with its barriers, the alternative
     exchanges): RANK / LOCAL_RANK / WORLD_SIZE from the environment, the RCCL id through a file, ONE JSON line from rank 0, exit code 0."""
     pytest.importorskip("torch")
-    env = dict(os.environ, SLGC_RANKS_AS_HOSTS="1", SLGC_BENCH_TIMEOUT_S="240", SLGC_BENCH_ALT_TIMEOUT_S="120")
+    env = dict(os.environ, SLGC_RANKS_AS_HOSTS="1", SLGC_BENCH_TIMEOUT_S="150", SLGC_BENCH_ALT_TIMEOUT_S="90")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "c2_1920x1080x44", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for attempt in range(3):                                                # a run that times out is repeated (run_bench's docstring); a wrong result never
+        env["MASTER_PORT"] = cmd[cmd.index("--master-port") + 1] = str(29611 + attempt)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        except subprocess.TimeoutExpired:
+            if attempt == 2:
+                raise
+            continue
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        first = json.loads(lines[-1]) if lines else None
+        if r.returncode != 0 and (first is None or "timed out" in str(first.get("error", "")) + str(first.get("sharded_alternatives", ""))) and attempt < 2:
+            continue
+        break
     _skip_if_transport_unavailable(r, json.loads(lines[-1]) if lines else None)
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     j = json.loads(lines[0])

@@ -127,6 +127,12 @@ def _worker(rank, world, key, H, q):
 @pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (4, 3)])
 def test_collectives_and_one_call_sharded_scan_with_real_rccl_ranks(world, H):
     """(4, 3): more ranks than rows -> a rank with an empty band takes part in every collective."""
+    for attempt in range(3):                      # several RCCL ranks on ONE GPU occasionally stop making progress (tests/test_gpu_rccl_multi.py:
+        if _one_attempt(world, H, last=attempt == 2):          # run_bench): a run that only TIMES OUT is repeated, a wrong result never
+            return
+
+
+def _one_attempt(world, H, last):
     import multiprocessing as mp
     import queue as pyqueue
     mpc = mp.get_context("spawn")
@@ -135,7 +141,7 @@ def test_collectives_and_one_call_sharded_scan_with_real_rccl_ranks(world, H):
     procs = [mpc.Process(target=_worker, args=(r, world, key, H, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results, deadline = [], time.time() + 240
+    results, deadline = [], time.time() + 90     # a healthy run takes a few seconds
     try:
         while len(results) < world and time.time() < deadline:
             try:
@@ -150,8 +156,11 @@ def test_collectives_and_one_call_sharded_scan_with_real_rccl_ranks(world, H):
             pytest.skip(next(info for _, status, info in results if status == "skip"))
         for rank, status, info in results:
             assert status == "ok", f"rank {rank}: {info}"
+        if len(results) < world and not last and all(p.exitcode is None for p in procs):
+            return False                           # nobody failed, nobody finished: timed out -> once more
         assert len(results) == world, f"only {len(results)} of {world} ranks reported (exit codes {[p.exitcode for p in procs]})"
         assert len({info for _, _, info in results}) == 1
+        return True
     finally:
         t_end = time.time() + 10
         for p in procs:
