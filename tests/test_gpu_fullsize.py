@@ -446,7 +446,7 @@ LINE_CASES = [
     (256, 200, "density 0.0"), (256, 200, "density 0.01"), (256, 200, "density 0.1"), (256, 200, "density 0.5"), (256, 200, "density 0.97"),
     (256, 200, "density 1.0"), (128, 3000, "density 0.8"), (332, 77, "density 0.8"), (64, 33, "density 0.9"), (4, 1, "density 1.0"),
     (256, 200, "rows 31 32"), (256, 200, "every 40th row"), (256, 200, "one column"), (256, 200, "checkerboard"), (256, 200, "bands"),
-    (1920, 1080, "density 0.85"),
+    (1920, 1080, "density 0.85"), (4096, 3000, "density 0.3"), (4096, 3000, "bands"),       # thousands of tiles; the sizes where the library picks whole lines itself
 ]
 
 
