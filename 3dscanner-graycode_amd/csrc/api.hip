@@ -284,6 +284,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_tri_nt = xcd_env("SLGC_TRI_NT", 1);
     ctx->tune_xcd = xcd_env("SLGC_XCD", 1);
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
+    ctx->tune_guard_list = xcd_env("SLGC_GUARD_LIST", 1);
     ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     ctx->lut_nodes_err = -1.0f;
@@ -341,6 +342,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "tri_nt")) ctx->tune_tri_nt = value & 1;
     else if (!strcmp(name, "xcd")) ctx->tune_xcd = value != 0;
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
+    else if (!strcmp(name, "guard_list")) ctx->tune_guard_list = value != 0;
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "lists_lines")) ctx->tune_lists_lines = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -1324,14 +1326,18 @@ extern "C" int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plan
     return launch_synth(ctx, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, shadow);
 }
 
-extern "C" int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
-                                       int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz)
+// The physical generator with its knobs exposed: the two surface gains of the 16-pixel checker (frames = 15 + gain * bit + noise), and
+// r2_max, the radius (squared, normalised projector coordinates) up to which the projector's lens model is trusted to be monotonic.
+extern "C" int slgc_synth_physical_ex_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
+                                          int proj_h, uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h_true,
+                                          int16_t *d_v_true, float *d_truth_xyz)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (N < 14 || N > 65 || rows < 0 || W < 0 || row0 < 0 || row0 + rows > H || (d_stack && plane_stride < (size_t)rows * W) || proj_w < 1 || proj_h < 1 ||
-        proj_w > 32767 || proj_h > 32767 || (d_h_true == nullptr) != (d_v_true == nullptr))
+        proj_w > 32767 || proj_h > 32767 || (d_h_true == nullptr) != (d_v_true == nullptr) || noise < 0 || gain_lo < 0 || gain_hi < 0 || gain_lo > 240 ||
+        gain_hi > 240 || !(r2_max > 0.0))
         return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments");
     if (!d_h_true) {
         void *codes;
@@ -1340,7 +1346,25 @@ extern "C" int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t p
         d_h_true = (int16_t *)codes;
         d_v_true = d_h_true + ((npix + 31) & ~(size_t)31);
     }
-    return launch_synth_physical(ctx, d_stack, plane_stride, N, H, W, row0, rows, proj_w, proj_h, seed, noise, d_h_true, d_v_true, d_truth_xyz);
+    return launch_synth_physical(ctx, d_stack, plane_stride, N, H, W, row0, rows, proj_w, proj_h, seed, noise, gain_lo, gain_hi, r2_max, d_h_true, d_v_true,
+                                 d_truth_xyz);
+}
+
+extern "C" int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
+                                       int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz)
+{
+    return slgc_synth_physical_ex_dev(ctx, d_stack, plane_stride, N, H, W, row0, rows, proj_w, proj_h, seed, noise, 140, 180, 0.16, d_h_true, d_v_true,
+                                      d_truth_xyz);
+}
+
+extern "C" int slgc_synth_uniform_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_stack || N < 1 || rows < 0 || W < 0 || W % 4 || row0 < 0 || row0 + rows > H || plane_stride < (size_t)rows * W || plane_stride % 4 ||
+        (uintptr_t)d_stack % 4 || (size_t)H * W / 4 >= ((size_t)1 << 32))
+        return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments (W, plane_stride and the stack pointer must be multiples of 4)");
+    return launch_synth_uniform(ctx, d_stack, plane_stride, N, W, row0, rows, seed);
 }
 
 extern "C" int slgc_event_record(slgc_ctx *ctx, int id)

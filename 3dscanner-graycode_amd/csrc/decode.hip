@@ -386,6 +386,8 @@ struct FrameSpec {
 #define SLGC_PARK_DEPTH 2      // steps of frame loads in flight ahead of the step being classified (specialised kernels)
 #endif
 constexpr int kWaveLdsBytes = 4096;     // LDS block of one wave: fused tail [indices 1 KB | rays / XYZ 3 KB], aliased by the 12 parked frames (3 KB)
+constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pixels (one byte each), behind the blocks of all waves -- inside the same
+                                        // 1280-byte LDS allocation granule of gfx950 as the two 4 KB blocks (8704 -> 8960 B, as 8192 is): no wave less per CU
 
 // ABL (timing-only diagnostic builds, results are wrong): 0 = real kernel; 1 = skip the 14 threshold-frame loads;
 // 2 = loads only (no classification arithmetic).
@@ -401,7 +403,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
     constexpr bool SPEC = NS > 0;
     using FS = FrameSpec<SPEC ? NS : 14>;
     static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * kWaveLdsBytes : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * (kWaveLdsBytes + (FUSE == 3 ? kWaveListBytes : 0)) : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
     uint32_t bid = FUSE != 0 ? (a.f.xcd_run ? xcd_block_fine(blockIdx.x, a.f.xcd_run, gridDim.x) : xcd_block(blockIdx.x, a.f.xcd_chunk)) : blockIdx.x;   // fused scan: optional XCD-aware tile maps (A/B)
     uint32_t scan = 0u;                                                                      // batched launch: which of the independent scans this workgroup belongs to
@@ -594,11 +596,13 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         // K3 appended: the maps never leave registers before they are triangulated (triangulate.py:56-61, 86-95 in the
         // cancelled algebraic form; rays from the per-calibration tables).  Same LDS exchange as k_triangulate_maps_lds:
         // indices -> pixel-per-lane gathers -> per-lane triangulation -> wave-contiguous XYZ stores.
-        // FUSE == 2: the exchange is WAVE-local -- a wave's 256 pixels (64 lanes x 4) are self-contained, every LDS hand-over
+        // FUSE >= 2: the exchange is WAVE-local -- a wave's 256 pixels (64 lanes x 4) are self-contained, every LDS hand-over
         // stays inside the wave (LDS operations of one wave execute in order), so the tail has no workgroup barrier at all and
         // the two waves of a workgroup drift apart freely.  FUSE == 1: the same exchange across the whole workgroup (A/B).
+        // FUSE == 3 (default): flat triangles are compacted over the wave before they are redone (below); FUSE == 2: redone lane by lane (A/B).
         static_assert(FUSE == 0 || NW == 1, "fused tail is written for 4 pixels per lane");
-        constexpr bool WAVE = FUSE == 2;
+        constexpr bool WAVE = FUSE >= 2;
+        constexpr bool GLIST = FUSE == 3 && ABL == 0;
         constexpr int SPAN = WAVE ? 64 : BLOCK;                     // lanes that exchange with each other
         const int tid = threadIdx.x;
         const int t = WAVE ? (tid & 63) : tid;                      // index inside the exchanging group
@@ -667,10 +671,44 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
             cam_rays_from_nodes(cam_v4f{c01.x, c01.y, c01.z, c01.w}, cam_v4f{c23.x, c23.y, c23.z, c23.w}, fx, fy);
             if (live) cam_rays_exact_where_tiny(fx, fy, a.f.cam_lut + off);
         }
-        triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
+        uint32_t ill = 0;
+        if constexpr (GLIST) ill = triangulate4_flag(fx, fy, px, py, valid, a.f.kf, out);
+        else triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
+        if constexpr (GLIST) {
+            // Flat triangles (tri_math.h: error amplification > kGuardAmp) are redone on the reference's float32 intermediates in float64.  A lane-level
+            // loop makes the whole wave walk that path once per flagged POSITION (up to 4 times, each for a handful of lanes -- and scattered
+            // mis-decodes put a flagged pixel into nearly every wave).  Here the wave compacts its flagged pixels into a byte list (ballot + mbcnt
+            // ranks) and redoes 64 of them per pass, lane r taking list entry r: its rays come from the exact tables (camera: per-pixel table,
+            // projector: the index still in the wave's index block), its XYZ replaces the fast one in the staging block before the stores.
+            if (__builtin_amdgcn_ballot_w64(ill != 0u)) {                       // wave-uniform
+                unsigned char *s_list = s_raw + (BLOCK / 64) * kWaveLdsBytes + grp * kWaveListBytes;
+                uint32_t n = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool f = (ill >> j) & 1u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+                    if (f) s_list[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned char)(4 * t + j);
+                    n += (uint32_t)__builtin_popcountll(m);
+                }
+                wave_lds_sync();
+                float *s_xyz = reinterpret_cast<float *>(s_buf);
+                const float2 *cam_wave = a.f.cam_lut + (off - 4u * (uint32_t)t);         // the wave's first pixel in the exact per-pixel table
+#pragma unroll 1
+                for (uint32_t base = 0; base < n; base += 64u) {
+                    if (base + (uint32_t)t < n) {
+                        const uint32_t p = s_list[base + t];
+                        const float2 cr = cam_wave[p], pr = a.f.proj_lut[s_idx1[p]];
+                        const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, a.f.T, a.f.t_len);
+                        s_xyz[3 * p] = r.x;
+                        s_xyz[3 * p + 1] = r.y;
+                        s_xyz[3 * p + 2] = r.z;
+                    }
+                }
+            }
+        }
         sync();
         const uint32_t first = bid * BLOCK + grp * SPAN, ngroups = a.npix / 4;                  // in 4-pixel groups
         const uint32_t nvec = first < ngroups ? ((ngroups - first < (uint32_t)SPAN ? ngroups - first : (uint32_t)SPAN) * 3u) : 0u;
@@ -1026,19 +1064,27 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         ctx->last_nodes = b.f.cn.nodes ? 1 : 0;
         ctx->last_guard = 1;
         ctx->last_ragged = 0;
+        const bool glist = ctx->tune_guard_list != 0;       // flat triangles compacted over the wave (default) or redone lane by lane (A/B)
 #define SLGC_SPEC(NSV)                                                                                             \
         if (ns == NSV) {                                                                                           \
-            if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2, NSV>), dim3(blocks), dim3(128), b);    \
-            else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2, NSV>), dim3(blocks), dim3(128), b);         \
+            if (g.n_runs > 1) {                                                                                    \
+                if (glist) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 3, NSV>), dim3(blocks), dim3(128), b);       \
+                else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2, NSV>), dim3(blocks), dim3(128), b);             \
+            } else {                                                                                               \
+                if (glist) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 3, NSV>), dim3(blocks), dim3(128), b);      \
+                else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2, NSV>), dim3(blocks), dim3(128), b);            \
+            }                                                                                                      \
         }
         SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42)
 #undef SLGC_SPEC
         if (ns == 0) {
             if (g.n_runs > 1) {
-                if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2>), dim3(blocks), dim3(128), b);
+                if (wave && glist) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 3>), dim3(blocks), dim3(128), b);
+                else if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 2>), dim3(blocks), dim3(128), b);
                 else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 1>), dim3(blocks), dim3(128), b);
             } else {
-                if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2>), dim3(blocks), dim3(128), b);
+                if (wave && glist) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 3>), dim3(blocks), dim3(128), b);
+                else if (wave) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2>), dim3(blocks), dim3(128), b);
                 else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 1>), dim3(blocks), dim3(128), b);
             }
         }

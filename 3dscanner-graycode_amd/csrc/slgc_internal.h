@@ -69,6 +69,7 @@ struct slgc_ctx {
     int last_guard;         // 1 = float32 fast form with the flat-triangle guard, 0 = exact (acos / sin) mode, -1 = unguarded (diagnostic build only)
     int last_list_kernel;   // SLGC_LISTS_*: which scatter the last x-major list build launched
     int last_ragged;        // 1 = a byte-wide / per-pixel fallback kernel took part (misaligned buffers, ragged tails)
+    int tune_guard_list;    // fused scan: 1 = flat triangles compacted over the wave and redone 64 per pass (default), 0 = redone lane by lane
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
     void *dl_stage;         // pinned ring the large device-to-host results land in (api.hip: download_par)
@@ -177,7 +178,8 @@ int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, in
                  int noise, int shadow);
 int launch_move_only(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz);
 int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
-                          uint32_t seed, int noise, int16_t *d_h, int16_t *d_v, float *d_truth);
+                          uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h, int16_t *d_v, float *d_truth);
+int launch_synth_uniform(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int W, int row0, int rows, uint32_t seed);
 // ingest.hip
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,

@@ -25,6 +25,7 @@ struct SynthArgs {
     uint32_t seed;
     int noise;
     int sy0, sy1, sx0, sx1;  // shadow rectangle (empty when sy0 >= sy1)
+    int gain_lo, gain_hi;    // k_synth_render: the two surface gains of the 16-pixel checker
 };
 
 // one thread = 4 consecutive pixels of one frame (dword store); grid.y = frame
@@ -79,10 +80,9 @@ __global__ void __launch_bounds__(256) k_synth(const SynthArgs a)
 // operation order of the NumPy twin (oracle/oracle_np.py: synth_physical_codes / render_codes) -- bit-identical (-ffp-contract=off).
 constexpr double kPlaneP[3] = {0.0, 0.0, 0.56}, kPlaneN[3] = {0.18, -0.10, -1.0};
 constexpr double kSphereC[3] = {0.045, 0.015, 0.46}, kSphereR = 0.06;
-constexpr double kPhysR2Max = 0.16;
 constexpr int kPhysUndistortIters = 20;
 
-__global__ void __launch_bounds__(256) k_synth_physical_codes(const Calib c, int W, int row0, size_t npix, int pw, int ph, int code_bits,
+__global__ void __launch_bounds__(256) k_synth_physical_codes(const Calib c, int W, int row0, size_t npix, int pw, int ph, int code_bits, double r2_max,
                                                               int16_t *__restrict__ h, int16_t *__restrict__ v, float *__restrict__ truth)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_synth_physical_codes(const Calib c, int
     const double pu = floor((c.proj_k[0] * xd + c.proj_k[2]) + 0.5);
     const double pv = floor((c.proj_k[1] * yd + c.proj_k[3]) + 0.5);
     const double top = (double)(((1 << code_bits) < 32767 ? (1 << code_bits) : 32767) - 1);
-    const bool lit = (Zp > 0.0) && (r2 <= kPhysR2Max) && (pu >= 0.0) && (pu <= (double)pw - 1.0) && (pv >= 0.0) && (pv <= (double)ph - 1.0) && !shadow &&
+    const bool lit = (Zp > 0.0) && (r2 <= r2_max) && (pu >= 0.0) && (pu <= (double)pw - 1.0) && (pv >= 0.0) && (pv <= (double)ph - 1.0) && !shadow &&
                      (t > 0.0) && (pu <= top) && (pv <= top);
     h[p] = lit ? (int16_t)pu : (int16_t)-1;
     v[p] = lit ? (int16_t)pv : (int16_t)-1;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_synth_render(const SynthArgs a, const i
         const int hv = h[lp], vv = v[lp];
         int val = 15;
         if (hv != -1 && vv != -1) {
-            const int gain = ((((x >> 4) ^ (y >> 4)) & 1) == 1) ? 180 : 140;
+            const int gain = ((((x >> 4) ^ (y >> 4)) & 1) == 1) ? a.gain_hi : a.gain_lo;
             if (f == 1) val = 15 + gain;
             else if (f >= 2 && f < 2 + 4 * a.L) {
                 const int idx = f - 2, inv = idx >= 2 * a.L, k2 = idx - (inv ? 2 * a.L : 0), k = k2 >> 1;
@@ -185,6 +185,18 @@ __global__ void __launch_bounds__(256) k_synth_render(const SynthArgs a, const i
     const size_t left = npix - q * 4;
     if (left >= 4 && ((uintptr_t)dst & 3) == 0) *reinterpret_cast<uint32_t *>(dst) = word;
     else for (size_t j = 0; j < (left < 4 ? left : 4); ++j) dst[j] = (uint8_t)(word >> (8 * j));
+}
+
+// SURVEY.md 8(d) "S-uniform": every byte of every frame uniform in 0..255 (the worst case for the classification: ~23 % of the pixels decode,
+// to arbitrary codes).  The survey draws it from NumPy's PCG64; on the device it is a counter hash -- one mix32 per dword, keyed by (frame,
+// dword of the WHOLE image, seed), so a band holds the same bytes as the same rows of the whole image.  W % 4 == 0.  Twin: oracle_np.synth_uniform.
+__global__ void __launch_bounds__(256) k_synth_uniform(uint8_t *__restrict__ stack, size_t plane_stride, uint32_t q0, uint32_t nq, uint32_t seed)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t f = blockIdx.y;
+    const uint32_t r = mix32((q0 + q) * 0x9E3779B1u + f * 0x85EBCA77u + seed);
+    *reinterpret_cast<uint32_t *>(stack + (size_t)f * plane_stride + (size_t)q * 4) = r;
 }
 
 // ---- the yardstick of the roofline fractions: a kernel that ONLY moves a scan's bytes -------------------------------------------------
@@ -237,16 +249,26 @@ int launch_move_only(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride,
 }
 
 int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
-                          uint32_t seed, int noise, int16_t *d_h, int16_t *d_v, float *d_truth)
+                          uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h, int16_t *d_v, float *d_truth)
 {
     const size_t npix = (size_t)rows * W;
     if (npix == 0) return SLGC_OK;
     SynthArgs a{};
     a.stack = d_stack; a.plane_stride = plane_stride; a.N = N; a.L = (N - 2) / 4; a.H = H; a.W = W; a.row0 = row0; a.rows = rows;
-    a.seed = seed; a.noise = noise;
+    a.seed = seed; a.noise = noise; a.gain_lo = gain_lo; a.gain_hi = gain_hi;
     hipLaunchKernelGGL(k_synth_physical_codes, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, W, row0, npix, proj_w, proj_h,
-                       a.L, d_h, d_v, d_truth);
+                       a.L, r2_max, d_h, d_v, d_truth);
     if (d_stack) hipLaunchKernelGGL(k_synth_render, dim3((unsigned)(((npix + 3) / 4 + 255) / 256), N), dim3(256), 0, ctx->stream, a, d_h, d_v);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+int launch_synth_uniform(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int W, int row0, int rows, uint32_t seed)
+{
+    const size_t nq = (size_t)rows * W / 4;
+    if (nq == 0) return SLGC_OK;
+    hipLaunchKernelGGL(k_synth_uniform, dim3((unsigned)((nq + 255) / 256), N), dim3(256), 0, ctx->stream, d_stack, plane_stride, (uint32_t)((size_t)row0 * W / 4),
+                       (uint32_t)nq, seed);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

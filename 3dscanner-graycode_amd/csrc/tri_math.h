@@ -147,6 +147,26 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
     }
 }
 
+// The fast pass alone: XYZ of the lane's four pixels by the float32 form, and which of them are flat (bit j of the result; decodable pixels
+// only).  The caller redoes the flagged pixels through law_of_sines_mirror -- the fused scan kernel compacts them over the WAVE first
+// (decode.hip), so a wave pays one pass per 64 flagged pixels instead of one pass per flagged position of its lanes.
+__device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+                                                      uint32_t valid, const TriF32 &k, float (&out)[12])
+{
+    uint32_t ill = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], px[j], py[j], k);
+        const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
+        ill |= tri_flat(t, cx[j], cy[j], px[j], py[j], k) ? (1u << j) : 0u;
+        const bool ok = (valid >> j) & 1u;
+        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
+        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
+        out[3 * j + 2] = ok ? s : __builtin_nanf("");
+    }
+    return ill & valid;
+}
+
 // One pixel through the same arithmetic as triangulate4 (bit-identical results): the x-major scatter of slgc_cloud_dev triangulates a pixel where
 // it writes it.  cam_exact = this pixel's entry of the exact per-pixel camera table (read only on the guarded path).
 template <bool GUARD>

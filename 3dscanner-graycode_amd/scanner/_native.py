@@ -84,6 +84,8 @@ SIGNATURES = {
     "slgc_triangulate_wire_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_synth_physical_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.c_uint32, _i, _vp, _vp, _vp]),
+    "slgc_synth_physical_ex_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.c_uint32, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "slgc_synth_uniform_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "slgc_prof_begin": (_i, [_vp, _i, _i]),
@@ -648,12 +650,24 @@ class Context:
         self._ck(lib().slgc_synth_scene_dev(self._h, d_stack, plane_stride, N, H, W, row0, rows, seed, noise, int(bool(shadow))))
 
     def synth_physical_dev(self, d_stack, plane_stride, N, H, W, proj_size, row0=0, rows=None, seed=1, noise=3, d_h_true=None, d_v_true=None,
-                           d_truth_xyz=None):
+                           d_truth_xyz=None, gains=None, r2_max=None):
         """Physically consistent synthetic capture (set_calibration first): frames encode the projector pixel that really lights each
-        camera pixel of a plane + sphere scene; optional device outputs: the encoded codes (int16, -1 = unlit) and the true surface points."""
+        camera pixel of a plane + sphere scene; optional device outputs: the encoded codes (int16, -1 = unlit) and the true surface points.
+        gains = (lo, hi) surface gains of the checker (default 140, 180); r2_max = trusted radius^2 of the projector lens model (default 0.16)."""
         rows = H if rows is None else rows
-        self._ck(lib().slgc_synth_physical_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(proj_size[0]),
-                                               int(proj_size[1]), int(seed), int(noise), d_h_true, d_v_true, d_truth_xyz))
+        if gains is None and r2_max is None:
+            self._ck(lib().slgc_synth_physical_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(proj_size[0]),
+                                                   int(proj_size[1]), int(seed), int(noise), d_h_true, d_v_true, d_truth_xyz))
+            return
+        lo, hi = (140, 180) if gains is None else gains
+        self._ck(lib().slgc_synth_physical_ex_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(proj_size[0]),
+                                                  int(proj_size[1]), int(seed), int(noise), int(lo), int(hi), float(0.16 if r2_max is None else r2_max),
+                                                  d_h_true, d_v_true, d_truth_xyz))
+
+    def synth_uniform_dev(self, d_stack, plane_stride, N, H, W, row0=0, rows=None, seed=0):
+        """SURVEY.md 8(d) S-uniform: every byte uniform in 0..255 (counter hash; twin: oracle_np.synth_uniform)."""
+        rows = H if rows is None else rows
+        self._ck(lib().slgc_synth_uniform_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(seed)))
 
     def prof_begin(self, max_launches: int = 4096, stride: int = 1):
         self._ck(lib().slgc_prof_begin(self._h, int(max_launches), int(stride)))

@@ -332,6 +332,18 @@ int slgc_move_only_dev(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_strid
 int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
                             int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz);
 
+/* The same generator with its knobs: gain_lo / gain_hi = the two surface gains of its 16-pixel checker (frames = 15 + gain * bit + noise;
+ * slgc_synth_physical_dev uses 140 / 180), r2_max = the squared radius in normalised projector coordinates up to which the projector's lens
+ * model is taken to be monotonic (0.16 for the reference's `proj` calibration, which folds over at ~0.22; a mild lens can take 1.5).
+ * Twin: oracle_np.synth_physical(..., gains=, r2_max=). */
+int slgc_synth_physical_ex_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
+                               int proj_h, uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h_true,
+                               int16_t *d_v_true, float *d_truth_xyz);
+
+/* SURVEY.md section 8(d) "S-uniform": every byte of every frame uniform in 0..255 (counter hash keyed by frame, dword of the whole image and
+ * seed: a band holds the bytes of the same rows of the whole image).  W, plane_stride, d_stack multiples of 4.  Twin: oracle_np.synth_uniform. */
+int slgc_synth_uniform_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed);
+
 /* HIP-event timing on the context's stream: id in [0,16). */
 int slgc_event_record(slgc_ctx *ctx, int id);
 int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms);

@@ -467,7 +467,7 @@ def _dist14(dist):
     return k
 
 
-def synth_physical_codes(H, W, proj_size, cam_mtx, cam_dist, proj_mtx, proj_dist, proj_R, proj_T, row0=0, rows=None, code_bits=15):
+def synth_physical_codes(H, W, proj_size, cam_mtx, cam_dist, proj_mtx, proj_dist, proj_R, proj_T, row0=0, rows=None, code_bits=15, r2_max=PHYS_R2_MAX):
     """-> (h int16 [rows,W], v int16 [rows,W], truth float64 [rows,W,3]): the projector pixel that lights each camera pixel (-1 = unlit) and
     the true surface point in the frame Triangulate.triangulate reports (relative to the camera centre, projector axes: R x_c).
     code_bits: a pattern of L bits per axis can only address projector pixels below 2^L (44 frames = 10 bits on a 1920-pixel projector:
@@ -529,7 +529,7 @@ def synth_physical_codes(H, W, proj_size, cam_mtx, cam_dist, proj_mtx, proj_dist
         pu = np.floor((P[0, 0] * xd + P[0, 2]) + 0.5)
         pv = np.floor((P[1, 1] * yd + P[1, 2]) + 0.5)
         top = float(min(1 << code_bits, 32767) - 1)
-        lit = (Zp > 0.0) & (r2 <= PHYS_R2_MAX) & (pu >= 0.0) & (pu <= pw - 1.0) & (pv >= 0.0) & (pv <= ph - 1.0) & (~shadow) & (t > 0.0) & \
+        lit = (Zp > 0.0) & (r2 <= r2_max) & (pu >= 0.0) & (pu <= pw - 1.0) & (pv >= 0.0) & (pv <= ph - 1.0) & (~shadow) & (t > 0.0) & \
               (pu <= top) & (pv <= top)
         h = np.where(lit, pu, -1.0).astype(np.int16)
         vv = np.where(lit, pv, -1.0).astype(np.int16)
@@ -539,14 +539,14 @@ def synth_physical_codes(H, W, proj_size, cam_mtx, cam_dist, proj_mtx, proj_dist
     return h, vv, truth
 
 
-def render_codes(n_frames, H, W, h, v, seed=1, noise=3, row0=0):
+def render_codes(n_frames, H, W, h, v, seed=1, noise=3, row0=0, gains=(140, 180)):
     """Frames of a capture whose pixel (y, x) is lit by projector pixel (h, v) (-1 = unlit: ambient in every frame): the frame order of
     generate_codes.py:53-79, ambient 15, a 140 / 180 checker of surface gains, hash noise -- twin of csrc/synth.hip: k_synth_render."""
     rows = h.shape[0]
     L = (n_frames - 2) // 4
     yy, xx = np.mgrid[row0:row0 + rows, 0:W].astype(np.int64)
     lit = (h != -1) & (v != -1)
-    gain = np.where((((xx >> 4) ^ (yy >> 4)) & 1) == 1, 180, 140)
+    gain = np.where((((xx >> 4) ^ (yy >> 4)) & 1) == 1, int(gains[1]), int(gains[0]))
     hs, vs = h.astype(np.int64) & ((1 << L) - 1), v.astype(np.int64) & ((1 << L) - 1)
     gx, gy = hs ^ (hs >> 1), vs ^ (vs >> 1)
     img = np.full((n_frames, rows, W), 15, dtype=np.int64)
@@ -572,11 +572,28 @@ def render_codes(n_frames, H, W, h, v, seed=1, noise=3, row0=0):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def synth_physical(n_frames, H, W, proj_size, calib, seed=1, noise=3, row0=0, rows=None):
+def synth_physical(n_frames, H, W, proj_size, calib, seed=1, noise=3, row0=0, rows=None, gains=(140, 180), r2_max=PHYS_R2_MAX):
     """-> (stack uint8 [N,rows,W], h, v, truth): see synth_physical_codes / render_codes.  calib = (cam_mtx, cam_dist, proj_mtx (scaled),
-    proj_dist, proj_R, proj_T) as slgc_set_calibration takes them."""
-    h, v, truth = synth_physical_codes(H, W, proj_size, *calib, row0=row0, rows=rows, code_bits=(n_frames - 2) // 4)
-    return render_codes(n_frames, H, W, h, v, seed=seed, noise=noise, row0=row0), h, v, truth
+    proj_dist, proj_R, proj_T) as slgc_set_calibration takes them.  gains / r2_max: slgc_synth_physical_ex_dev's knobs."""
+    h, v, truth = synth_physical_codes(H, W, proj_size, *calib, row0=row0, rows=rows, code_bits=(n_frames - 2) // 4, r2_max=r2_max)
+    return render_codes(n_frames, H, W, h, v, seed=seed, noise=noise, row0=row0, gains=gains), h, v, truth
+
+
+def synth_uniform(n_frames, H, W, seed=0, row0=0, rows=None):
+    """SURVEY.md 8(d) S-uniform as the device generates it (csrc/synth.hip: k_synth_uniform): every byte uniform in 0..255 from a counter
+    hash keyed by (frame, dword of the whole image, seed); little-endian bytes of one mix32 per 4 pixels.  W % 4 == 0."""
+    rows = H - row0 if rows is None else rows
+    assert W % 4 == 0
+    q = (np.arange(rows * W // 4, dtype=np.uint64) + np.uint64(row0 * W // 4)).astype(np.uint32)
+    f = np.arange(n_frames, dtype=np.uint32)[:, None]
+    with np.errstate(over="ignore"):
+        x = q[None] * np.uint32(0x9E3779B1) + f * np.uint32(0x85EBCA77) + np.uint32(seed)
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return np.ascontiguousarray(x).astype("<u4").view(np.uint8).reshape(n_frames, rows, W)
 
 
 # ----------------------------------------------------------------------------- "next" rows (SURVEY 8(f))

@@ -1,0 +1,60 @@
+"""bench.py: the CPU baseline leg (the only place of the bench that imports oracle/)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+from .common import ROOT, WORKLOADS, calibration
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (N = 1)
+def cpu_baseline():
+    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames) at FULL
+    size: get_codes with the reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the per-pixel Python
+    loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    import oracle_np as onp
+    cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
+    K, cd, pk, pd, R, T = calibration(cw, ch, pw, ph)
+    st, _, _ = onp.synth_scene_int(n, ch, cw, seed=1)
+    white = np.repeat(st[1][:, :, None], 3, axis=2)
+    t0 = time.perf_counter()
+    hc, vc = onp.get_codes_loops(st.astype(np.float64))                # float64 stack like the reference driver (src/3:68-70)
+    t_codes = time.perf_counter() - t0
+    hp, vp = onp.codes_to_pixels_loops(hc, vc)
+    t_pix = time.perf_counter() - t0 - t_codes
+    cam, proj, _ = onp.cam_proj_pts_loops(hp, vp, (cw, ch), (pw, ph), white)
+    pts = onp.triangulate(cam, proj, K, cd, pk, pd, R, T)
+    dt = time.perf_counter() - t0
+    mpix = cw * ch / 1e6
+    # strong baseline: the plain-C oracle on the headline workload's own size class (a 2048x1024 crop of the 44-frame scene)
+    st2, _, _ = onp.synth_scene_int(44, 1024, 2048, seed=1)
+    cal3 = calibration(4096, 3000, 1920, 1200)
+    t1 = time.perf_counter()
+    oc.scan_dense(st2, (1920, 1200), *cal3)
+    dt_c = time.perf_counter() - t1
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    dt_mt, used = None, 1
+    for nthr in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
+        oc.set_threads(nthr)
+        oc.scan_dense(st2, (1920, 1200), *cal3)                        # thread pool start-up
+        t2 = time.perf_counter()
+        oc.scan_dense(st2, (1920, 1200), *cal3)
+        d = time.perf_counter() - t2
+        if dt_mt is None or d < dt_mt:
+            dt_mt, used = d, nthr
+    oc.set_threads(1)
+    mpix2 = 2048 * 1024 / 1e6
+    return {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"BASELINE configs[0] at full size: {cw}x{ch} camera, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
+                      f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {pts.shape[1]} points; "
+                      "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
+            "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
+                                   "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
+            "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": "plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, 2048x1024x44 crop of the headline scene",
+            "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
+            "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP), best of 8/16/32/64/128/all visible cores, same crop"}
+
+

@@ -1,0 +1,496 @@
+"""bench.py: what one rank does (set-up, timed region, extras, the JSON line)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, STAGE, WORKLOADS, calibration, csrc_fingerprint, digest64, launch_stats,
+                     workload_label)
+from .cpu import cpu_baseline
+from .legs import physical_accuracy, reference_product, sustained_leg, throughput_batched, throughput_mode
+from .sharded_legs import sharded_report, verify_sharded
+
+
+def run_rank(args, rank, local_rank, world):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's host driver only supports dmabuf IPC: RCCL's P2P set-up fails without it
+    if os.environ.get("SLGC_RANKS_AS_HOSTS") == "1" and world > 1 and "NCCL_HOSTID" not in os.environ:
+        # the same TEST MODE under an external launcher (torch.distributed.run gives every rank the same environment): see spawn_ranks
+        os.environ.update(NCCL_HOSTID=f"slgc-rank-{rank}-{os.environ.get('MASTER_PORT', '0')}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
+    from scanner import _native
+    cam_w, cam_h, proj_w, proj_h, N = WORKLOADS[args.workload]
+    G = args.gpus
+    use_comm = G > 1 or args.force_sharded
+    mode = (_native.TRI_ALGEBRAIC if args.mode == "algebraic" else _native.TRI_EXACT) | (2 if args.tri == "direct" else 0)
+    mode_split, mode_fused = mode | _native.TRI_SPLIT, mode & ~_native.TRI_SPLIT
+    mode = mode_split if args.pipeline == "split" else mode_fused
+    if args.event_stride <= 0:
+        args.event_stride = 1 if args.steps < 16 else 2 if args.steps < 64 else 4
+
+    if G > 1:
+        # a rank that waits for ever in a collective (a peer died, the fabric is unhappy) must not leave the driver without a line
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "Mpixels/s decode+triangulate", "value": None, "unit": "Mpixels/s", "n_gpus": G, "steps": args.steps,
+                                  "warmup": args.warmup, "error": f"timed out after SLGC_BENCH_TIMEOUT_S in the multi-rank run (stage: {STAGE[0]})"}), flush=True)
+            os._exit(4)
+
+        killer = threading.Timer(float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900")), give_up)
+        killer.daemon = True
+        killer.start()
+
+    STAGE[0] = "context"
+    n_dev = max(1, _native.device_count())
+    device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
+    ctx = _native.Context(device)
+    calib = calibration(cam_w, cam_h, proj_w, proj_h)
+    ctx.set_calibration(*calib)
+    if G == 1 and args.force_sharded:
+        ctx.comm_init(0, 1, _native.Context.comm_unique_id())
+    if G > 1:
+        from scanner import sharded
+        STAGE[0] = "rccl unique id"
+        uid, uid_path = sharded.share_unique_id(rank, _native.Context.comm_unique_id, key=os.environ.get("SLGC_UID_KEY"))
+        STAGE[0] = "ncclCommInitRank"
+        ctx.comm_init(rank, G, uid)
+        STAGE[0] = "first barrier"
+        ctx.comm_barrier()
+        STAGE[0] = "setup"
+        if rank == 0:
+            try:
+                os.remove(uid_path)
+            except OSError:
+                pass
+    if use_comm:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints its version banner through C stdio: flush it now so rank 0's JSON stays the last line
+
+    from scanner import sharded
+    plan = sharded.ShardPlan(cam_h, cam_w, G)
+    row0, rows = plan.band(rank)
+    band_px = rows * cam_w
+    plane = band_px + args.plane_pad        # each rank holds only its row band of every frame; pad 0 = the reference's contiguous [N,H,W]
+    if args.buffers <= 0:                                   # enough distinct stacks to exceed the 256 MB Infinity Cache
+        args.buffers = max(2, -(-300_000_000 // max(1, N * plane)))
+    def make_stacks(scene):
+        out_ = []
+        for b in range(max(1, args.buffers)):
+            s = ctx.alloc(max(16, N * plane))
+            if rows and scene == "physical":
+                ctx.synth_physical_dev(s.ptr, plane, N, cam_h, cam_w, (proj_w, proj_h), row0=row0, rows=rows, seed=1 + b, noise=3)
+            elif rows:
+                ctx.synth_scene_dev(s.ptr, plane, N, cam_h, cam_w, row0=row0, rows=rows, seed=1 + b, noise=3, shadow=True)
+            out_.append(s)
+        return out_
+
+    stacks = make_stacks(args.scene)
+    maps = ctx.alloc(max(16, band_px * 4))
+    xyz = ctx.alloc(max(16, band_px * 12))
+    count = ctx.alloc(16).zero()
+    sharded_scanner = None
+    if use_comm:                            # (sets slgc_tune "image_rows": the ray-table choice below is the whole image's)
+        sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode,
+                                                 exchange_kind=args.exchange, wire=args.wire)
+    elif args.image_rows > 0:               # band workloads (b2 / b4 / b8): time the band kernels as a rank of the sharded scan would run them
+        ctx.tune("image_rows", args.image_rows)
+    # per-calibration work, hoisted out of the scans and timed on its own: both undistortPoints calls evaluated into the two ray tables
+    ctx.synchronize()
+    if use_comm:
+        ctx.tune("image_rows", cam_h)       # what the scanner sets around its own calls: the tables built here are the ones it will use
+    ctx.event_record(0)
+    ctx.build_ray_tables_dev(cam_h if use_comm and args.exchange == "maps" else rows, cam_w, 0 if use_comm and args.exchange == "maps" else row0,
+                             (proj_w, proj_h))
+    ctx.event_record(1)
+    luts_us = ctx.event_elapsed_ms(0, 1) * 1e3
+    if use_comm:
+        ctx.tune("image_rows", 0)
+    ctx.synchronize()
+    pipelined = use_comm and args.exchange in ("maps", "xyz") and not args.no_overlap
+
+    def step(i, counted=False, mode=mode, src=None, no_maps=False):
+        src = stacks if src is None else src
+        s = src[i % len(src)]
+        if pipelined:
+            return sharded_scanner.submit(s.ptr, plane)      # exchange of this scan overlaps the neighbours' kernels
+        if use_comm:
+            return sharded_scanner.scan(s.ptr, plane)
+        ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
+                     None if no_maps else maps.at(0), None if no_maps else maps.at(band_px * 2), mode=mode)
+        return None
+
+    def drain():
+        if sharded_scanner is not None:
+            sharded_scanner.flush()
+        ctx.synchronize()
+
+    def timed(K, W_, stride=None, preheat=True, **kw):
+        if preheat and args.preheat > 0:                     # untimed: bring the clocks up before the counted warm-up
+            t_end = time.perf_counter() + args.preheat
+            i = 0
+            more = True
+            while more:
+                for _ in range(16):
+                    step(i, **kw)
+                    i += 1
+                drain()
+                more = time.perf_counter() < t_end
+                if use_comm:                                 # every rank must run the SAME number of scans (each one is a collective): the
+                    more = ctx.comm_allreduce_max(1.0 if more else 0.0) > 0.5       # ranks agree on going on -- a clock per rank would not
+        for i in range(W_):
+            step(i, **kw)
+        drain()
+        if use_comm:
+            ctx.comm_barrier()
+        ctx.prof_begin(K + 8, stride or args.event_stride)   # HIP-event pair bound to every stride-th kernel dispatch of the region
+        t0 = time.perf_counter()
+        tot = None
+        for i in range(K):
+            tot = step(i, **kw)
+        drain()                                              # the K-th scan's exchange + triangulation are inside the timed region
+        if use_comm:
+            ctx.comm_barrier()
+        el = time.perf_counter() - t0
+        kms, kn = ctx.prof_end()
+        samples = ctx.prof_samples()
+        if use_comm:
+            el = ctx.comm_allreduce_max(el)
+            kms = ctx.comm_allreduce_max(kms)
+        return el, kms, kn, tot, samples
+
+    STAGE[0] = "timed region (incl. pre-heat and warm-up)"
+    elapsed, dec_ms, dec_n, total_pts, dec_samples = timed(args.steps, args.warmup)
+    STAGE[0] = "extras"
+    executed = ctx.last_scan_path()                          # what the library actually launched in the timed region (not what this script asked for)
+    last_stack = (args.steps - 1) % len(stacks)              # what the output buffers hold now
+    single = G == 1 and not use_comm
+    extras = single and not args.no_extras and args.mode == "algebraic" and args.tri == "lut"
+
+    def scene_stats(src):
+        """valid / guard-flagged pixels of one scan of src[0] (untimed)"""
+        count.zero()
+        ctx.scan_dev(src[0].ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode_fused)
+        ctx.guard_count_dev(maps.at(0), maps.at(band_px * 2), rows, cam_w, row0, (proj_w, proj_h), count.ptr)
+        ctx.synchronize()
+        return tuple(int(x) for x in count.download((2,), np.uint64))
+
+    other_scene = None
+    if extras:
+        # the same kernel on the other synthetic capture: S-scene = arbitrary smooth code maps (epipolar-inconsistent: part of its pixels
+        # takes the guarded float64 path), physical = one surface seen by camera and projector (few lit pixels with these calibrations)
+        o_name = "physical" if args.scene == "s-scene" else "s-scene"
+        o_stacks = make_stacks(o_name)
+        s_scene_stacks = o_stacks if o_name == "s-scene" else stacks
+        o_el, o_kms, o_kn, _, o_samples = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, src=o_stacks)
+        o_exec = ctx.last_scan_path()
+        o_valid, o_flag = scene_stats(o_stacks)
+        acc = None
+        if o_name == "physical" or args.scene == "physical":
+            acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), calib, maps, xyz, band_px, mode_fused)
+        other_scene = (o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc)
+
+    sustained = None
+    if single and not args.no_extras and args.sustained > 0:
+        sustained = sustained_leg(ctx, step, drain, args.sustained, cam_w * rows / 1e6)
+
+    other = None
+    if extras:
+        om = mode_fused if args.pipeline == "split" else mode_split
+        other = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=om)
+        other_executed = ctx.last_scan_path()
+
+    xyz_only = None
+    if extras:
+        # the same scan for a caller that wants the cloud only (no map buffers passed): the fused kernel then moves exactly SURVEY 8(d)'s N + 12 B/pixel
+        xyz_only = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, no_maps=True)
+        xyz_only_executed = ctx.last_scan_path()
+
+    dec_alone = None
+    if extras:
+        # the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way)
+        for i in range(3):
+            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        ctx.synchronize()
+        ctx.prof_begin(args.steps + 8)
+        for i in range(args.steps):
+            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        dec_alone = ctx.prof_end() + (ctx.prof_samples(),)
+        dec_alone_exec = ctx.last_scan_path()
+
+    movement = None
+    if extras and N in (42, 44, 46) and band_px % 256 == 0 and plane % 4 == 0:
+        # the yardstick: a kernel that ONLY moves the bytes of this scan (slgc_move_only_dev) -- N planes in; maps + 12 B/px, 12 B/px alone, or the
+        # maps alone out -- launched back to back over the same rotated stacks, timed with HIP events around the batch
+        def move(K, **out_ptrs):
+            for i in range(3):
+                ctx.move_only_dev(stacks[i % len(stacks)].ptr, plane, N, band_px, **out_ptrs)
+            ctx.synchronize()
+            ctx.event_record(2)
+            for i in range(K):
+                ctx.move_only_dev(stacks[i % len(stacks)].ptr, plane, N, band_px, **out_ptrs)
+            ctx.event_record(3)
+            ctx.synchronize()
+            return ctx.event_elapsed_ms(2, 3) / K
+        K_mv = max(10, args.steps)
+        movement = {"fused_with_maps_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2), d_xyz=xyz.ptr),
+                    "fused_xyz_only_ms": move(K_mv, d_xyz=xyz.ptr),
+                    "decode_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2))}
+
+    ref_product = None
+    if extras and row0 == 0:
+        ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
+        ref_product["scene"] = "s-scene"
+
+    thr = thr_batched = None
+    if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
+        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
+        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
+
+    # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
+    count.zero()
+    if not use_comm:
+        ctx.scan_dev(stacks[0].ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode)
+        ctx.guard_count_dev(maps.at(0), maps.at(band_px * 2), rows, cam_w, row0, (proj_w, proj_h), count.ptr)
+    elif args.exchange == "records":
+        pass
+    else:
+        ctx.guard_count_dev(sharded_scanner.h_full.ptr, sharded_scanner.v_full.ptr, cam_h, cam_w, 0, (proj_w, proj_h), count.ptr)
+    ctx.synchronize()
+    valid, flagged = (int(x) for x in count.download((2,), np.uint64))
+    if use_comm and args.exchange == "records":
+        valid, flagged = int(total_pts), None
+
+    verify = None
+    shard_info = None
+    if use_comm:
+        STAGE[0] = "sharded report (compute-only timing)"
+        shard_info = sharded_report(ctx, sharded_scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, (proj_w, proj_h), mode, elapsed)
+        if not args.no_verify and args.exchange in ("maps", "xyz"):
+            STAGE[0] = "verification"
+            verify = verify_sharded(ctx, sharded_scanner, G, rank, N, cam_w, cam_h, (proj_w, proj_h), 1 + last_stack, args.plane_pad, args.scene)
+
+    out = None
+    if rank == 0:
+        mpix_per_step = cam_w * cam_h / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        value = mpix_per_step * args.steps / elapsed
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        try:
+            traffic_db = json.load(open(tpath))
+        except Exception:  # noqa: BLE001
+            traffic_db = {}
+        fp = csrc_fingerprint()
+
+        def kernel_name(ex, pipeline):
+            spec = f"NS={ex['ns_frames']} (threshold frames parked in LDS)" if ex["ns_frames"] else "generic frame count"
+            if pipeline == "split":
+                return f"k_decode_pk<4,128,nt> {spec}"
+            return f"k_decode_pk<4,128,nt,FUSE=2> {spec} + triangulation tail (camera rays: {'node table' if ex['node_table'] else 'per-pixel table'})"
+
+        def kernel_roofline(pipeline, kms, kn, samples, ex=None, scene=None):
+            """SURVEY.md 8(d) byte definitions: decode kernel N + 4 B/pixel (N uint8 reads, 2 int16 writes); fused decode -> XYZ
+            N + 12 B/pixel.  The fused kernel also writes the 4 B/pixel maps (a product): frac_incl_maps counts them too."""
+            per_px = (N + 4) if pipeline == "split" else (N + 12)
+            avg_ms = kms / max(1, kn)
+            ach = per_px * band_px / (avg_ms * 1e-3) / 1e9
+            r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                 "traffic": None, "kernel": kernel_name(ex or executed, pipeline),
+                 "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, **launch_stats(samples),
+                 "algorithmic_bytes_per_px": per_px, "algorithmic_bytes_per_launch": per_px * band_px}
+            if pipeline != "split":
+                r["frac_incl_maps"] = round((N + 16) * band_px / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                r["frac_incl_maps_note"] = "N + 16 B/pixel: the 4 B/pixel int16 maps the fused kernel also writes counted as algorithmic"
+            t = traffic_db.get(f"{args.workload}/g{G}/{pipeline}")
+            if t and t.get("csrc_fingerprint") == fp:
+                # the counters were collected per scene for the fused kernel (tools/pmc.sh): fewer lit pixels = fewer projector-table lines gathered
+                sc = scene or args.scene
+                r["traffic"] = t.get("s_scene_hbm_bytes_per_launch") if (sc == "s-scene" and pipeline != "split" and "s_scene_hbm_bytes_per_launch" in t) else t["hbm_bytes_per_launch"]
+                r["traffic_source"] = t.get("source")
+                r["traffic_scene"] = "s-scene" if (pipeline == "split" or sc == "s-scene") else "physical"
+            elif t:
+                r["traffic_note"] = ("profiles/traffic.json was measured on other kernel sources (fingerprint mismatch): stale, not reported; "
+                                     "re-run tools/pmc.sh")
+            return r
+
+        main_pipeline = "split" if (use_comm and args.exchange == "maps") else args.pipeline
+        if not use_comm:                                     # the label follows the launch, not the request
+            main_pipeline = "fused" if executed["path"] in ("fused", "batch-fused") else "split"
+        out = {
+            "metric": "Mpixels/s decode+triangulate", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": G,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload_label(args.workload, cam_w, cam_h, proj_w, proj_h, N, G if use_comm else 0),
+                       "pipeline": ({"maps": "decode kernel per band, map bands all-gathered, full-image triangulation kernel on every rank",
+                                     "xyz": "fused kernel per band, map + XYZ bands all-gathered in place",
+                                     "records": "fused kernel per band, compaction, 16-byte XYZ+key records all-gatherv'ed"}[args.exchange] if use_comm
+                                    else {"fused": "fused (one kernel)", "batch-fused": "fused (one kernel, batched)", "split": "split (decode kernel + triangulation kernel)",
+                                          "split-ragged": "split (decode kernel + triangulation kernel, with byte-wide / per-pixel fallback kernels)"}.get(executed["path"], executed["path"])),
+                       "executed": {**executed, "source": "slgc_last_scan_path after the timed region", "requested_pipeline": args.pipeline},
+                       "scene": {"s-scene": "S-scene (SURVEY.md 8(d): smooth synthetic code maps, shadow rectangle, noise 3)",
+                                 "physical": "physical (plane + sphere seen by camera and projector through the calibration, noise 3)"}[args.scene],
+                       "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks), "plane_pad_bytes": args.plane_pad,
+                       "outputs": "int16 h/v maps + dense float32 XYZ in HBM" + ("" if not use_comm else "; whole cloud reassembled on every rank"),
+                       "preheat_s": args.preheat, "event_stride": args.event_stride,
+                       "luts_hoisted_us": round(luts_us, 1),
+                       "luts_hoisted_note": "per-calibration ray tables (both cv2.undistortPoints calls on integer pixel coordinates) built once "
+                                            "before the timed region, not per scan",
+                       "camera_rays": (lambda use, err: {"node_table_in_use": use, "node_table_error_vs_limit_2.4e-7": err,
+                                                         "note": "per-pixel table 8 B/pixel, or (bands above 64 MB of rays) the every-4th-column "
+                                                                 "table 2 B/pixel + a cubic through 4 nodes per 4-pixel group; flat triangles and "
+                                                                 "zero-crossing rays always read the exact per-pixel table"})(*ctx.ray_table_info()),
+                       "guard_flagged_pixels": flagged,
+                       "guard_note": "decodable pixels of one scan that triangulation redoes on the reference's float32 intermediates (flat triangles)"},
+            "roofline": kernel_roofline(main_pipeline, dec_ms, dec_n, dec_samples),
+            "valid_pixels_per_scan": valid,
+            "device": ctx.device_name(),
+        }
+        if shard_info:
+            out["sharded"] = shard_info
+        if verify is not None:
+            out["verify"] = verify
+        if other is not None:
+            o_el, o_kms, o_kn, _, o_samples = other
+            o_name = "fused" if args.pipeline == "split" else "split"
+            out[o_name + "_pipeline"] = {"value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
+                                         "ms_per_step": round(o_el / args.steps * 1e3, 4), "steps": args.steps,
+                                         "executed": other_executed,
+                                         "roofline": kernel_roofline("fused" if other_executed["path"] == "fused" else "split", o_kms, o_kn, o_samples, other_executed),
+                                         "note": "same scan, same run, timed right after the main region"}
+        if movement is not None:
+            def beside(roof, key):
+                mv = movement[key]
+                roof["movement_only"] = {"avg_launch_ms": round(mv, 5), "kernel_over_movement": round(roof["avg_launch_ms"] / mv, 3),
+                                         "frac": round(roof["algorithmic_bytes_per_launch"] / (mv * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "slgc_move_only_dev in the same run: a kernel that only moves this scan's bytes (N planes read 4 B per lane "
+                                                 "and plane; the same outputs in the same store shapes); frac = what IT reaches on the same algorithmic bytes"}
+            if main_pipeline == "fused":
+                beside(out["roofline"], "fused_with_maps_ms")
+        if xyz_only is not None:
+            x_el, x_kms, x_kn, _, x_samples = xyz_only
+            xr = kernel_roofline("fused" if xyz_only_executed["path"] == "fused" else "split", x_kms, x_kn, x_samples, xyz_only_executed)
+            xr.pop("frac_incl_maps", None), xr.pop("frac_incl_maps_note", None)
+            xr["traffic"] = None                              # the committed counters are of the kernel that also stores the maps
+            xr.pop("traffic_source", None), xr.pop("traffic_scene", None)
+            if movement is not None and xyz_only_executed["path"] == "fused":
+                beside(xr, "fused_xyz_only_ms")
+            out["xyz_only"] = {"value": round(mpix_per_step * args.steps / x_el, 1), "unit": "Mpixels/s", "ms_per_step": round(x_el / args.steps * 1e3, 4),
+                               "steps": args.steps, "executed": xyz_only_executed, "roofline": xr,
+                               "note": "the headline scan with d_h = d_v = NULL (cloud wanted, maps not): same kernel, the two int16 map stores "
+                                       "skipped; XYZ bit-identical (tests/test_gpu_fullsize.py).  NOT the headline: the reference's decode script "
+                                       "keeps the maps, so `value` is measured with them stored"}
+        if dec_alone is not None:
+            dr = kernel_roofline("split", *dec_alone, ex=dec_alone_exec)
+            if movement is not None:
+                beside(dr, "decode_ms")
+            out["decode_kernel_alone"] = {"roofline": dr, "scene": "s-scene",
+                                          "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "
+                                                  "kernel's heavier input), same run (the north star's >= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
+        if ref_product is not None:
+            out["reference_product"] = ref_product
+        if sustained is not None:
+            out["sustained"] = sustained
+        if other_scene is not None:
+            o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc = other_scene
+            out["other_scene"] = {"scene": o_name, "value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
+                                  "ms_per_step": round(o_el / args.steps * 1e3, 4), "executed": o_exec,
+                                  "roofline": kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec, scene=o_name),
+                                  "valid_pixels_per_scan": o_valid, "guard_flagged_pixels": o_flag,
+                                  "note": "the headline step on the other synthetic capture, same run (bench.py --scene picks which one is the headline)"}
+            if acc is not None:
+                out["physical_scene_accuracy"] = acc
+        if thr is not None:
+            t_el, t_scans, t_mpix = thr
+            t_steps = max(5, args.steps // 4)
+            out["throughput_mode"] = {"value": round(t_scans * t_mpix * t_steps / t_el, 1), "unit": "Mpixels/s",
+                                      "config": f"{t_scans} independent 1920x1080x44 scans per step ({t_scans // G} per GPU), no collective "
+                                                "(BASELINE.json configs[4], replicas only)",
+                                      "scans_per_s": round(t_scans * t_steps / t_el, 1), "steps": t_steps, "streams_per_gpu": args.streams,
+                                      "scene": args.scene, "scaling": "weak"}
+            if thr_batched is not None:
+                b_el, b_scans, b_mpix = thr_batched
+                out["throughput_mode"]["batched"] = {"value": round(b_scans * b_mpix * t_steps / b_el, 1), "unit": "Mpixels/s",
+                                                     "scans_per_s": round(b_scans * t_steps / b_el, 1),
+                                                     "note": "the same scans through slgc_scan_batch_dev: each GPU's share in one launch per step"}
+        if single and not args.no_cpu_baseline and not args.no_extras:
+            out["cpu_baseline"] = cpu_baseline()
+
+    import threading
+    emit_lock, emitted = threading.Lock(), []
+
+    def emit(extra=None):
+        with emit_lock:                                      # exactly one JSON line, whichever thread gets here first (main or the watchdog)
+            if emitted:
+                return
+            emitted.append(True)
+            if rank == 0:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+                line = dict(out)
+                if extra:
+                    line.update(extra)
+                print(json.dumps(line), flush=True)
+
+    # Extras of the multi-rank run, AFTER everything above is measured and assembled: a watchdog prints the line as it stands and ends
+    # the process if they do not come back (a hang in a collective that has never run on more than one GPU must not cost the run).
+    def bail():
+        emit({"sharded_alternatives": {"error": f"timed out: the line was printed without them (stage: {STAGE[0]})"}})
+        os._exit(3 if (verify is not None and not verify.get("ok", False)) else 5)      # 5 = the extras hung (the headline above is complete)
+
+    watchdog = threading.Timer(float(os.environ.get("SLGC_BENCH_ALT_TIMEOUT_S", "120")), bail)
+    watchdog.daemon = True
+    watchdog.start()
+    alternatives = None
+    STAGE[0] = "sharded alternatives"
+    if use_comm and args.exchange == "maps" and not args.no_extras and pipelined:
+        # The first run on real xGMI is rare: time the other exchange forms too (same stacks, same pipelining, each verified against the maps
+        # the main strategy left) -- extras after the counted region, a failure here is reported and changes nothing above.
+        sharded_scanner.submit(stacks[last_stack].ptr, plane)
+        sharded_scanner.flush()
+        h_main, v_main, _ = sharded_scanner.fetch_dense()
+        main_digest = digest64(h_main, v_main)
+        alternatives = {}
+        other_wire = "int16" if sharded_scanner.wire == "hv24" else "hv24"           # whichever wire the main strategy did not use
+        for label, kind, wire in (("maps_" + other_wire, "maps", other_wire), ("xyz", "xyz", "int16")):
+            if wire == "hv24" and int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS:
+                continue
+            try:
+                alt = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
+                K = max(5, args.steps // 2)
+                for i in range(3):
+                    alt.submit(stacks[i % len(stacks)].ptr, plane)
+                alt.flush()
+                ctx.synchronize()
+                ctx.comm_barrier()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    alt.submit(stacks[i % len(stacks)].ptr, plane)
+                alt.flush()
+                ctx.synchronize()
+                ctx.comm_barrier()
+                el_alt = ctx.comm_allreduce_max(time.perf_counter() - t0)
+                alt.submit(stacks[last_stack].ptr, plane)                 # the stack the main strategy finished on
+                alt.flush()
+                ha, va, _ = alt.fetch_dense()
+                same = ctx.comm_allgather_i64(1 if digest64(ha, va) == main_digest else 0)
+                alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K,
+                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "maps_int16": 4, "xyz": 16}[label],
+                                       "maps_equal_main_strategy_on_every_rank": bool(all(same))}
+                del alt
+            except Exception as e:  # noqa: BLE001
+                alternatives[label] = {"error": f"{type(e).__name__}: {e}"}
+
+    STAGE[0] = "final barrier"
+    watchdog.cancel()
+    emit({"sharded_alternatives": alternatives} if (rank == 0 and alternatives) else None)
+    if use_comm:
+        ctx.comm_barrier()
+    ctx.close()
+    if verify is not None and not verify.get("ok", False):
+        sys.exit(3)
+    if single and args.pipeline == "fused" and args.mode == "algebraic" and args.tri == "lut" and executed["path"] != "fused":
+        print(f"bench.py: the headline asked for the fused kernel but the library launched '{executed['path']}'", file=sys.stderr)
+        sys.exit(6)
+
+

@@ -1,0 +1,72 @@
+"""bench.py: report and self-verification of the row-sharded scan (N > 1 or --force-sharded)."""
+import time
+
+import numpy as np
+
+from .common import digest64
+
+
+def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, proj_size, mode, elapsed):
+    """compute-only vs with-exchange rates of the sharded scan and the bytes each rank puts on / takes off the links."""
+    K = max(5, args.steps // 2)
+    t_compute = None
+    if args.exchange in ("maps", "xyz"):
+        for rep in range(2):                                   # first pass warms up
+            ctx.synchronize()
+            ctx.comm_barrier()
+            t0 = time.perf_counter()
+            for i in range(K):
+                scanner.compute_only(stacks[i % len(stacks)].ptr, plane)
+            ctx.synchronize()
+            t_compute = time.perf_counter() - t0
+        t_compute = ctx.comm_allreduce_max(t_compute)
+    px = cam_w * cam_h
+    per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
+    info = {"rccl_nranks": G, "exchange": args.exchange, "wire": scanner.wire if args.exchange == "maps" else None,
+            "overlap": not args.no_overlap and args.exchange != "records",
+            "exchange_bytes_per_rank": {"sent": int(rows * cam_w * per_px), "received": int((px - rows * cam_w) * per_px)},
+            "with_exchange_value": round(px / 1e6 * args.steps / elapsed, 1), "unit": "Mpixels/s"}
+    if t_compute:
+        info["compute_only_value"] = round(px / 1e6 * K / t_compute, 1)
+        info["compute_only_note"] = "the same kernels per rank with the exchange left out (what the links would have to keep up with)"
+    return info
+
+
+def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plane_pad, scene="s-scene"):
+    """After the timed region: (1) every rank hashes the reassembled int16 maps and a strided XYZ sample it holds -> all-gather ->
+    must be equal on all ranks; (2) every rank scans the SAME full image (same seed) alone on its own GPU with the fused kernel ->
+    maps must be bit-identical, the XYZ sample equal to float32 resolution."""
+    from scanner import _native
+    px = cam_w * cam_h
+    h, v, xyz = scanner.fetch_dense()
+    sample = xyz.reshape(-1, 3)[::97]
+    mine = digest64(h, v, np.nan_to_num(sample, nan=-1.0))
+    ranks_equal = True
+    allh = ctx.comm_allgather_i64(mine)                      # nranks = 1 (--force-sharded) included: the same calls as on a node
+    ranks_equal = len(allh) == G and all(x == allh[0] for x in allh)
+    full = ctx.alloc(N * px)
+    if scene == "physical":
+        ctx.synth_physical_dev(full.ptr, px, N, cam_h, cam_w, proj_size, row0=0, rows=cam_h, seed=seed, noise=3)
+    else:
+        ctx.synth_scene_dev(full.ptr, px, N, cam_h, cam_w, row0=0, rows=cam_h, seed=seed, noise=3, shadow=True)
+    m1, x1 = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.scan_dev(full.ptr, 1, N * px, px, N, cam_h, cam_w, 0, proj_size, x1.ptr, None, m1.at(0), m1.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+    ctx.synchronize()
+    h1, v1 = m1.download((cam_h, cam_w), np.int16), m1.download((cam_h, cam_w), np.int16, px * 2)
+    s1 = x1.download((px, 3), np.float32)[::97]
+    maps_equal = bool(np.array_equal(h, h1) and np.array_equal(v, v1))
+    fin = np.isfinite(s1).all(axis=1)
+    # bit for bit: the ray-table choice is taken for the whole image (slgc_tune "image_rows"), whatever band a rank scans
+    xyz_equal = bool(np.array_equal(np.isfinite(sample).all(axis=1), fin) and np.array_equal(sample[fin].view(np.uint32), s1[fin].view(np.uint32)))
+    for b in (full, m1, x1):
+        b.free()
+    ok_local = maps_equal and xyz_equal
+    ok_all = ok_local
+    oks = ctx.comm_allgather_i64(1 if ok_local else 0)
+    ok_all = len(oks) == G and all(oks)
+    return {"ok": bool(ranks_equal and ok_all), "ranks_hold_identical_results": bool(ranks_equal), "maps_equal_single_gpu_scan": maps_equal,
+            "xyz_sample_equal_single_gpu_scan": xyz_equal, "valid_pixels": int(((h != -1) & (v != -1)).sum()), "digest": f"{mine:016x}",
+            "note": "every rank compared its reassembled maps and a 1/97 XYZ sample, both bit for bit, with a single-GPU fused scan of the same "
+                    "stack, and its digest with every other rank's"}
+
+
