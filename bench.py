@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "3dscanner-graycode_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-from benchlib.common import PREHEAT_S, WORKLOADS, calibration, csrc_fingerprint  # noqa: E402,F401  (tests and tools use bench.WORKLOADS / bench.calibration)
+from benchlib.common import PREHEAT_S, SCENES, WORKLOADS, calibration, csrc_fingerprint, synth_into  # noqa: E402,F401  (tests and tools use bench.WORKLOADS / bench.calibration)
 from benchlib.legs import throughput_lanes, throughput_step  # noqa: E402,F401
 from benchlib.run import run_rank  # noqa: E402
 
@@ -106,11 +106,16 @@ def main():
                     help="extra bytes between frame planes in HBM (multiple of 16; 0 = contiguous [N,H,W] like the reference)")
     ap.add_argument("--preheat", type=float, default=PREHEAT_S,
                     help="seconds of untimed back-to-back scans before the counted warm-up (clock ramp of a fresh box); 0 under a counter profiler")
-    ap.add_argument("--scene", default="physical", choices=["s-scene", "physical"],
-                    help="synthetic capture of the timed region: the physically consistent plane + sphere scene (slgc_synth_physical_dev: one surface "
-                         "seen by camera and projector through the benchmark calibration, 9-28 %% of the camera pixels lit; default) or SURVEY.md 8(d)'s "
-                         "S-scene (arbitrary smooth code maps, ~80 %% decodable but epipolar-inconsistent).  The kernels do the same work per pixel "
-                         "whether it decodes or not; the other scene is timed as an extra leg of the same run, and the decode-only legs always use the S-scene")
+    ap.add_argument("--scene", default="physical", choices=sorted(SCENES),
+                    help="synthetic capture of the timed region (benchlib/common.py SCENES; every one is also timed as a leg of the default run): physical = "
+                         "plane + sphere seen by camera and projector through the covering rig, > 90 %% of the camera pixels lit by one consistent surface "
+                         "(default); noisy-physical = the same, dim and noisy (wrong codes appear); physical-survey = the same surface through SURVEY.md "
+                         "8(d)'s calibration (9-28 %% lit); s-scene / s-uniform = SURVEY.md 8(d)'s synthetic inputs on SURVEY.md 8(d)'s calibration")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic from this run's own counters: before touching the GPU, start two rocprofv3 --pmc children (FETCH_SIZE, WRITE_SIZE) of "
+                         "a 5-step headline run and fold their bytes per launch into the line (auto: single GPU, default extras, rocprofv3 on PATH; "
+                         "otherwise / on failure the committed constant of profiles/traffic.json is used, and the line says which)")
+    ap.add_argument("--no-small-images", action="store_true", help="skip the BASELINE configs[1] / configs[0] fused-kernel legs of the default run")
     ap.add_argument("--image-rows", type=int, default=0,
                     help="single-GPU band workloads: height of the whole image the band belongs to (slgc_tune image_rows; 0 = the band is the image)")
     ap.add_argument("--sustained", type=float, default=1.0,
@@ -126,6 +131,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
+    args.pmc_live, args.pmc_note = None, "not requested"
+    if args.pmc != "off" and world == 1 and args.gpus == 1 and not args.force_sharded and (args.pmc == "on" or not args.no_extras):
+        from benchlib import pmc
+        cw, ch, _, _, _ = WORKLOADS[args.workload]
+        live, note = pmc.collect(os.path.abspath(__file__), args.workload, args.scene, args.pipeline, grid_size=-(-(cw * ch // 4) // 128) * 128)
+        args.pmc_note = note or "collected"
+        if live:
+            args.pmc_live = {f"{args.pipeline}/{args.scene}": live}
     try:
         run_rank(args, rank, local_rank, world)
     except Exception as e:  # noqa: BLE001

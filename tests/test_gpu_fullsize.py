@@ -197,7 +197,7 @@ def test_throughput_mode_scans_match_oracle(ctx, scene):
     of the scans (one per lane) are compared with the oracle, every pixel."""
     from scanner import _native
     W, H, pw, ph, N = bench.WORKLOADS["c2_1920x1080x44"]
-    calib = bench.calibration(W, H, pw, ph)
+    calib = bench.calibration(W, H, pw, ph, rig=bench.SCENES[scene]["rig"])
     px = W * H
     lanes = bench.throughput_lanes(_native, 0, 16, 2, scene)
     try:

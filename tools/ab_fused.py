@@ -25,21 +25,18 @@ ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--pipeline", default="fused", choices=["fused", "split", "decode"])
 ap.add_argument("--workload", default="c3_4096x3000x44")
-ap.add_argument("--scene", default="physical", choices=["physical", "s-scene"], help="synthetic capture (bench.py --scene)")
+ap.add_argument("--scene", default="physical", choices=sorted(bench.SCENES), help="synthetic capture (bench.py --scene)")
 ap.add_argument("--preheat", type=float, default=0.2, help="seconds of untimed launches first (0 under a counter profiler)")
 args = ap.parse_args()
 
 W, H, pw, ph, N = bench.WORKLOADS[args.workload]
 px = W * H
 ctx = _native.Context(0)
-ctx.set_calibration(*bench.calibration(W, H, pw, ph))
+ctx.set_calibration(*bench.calibration(W, H, pw, ph, rig=bench.SCENES[args.scene]["rig"]))
 stacks = []
 for b in range(max(2, -(-300_000_000 // (N * px)))):
     s = ctx.alloc(N * px)
-    if args.scene == "physical":
-        ctx.synth_physical_dev(s.ptr, px, N, H, W, (pw, ph), seed=1 + b, noise=3)
-    else:
-        ctx.synth_scene_dev(s.ptr, px, N, H, W, seed=1 + b, noise=3, shadow=True)
+    bench.synth_into(ctx, args.scene, s.ptr, px, N, H, W, (pw, ph), 1 + b)
     stacks.append(s)
 maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
 names, values = [], []
@@ -101,7 +98,7 @@ for r in range(args.rounds):
             if args.pipeline != "decode":
                 hsh.update(np.nan_to_num(xyz.download((px * 3,), np.float32), nan=-1.0).data)
             digests[cfg] = hsh.hexdigest()
-print(f"{args.workload} pipeline={args.pipeline} rounds={args.rounds} iters={args.iters}  (first kernel of the step: HIP events bound to its dispatch; step: whole step)")
+print(f"{args.workload} scene={args.scene} pipeline={args.pipeline} rounds={args.rounds} iters={args.iters}  (first kernel of the step: HIP events bound to its dispatch; step: whole step)")
 per_px = (N + 4) if args.pipeline in ("split", "decode") else (N + 12)
 for cfg in configs:
     s = np.sort(np.array(samples[cfg])) * 1e3

@@ -9,14 +9,9 @@ from .common import ROOT, WORKLOADS, calibration
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (N = 1)
-def cpu_baseline():
-    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames) at FULL
-    size: get_codes with the reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the per-pixel Python
-    loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_c as oc
-    import oracle_np as onp
-    cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
+def _port_scan(onp, name):
+    """One decode + triangulate of a BASELINE configuration through the reference-cost port; -> (seconds, seconds get_codes, seconds loops, points)"""
+    cw, ch, pw, ph, n = WORKLOADS[name]
     K, cd, pk, pd, R, T = calibration(cw, ch, pw, ph)
     st, _, _ = onp.synth_scene_int(n, ch, cw, seed=1)
     white = np.repeat(st[1][:, :, None], 3, axis=2)
@@ -27,8 +22,25 @@ def cpu_baseline():
     t_pix = time.perf_counter() - t0 - t_codes
     cam, proj, _ = onp.cam_proj_pts_loops(hp, vp, (cw, ch), (pw, ph), white)
     pts = onp.triangulate(cam, proj, K, cd, pk, pd, R, T)
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0, t_codes, t_pix, pts.shape[1]
+
+
+def cpu_baseline(with_c2=True):
+    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames) and configs[1]
+    (1920x1080, 44 frames) at FULL size: get_codes with the reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the
+    per-pixel Python loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    import oracle_np as onp
+    cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
+    dt, t_codes, t_pix, npts = _port_scan(onp, "c1_1280x720x42")
     mpix = cw * ch / 1e6
+    c2 = None
+    if with_c2:
+        d2, c2_codes, c2_pix, c2_pts = _port_scan(onp, "c2_1920x1080x44")
+        c2 = {"value": round(1920 * 1080 / 1e6 / d2, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+              "sample": f"BASELINE configs[1] at full size: 1920x1080 camera and projector, 44 frames, S-scene, decode + triangulate, {d2:.1f} s "
+                        f"({c2_codes:.1f} s get_codes, {c2_pix:.1f} s gray_to_decimal loops), {c2_pts} points; same port, 1 thread"}
     # strong baseline: the plain-C oracle on the headline workload's own size class (a 2048x1024 crop of the 44-frame scene)
     st2, _, _ = onp.synth_scene_int(44, 1024, 2048, seed=1)
     cal3 = calibration(4096, 3000, 1920, 1200)
@@ -36,25 +48,30 @@ def cpu_baseline():
     oc.scan_dense(st2, (1920, 1200), *cal3)
     dt_c = time.perf_counter() - t1
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    dt_mt, used = None, 1
+    dt_mt, used, sweep = None, 1, {}
     for nthr in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
         oc.set_threads(nthr)
         oc.scan_dense(st2, (1920, 1200), *cal3)                        # thread pool start-up
         t2 = time.perf_counter()
         oc.scan_dense(st2, (1920, 1200), *cal3)
         d = time.perf_counter() - t2
+        sweep[str(nthr)] = round(2048 * 1024 / 1e6 / d, 2)
         if dt_mt is None or d < dt_mt:
             dt_mt, used = d, nthr
     oc.set_threads(1)
     mpix2 = 2048 * 1024 / 1e6
-    return {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"BASELINE configs[0] at full size: {cw}x{ch} camera, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
-                      f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {pts.shape[1]} points; "
-                      "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
-            "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
-                                   "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
-            "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": "plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, 2048x1024x44 crop of the headline scene",
-            "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
-            "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP), best of 8/16/32/64/128/all visible cores, same crop"}
-
-
+    out = {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+           "sample": f"BASELINE configs[0] at full size: {cw}x{ch} camera, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
+                     f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {npts} points; "
+                     "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
+           "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
+                                  "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
+           "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": "plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, 2048x1024x44 crop of the headline scene",
+           "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
+           "c_oracle_threads_sweep_mpix_s": sweep,
+           "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP); the figure is the BEST of the sweep over 8/16/32/64/128/all "
+                                      "visible cores (every point of the sweep is listed): the box shows the host's cores but the job's CPU quota and the "
+                                      "2 MB crop's memory traffic stop the scaling well below them, so more threads than the best point are slower, not faster"}
+    if c2:
+        out["c2"] = c2
+    return out

@@ -4,18 +4,10 @@ import time
 
 import numpy as np
 
-from .common import HBM_PEAK_GBS, WORKLOADS, calibration
+from .common import HBM_PEAK_GBS, SCENES, WORKLOADS, calibration, synth_into
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]
-def synth_into(c, scene, d_ptr, plane, n, H, W, proj_size, seed, row0=0, rows=None):
-    """One synthetic capture into HBM: the physically consistent scene (needs the context's calibration) or SURVEY 8(d)'s S-scene."""
-    if scene == "physical":
-        c.synth_physical_dev(d_ptr, plane, n, H, W, proj_size, row0=row0, rows=rows, seed=seed, noise=3)
-    else:
-        c.synth_scene_dev(d_ptr, plane, n, H, W, row0=row0, rows=rows, seed=seed, noise=3, shadow=True)
-
-
 def throughput_lanes(_native, device, per_rank, n_streams=2, scene="s-scene"):
     """BASELINE.json configs[4] on one GPU: `n_streams` contexts (HIP streams), each with its own rotated 1920x1080x44 stacks
     (>= 4 distinct stacks in total: 364 MB > Infinity Cache) and one set of output buffers.  -> [(ctx, stacks, maps, xyz)]"""
@@ -24,7 +16,7 @@ def throughput_lanes(_native, device, per_rank, n_streams=2, scene="s-scene"):
     lanes = []
     for sidx in range(max(1, n_streams)):
         c = _native.Context(device)
-        c.set_calibration(*calibration(cw, ch, pw, ph))
+        c.set_calibration(*calibration(cw, ch, pw, ph, rig=SCENES[scene]["rig"]))
         stacks = []
         for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):
             st = c.alloc(n * px)
@@ -55,7 +47,7 @@ def throughput_batched(ctx, _native, G, steps, mode, device, collective=False, s
     px = cw * ch
     per_rank = max(1, 16 // G)
     c = _native.Context(device)
-    c.set_calibration(*calibration(cw, ch, pw, ph))
+    c.set_calibration(*calibration(cw, ch, pw, ph, rig=SCENES[scene]["rig"]))
     sets = []
     for b in range(3):
         st = c.alloc(per_rank * n * px)
@@ -117,11 +109,61 @@ def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2, collectiv
 
 
 
-def physical_accuracy(ctx, N, H, W, row0, rows, plane, proj_size, calib, maps, xyz, band_px, mode_fused):
-    """Recovered XYZ of one fused scan of the physical scene against the generator's TRUE surface points (not against the oracle): the error
-    is the method's -- half a projector pixel of code quantisation seen through the triangulation geometry."""
+def small_image_legs(_native, device, steps, mode_fused, workloads=("c2_1920x1080x44", "c1_1280x720x42"),
+                     scenes=("physical", "s-scene", "s-uniform", "noisy-physical")):
+    """BASELINE configs[1] / configs[0] sizes (one round of resident waves: head and tail of the kernel stay exposed) through the fused kernel on
+    every synthetic capture, in the default run: kernel time from HIP events bound to the dispatches, rotated stacks > Infinity Cache."""
+    out = {}
+    for wl in workloads:
+        cw, ch, pw, ph, n = WORKLOADS[wl]
+        px = cw * ch
+        c = _native.Context(device)
+        maps, xyz, cnt = c.alloc(px * 4), c.alloc(px * 12), c.alloc(16)
+        rows = {}
+        for scene in scenes:
+            c.set_calibration(*calibration(cw, ch, pw, ph, rig=SCENES[scene]["rig"]))
+            stacks = []
+            for b in range(max(2, -(-300_000_000 // (n * px)))):
+                st = c.alloc(n * px)
+                synth_into(c, scene, st.ptr, px, n, ch, cw, (pw, ph), 21 + b)
+                stacks.append(st)
+
+            def scan(i):
+                c.scan_dev(stacks[i % len(stacks)].ptr, 1, n * px, px, n, ch, cw, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode_fused)
+
+            for i in range(4):
+                scan(i)
+            c.synchronize()
+            K = max(10, steps)
+            c.prof_begin(K + 8, 1)
+            t0 = time.perf_counter()
+            for i in range(K):
+                scan(i)
+            c.synchronize()
+            el = time.perf_counter() - t0
+            kms, kn = c.prof_end()
+            path = c.last_scan_path()
+            cnt.zero()
+            c.guard_count_dev(maps.at(0), maps.at(px * 2), ch, cw, 0, (pw, ph), cnt.ptr)
+            c.synchronize()
+            valid, flagged = (int(x) for x in cnt.download((2,), np.uint64))
+            avg = kms / max(1, kn)
+            rows[scene] = {"avg_launch_ms": round(avg, 5), "frac": round((n + 12) * px / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "ms_per_step": round(el / K * 1e3, 5), "value": round(px / 1e6 * K / el, 1), "valid_pixels_per_scan": valid,
+                           "guard_flagged_pixels": flagged, "path": path["path"], "launches_timed": kn}
+            for st in stacks:
+                st.free()
+        out[wl] = {"workload": f"{cw}x{ch} cam, {pw}x{ph} proj, {n} frames", "algorithmic_bytes_per_px": n + 12, "scenes": rows}
+        c.close()
+    return out
+
+
+def physical_accuracy(ctx, N, H, W, row0, rows, plane, proj_size, scene, maps, xyz, band_px, mode_fused):
+    """Recovered XYZ of one fused scan of a physical scene against the generator's TRUE surface points (not against the oracle): the error
+    is the method's -- half a projector pixel of code quantisation seen through the triangulation geometry.  The context's calibration must
+    be the scene's rig."""
     st, truth = ctx.alloc(max(16, N * plane)), ctx.alloc(max(16, band_px * 12))
-    ctx.synth_physical_dev(st.ptr, plane, N, H, W, proj_size, row0=row0, rows=rows, seed=1, noise=3, d_truth_xyz=truth.ptr)
+    synth_into(ctx, scene, st.ptr, plane, N, H, W, proj_size, 1, row0=row0, rows=rows, d_truth_xyz=truth.ptr)
     ctx.scan_dev(st.ptr, 1, N * plane, plane, N, rows, W, row0, proj_size, xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode_fused)
     ctx.synchronize()
     got = xyz.download((band_px, 3), np.float32)[::5]
@@ -133,7 +175,7 @@ def physical_accuracy(ctx, N, H, W, row0, rows, plane, proj_size, calib, maps, x
     truth.free()
     if not err.size:
         return {"error": "no lit pixel decoded"}
-    return {"pixels_compared": int(ok.sum()), "sampling": "every 5th pixel", "median_error_mm": round(float(np.median(err)) * 1e3, 4),
+    return {"scene": scene, "pixels_compared": int(ok.sum()), "sampling": "every 5th pixel", "median_error_mm": round(float(np.median(err)) * 1e3, 4),
             "max_error_mm": round(float(err.max()) * 1e3, 4), "max_relative_error": float(f"{float((err / rng).max()):.3e}"),
             "range_m": [round(float(rng.min()), 3), round(float(rng.max()), 3)],
             "note": "|recovered - true surface point| of a fused scan of the physical scene; the truth comes from the generator's ray casting, "

@@ -6,10 +6,10 @@ import time
 
 import numpy as np
 
-from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, STAGE, WORKLOADS, calibration, csrc_fingerprint, digest64, launch_stats,
-                     workload_label)
+from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, SCENES, STAGE, WORKLOADS, calibration, csrc_fingerprint, digest64, launch_stats,
+                     synth_into, workload_label)
 from .cpu import cpu_baseline
-from .legs import physical_accuracy, reference_product, sustained_leg, throughput_batched, throughput_mode
+from .legs import physical_accuracy, reference_product, small_image_legs, sustained_leg, throughput_batched, throughput_mode
 from .sharded_legs import sharded_report, verify_sharded
 
 
@@ -46,8 +46,15 @@ def run_rank(args, rank, local_rank, world):
     n_dev = max(1, _native.device_count())
     device = local_rank % n_dev                 # a launcher that narrows device visibility per rank leaves only device 0 visible
     ctx = _native.Context(device)
-    calib = calibration(cam_w, cam_h, proj_w, proj_h)
-    ctx.set_calibration(*calib)
+    rig_now = [SCENES[args.scene]["rig"]]             # the calibration the context holds: every synthetic capture belongs to a rig (common.SCENES)
+    ctx.set_calibration(*calibration(cam_w, cam_h, proj_w, proj_h, rig=rig_now[0]))
+
+    def use_rig(rig):
+        """Switch the context to another rig's calibration (the next scan rebuilds the ray tables: legs run their warm-up after this)."""
+        if rig != rig_now[0]:
+            ctx.synchronize()
+            ctx.set_calibration(*calibration(cam_w, cam_h, proj_w, proj_h, rig=rig))
+            rig_now[0] = rig
     if G == 1 and args.force_sharded:
         ctx.comm_init(0, 1, _native.Context.comm_unique_id())
     if G > 1:
@@ -75,14 +82,16 @@ def run_rank(args, rank, local_rank, world):
     plane = band_px + args.plane_pad        # each rank holds only its row band of every frame; pad 0 = the reference's contiguous [N,H,W]
     if args.buffers <= 0:                                   # enough distinct stacks to exceed the 256 MB Infinity Cache
         args.buffers = max(2, -(-300_000_000 // max(1, N * plane)))
-    def make_stacks(scene):
+    def make_stacks(scene, n_runs=1):
+        """args.buffers rotated captures of `scene` (n_runs > 1: that many captures of the same scene back to back in one buffer, N * plane apart,
+        each with its own noise -- the reference's MAX_NB_RUNS repeats, src/3-capture_decode.py:48)."""
+        use_rig(SCENES[scene]["rig"])
         out_ = []
         for b in range(max(1, args.buffers)):
-            s = ctx.alloc(max(16, N * plane))
-            if rows and scene == "physical":
-                ctx.synth_physical_dev(s.ptr, plane, N, cam_h, cam_w, (proj_w, proj_h), row0=row0, rows=rows, seed=1 + b, noise=3)
-            elif rows:
-                ctx.synth_scene_dev(s.ptr, plane, N, cam_h, cam_w, row0=row0, rows=rows, seed=1 + b, noise=3, shadow=True)
+            s = ctx.alloc(max(16, n_runs * N * plane))
+            for r in range(n_runs):
+                if rows:
+                    synth_into(ctx, scene, s.at(r * N * plane) if r else s.ptr, plane, N, cam_h, cam_w, (proj_w, proj_h), 1 + b + 100 * r, row0=row0, rows=rows)
             out_.append(s)
         return out_
 
@@ -110,14 +119,14 @@ def run_rank(args, rank, local_rank, world):
     ctx.synchronize()
     pipelined = use_comm and args.exchange in ("maps", "xyz") and not args.no_overlap
 
-    def step(i, counted=False, mode=mode, src=None, no_maps=False):
+    def step(i, counted=False, mode=mode, src=None, no_maps=False, n_runs=1):
         src = stacks if src is None else src
         s = src[i % len(src)]
         if pipelined:
             return sharded_scanner.submit(s.ptr, plane)      # exchange of this scan overlaps the neighbours' kernels
         if use_comm:
             return sharded_scanner.scan(s.ptr, plane)
-        ctx.scan_dev(s.ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
+        ctx.scan_dev(s.ptr, n_runs, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, count.ptr if counted else None,
                      None if no_maps else maps.at(0), None if no_maps else maps.at(band_px * 2), mode=mode)
         return None
 
@@ -126,7 +135,8 @@ def run_rank(args, rank, local_rank, world):
             sharded_scanner.flush()
         ctx.synchronize()
 
-    def timed(K, W_, stride=None, preheat=True, **kw):
+    def timed(K, W_, stride=None, preheat=True, scene=None, **kw):
+        use_rig(SCENES[scene or args.scene]["rig"])
         if preheat and args.preheat > 0:                     # untimed: bring the clocks up before the counted warm-up
             t_end = time.perf_counter() + args.preheat
             i = 0
@@ -176,22 +186,58 @@ def run_rank(args, rank, local_rank, world):
         ctx.synchronize()
         return tuple(int(x) for x in count.download((2,), np.uint64))
 
-    other_scene = None
+    def time_decode(src):
+        """the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way) -> (ms, launches, samples), path"""
+        for i in range(3):
+            ctx.decode_dev(src[i % len(src)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        ctx.synchronize()
+        ctx.prof_begin(args.steps + 8)
+        for i in range(args.steps):
+            ctx.decode_dev(src[i % len(src)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
+        return ctx.prof_end() + (ctx.prof_samples(),), ctx.last_scan_path()
+
+    # ---- the same kernels on every synthetic capture of common.SCENES (SURVEY.md 8(d) names S-uniform as the worst case and the S-scene as the
+    # realistic one; the physical ones are what a scanner sees): fused scan + decode kernel timed, valid / guard-flagged pixels counted
+    scene_legs = {}
+    s_scene_stacks = stacks if args.scene == "s-scene" else None
     if extras:
-        # the same kernel on the other synthetic capture: S-scene = arbitrary smooth code maps (epipolar-inconsistent: part of its pixels
-        # takes the guarded float64 path), physical = one surface seen by camera and projector (few lit pixels with these calibrations)
-        o_name = "physical" if args.scene == "s-scene" else "s-scene"
-        o_stacks = make_stacks(o_name)
-        s_scene_stacks = o_stacks if o_name == "s-scene" else stacks
-        o_el, o_kms, o_kn, _, o_samples = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, src=o_stacks)
-        o_exec = ctx.last_scan_path()
-        o_valid, o_flag = scene_stats(o_stacks)
-        acc = None
-        if o_name == "physical" or args.scene == "physical":
-            acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), calib, maps, xyz, band_px, mode_fused)
-        other_scene = (o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc)
+        for name in ("s-scene", "s-uniform", "noisy-physical", "physical"):
+            if name == args.scene or (SCENES[name]["kind"] == "uniform" and (cam_w % 4 or plane % 4)):
+                continue
+            STAGE[0] = f"scene leg {name}"
+            st = make_stacks(name)
+            o_el, o_kms, o_kn, _, o_samples = timed(args.steps, max(2, args.warmup // 2), preheat=False, scene=name, mode=mode_fused, src=st)
+            o_exec = ctx.last_scan_path()
+            o_valid, o_flag = scene_stats(st)
+            o_dec, o_dec_exec = time_decode(st)
+            acc = None
+            if SCENES[name]["kind"] == "physical":
+                acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), name, maps, xyz, band_px, mode_fused)
+            scene_legs[name] = (o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc, o_dec, o_dec_exec)
+            if name == "s-scene":
+                s_scene_stacks = st
+            else:
+                for b in st:
+                    b.free()
+        STAGE[0] = "extras"
+    head_acc = None
+    if extras and SCENES[args.scene]["kind"] == "physical":
+        use_rig(SCENES[args.scene]["rig"])
+        head_acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), args.scene, maps, xyz, band_px, mode_fused)
+    head_dec = None
+    if extras:
+        head_dec = time_decode(stacks)
+
+    # ---- two captures per scan, max-merged per code bit inside the kernel (the reference always merges MAX_NB_RUNS = 2: src/3-capture_decode.py:48,95-96)
+    two_runs = None
+    if extras:
+        pairs = make_stacks(args.scene, n_runs=2)
+        two_runs = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, src=pairs, n_runs=2) + (ctx.last_scan_path(),)
+        for b in pairs:
+            b.free()
 
     sustained = None
+    use_rig(SCENES[args.scene]["rig"])
     if single and not args.no_extras and args.sustained > 0:
         sustained = sustained_leg(ctx, step, drain, args.sustained, cam_w * rows / 1e6)
 
@@ -209,15 +255,7 @@ def run_rank(args, rank, local_rank, world):
 
     dec_alone = None
     if extras:
-        # the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way)
-        for i in range(3):
-            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
-        ctx.synchronize()
-        ctx.prof_begin(args.steps + 8)
-        for i in range(args.steps):
-            ctx.decode_dev(s_scene_stacks[i % len(stacks)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
-        dec_alone = ctx.prof_end() + (ctx.prof_samples(),)
-        dec_alone_exec = ctx.last_scan_path()
+        dec_alone, dec_alone_exec = time_decode(s_scene_stacks)
 
     movement = None
     if extras and N in (42, 44, 46) and band_px % 256 == 0 and plane % 4 == 0:
@@ -240,6 +278,7 @@ def run_rank(args, rank, local_rank, world):
 
     ref_product = None
     if extras and row0 == 0:
+        use_rig(SCENES["s-scene"]["rig"])
         ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
         ref_product["scene"] = "s-scene"
 
@@ -248,7 +287,14 @@ def run_rank(args, rank, local_rank, world):
         thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
         thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
 
+    small = None
+    if extras and args.workload == "c3_4096x3000x44" and not args.no_small_images:
+        STAGE[0] = "small images"
+        small = small_image_legs(_native, device, args.steps, mode_fused)
+        STAGE[0] = "extras"
+
     # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
+    use_rig(SCENES[args.scene]["rig"])
     count.zero()
     if not use_comm:
         ctx.scan_dev(stacks[0].ptr, 1, N * plane, plane, N, rows, cam_w, row0, (proj_w, proj_h), xyz.ptr, None, maps.at(0), maps.at(band_px * 2), mode=mode)
@@ -287,12 +333,13 @@ def run_rank(args, rank, local_rank, world):
             spec = f"NS={ex['ns_frames']} (threshold frames parked in LDS)" if ex["ns_frames"] else "generic frame count"
             if pipeline == "split":
                 return f"k_decode_pk<4,128,nt> {spec}"
-            return f"k_decode_pk<4,128,nt,FUSE=2> {spec} + triangulation tail (camera rays: {'node table' if ex['node_table'] else 'per-pixel table'})"
+            return f"k_decode_pk<4,128,nt,FUSE> {spec} + triangulation tail (camera rays: {'node table' if ex['node_table'] else 'per-pixel table'})"
 
-        def kernel_roofline(pipeline, kms, kn, samples, ex=None, scene=None):
+        def kernel_roofline(pipeline, kms, kn, samples, ex=None, scene=None, n_runs=1):
             """SURVEY.md 8(d) byte definitions: decode kernel N + 4 B/pixel (N uint8 reads, 2 int16 writes); fused decode -> XYZ
-            N + 12 B/pixel.  The fused kernel also writes the 4 B/pixel maps (a product): frac_incl_maps counts them too."""
-            per_px = (N + 4) if pipeline == "split" else (N + 12)
+            N + 12 B/pixel (n_runs captures per scan: n_runs * N frame bytes).  The fused kernel also writes the 4 B/pixel maps (a product):
+            frac_incl_maps counts them too."""
+            per_px = (n_runs * N + 4) if pipeline == "split" else (n_runs * N + 12)
             avg_ms = kms / max(1, kn)
             ach = per_px * band_px / (avg_ms * 1e-3) / 1e9
             r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -300,18 +347,26 @@ def run_rank(args, rank, local_rank, world):
                  "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, **launch_stats(samples),
                  "algorithmic_bytes_per_px": per_px, "algorithmic_bytes_per_launch": per_px * band_px}
             if pipeline != "split":
-                r["frac_incl_maps"] = round((N + 16) * band_px / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                r["frac_incl_maps"] = round((n_runs * N + 16) * band_px / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 r["frac_incl_maps_note"] = "N + 16 B/pixel: the 4 B/pixel int16 maps the fused kernel also writes counted as algorithmic"
-            t = traffic_db.get(f"{args.workload}/g{G}/{pipeline}")
-            if t and t.get("csrc_fingerprint") == fp:
-                # the counters were collected per scene for the fused kernel (tools/pmc.sh): fewer lit pixels = fewer projector-table lines gathered
-                sc = scene or args.scene
-                r["traffic"] = t.get("s_scene_hbm_bytes_per_launch") if (sc == "s-scene" and pipeline != "split" and "s_scene_hbm_bytes_per_launch" in t) else t["hbm_bytes_per_launch"]
-                r["traffic_source"] = t.get("source")
-                r["traffic_scene"] = "s-scene" if (pipeline == "split" or sc == "s-scene") else "physical"
+            sc = scene or args.scene
+            live = (getattr(args, "pmc_live", None) or {}).get(f"{pipeline}/{sc}") if n_runs == 1 else None
+            t = traffic_db.get(f"{args.workload}/g{G}/{pipeline}/{sc}") if n_runs == 1 else None
+            if live:
+                # counters collected by THIS run: bench.py started rocprofv3 --pmc children (FETCH_SIZE, WRITE_SIZE: separate passes, no tracing)
+                # before touching the GPU (benchlib/pmc.py)
+                r["traffic"] = live["hbm_bytes_per_launch"]
+                r["traffic_source"] = live["source"]
+                r["traffic_scene"] = sc
+            elif t and t.get("csrc_fingerprint") == fp:
+                r["traffic"] = t["hbm_bytes_per_launch"]
+                r["traffic_source"] = "committed constant (profiles/traffic.json, same kernel sources by fingerprint): " + str(t.get("source"))
+                r["traffic_scene"] = sc
             elif t:
                 r["traffic_note"] = ("profiles/traffic.json was measured on other kernel sources (fingerprint mismatch): stale, not reported; "
                                      "re-run tools/pmc.sh")
+            if r["traffic"]:
+                r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
             return r
 
         main_pipeline = "split" if (use_comm and args.exchange == "maps") else args.pipeline
@@ -328,8 +383,10 @@ def run_rank(args, rank, local_rank, world):
                                     else {"fused": "fused (one kernel)", "batch-fused": "fused (one kernel, batched)", "split": "split (decode kernel + triangulation kernel)",
                                           "split-ragged": "split (decode kernel + triangulation kernel, with byte-wide / per-pixel fallback kernels)"}.get(executed["path"], executed["path"])),
                        "executed": {**executed, "source": "slgc_last_scan_path after the timed region", "requested_pipeline": args.pipeline},
-                       "scene": {"s-scene": "S-scene (SURVEY.md 8(d): smooth synthetic code maps, shadow rectangle, noise 3)",
-                                 "physical": "physical (plane + sphere seen by camera and projector through the calibration, noise 3)"}[args.scene],
+                       "scene": SCENES[args.scene]["label"], "scene_name": args.scene, "rig": SCENES[args.scene]["rig"],
+                       "rig_note": "survey = SURVEY.md 8(d)'s calibration; covering = the same camera and stereo pose with a projector whose addressable "
+                                   "2^L x 2^L raster covers the camera's field of view (benchlib/common.py: calibration)",
+                       "valid_pixels_per_scan": valid, "valid_fraction": round(valid / max(1, band_px), 4) if valid is not None else None,
                        "rows_per_gpu": rows, "triangulation": args.mode + "/" + args.tri, "input_buffers_rotated": len(stacks), "plane_pad_bytes": args.plane_pad,
                        "outputs": "int16 h/v maps + dense float32 XYZ in HBM" + ("" if not use_comm else "; whole cloud reassembled on every rank"),
                        "preheat_s": args.preheat, "event_stride": args.event_stride,
@@ -345,6 +402,7 @@ def run_rank(args, rank, local_rank, world):
             "roofline": kernel_roofline(main_pipeline, dec_ms, dec_n, dec_samples),
             "valid_pixels_per_scan": valid,
             "device": ctx.device_name(),
+            "pmc": {"requested": getattr(args, "pmc", "off"), "result": getattr(args, "pmc_note", None)},
         }
         if shard_info:
             out["sharded"] = shard_info
@@ -381,25 +439,51 @@ def run_rank(args, rank, local_rank, world):
                                        "skipped; XYZ bit-identical (tests/test_gpu_fullsize.py).  NOT the headline: the reference's decode script "
                                        "keeps the maps, so `value` is measured with them stored"}
         if dec_alone is not None:
-            dr = kernel_roofline("split", *dec_alone, ex=dec_alone_exec)
+            dr = kernel_roofline("split", *dec_alone, ex=dec_alone_exec, scene="s-scene")
             if movement is not None:
                 beside(dr, "decode_ms")
             out["decode_kernel_alone"] = {"roofline": dr, "scene": "s-scene",
                                           "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "
                                                   "kernel's heavier input), same run (the north star's >= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
+        if small is not None:
+            out["small_images"] = small
         if ref_product is not None:
             out["reference_product"] = ref_product
         if sustained is not None:
             out["sustained"] = sustained
-        if other_scene is not None:
-            o_name, o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc = other_scene
-            out["other_scene"] = {"scene": o_name, "value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
-                                  "ms_per_step": round(o_el / args.steps * 1e3, 4), "executed": o_exec,
-                                  "roofline": kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec, scene=o_name),
-                                  "valid_pixels_per_scan": o_valid, "guard_flagged_pixels": o_flag,
-                                  "note": "the headline step on the other synthetic capture, same run (bench.py --scene picks which one is the headline)"}
-            if acc is not None:
-                out["physical_scene_accuracy"] = acc
+        if extras:
+            # one table over every synthetic capture: fused scan + decode kernel, valid / guard-flagged pixels
+            table = {args.scene: {"scene": SCENES[args.scene]["label"], "rig": SCENES[args.scene]["rig"], "headline": True, "value": round(value, 1), "unit": "Mpixels/s",
+                                  "ms_per_step": round(ms_per_step, 4), "frac": out["roofline"]["frac"], "avg_launch_ms": out["roofline"]["avg_launch_ms"],
+                                  "valid_pixels_per_scan": valid, "guard_flagged_pixels": flagged, "executed": executed,
+                                  "decode_kernel": (lambda d: {"frac": d["frac"], "avg_launch_ms": d["avg_launch_ms"]})(kernel_roofline("split", *head_dec[0], ex=head_dec[1]))}}
+            for name, (o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc, o_dec, o_dec_exec) in scene_legs.items():
+                fr = kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec, scene=name)
+                dr = kernel_roofline("split", *o_dec, ex=o_dec_exec, scene=name)
+                table[name] = {"scene": SCENES[name]["label"], "rig": SCENES[name]["rig"], "value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
+                               "ms_per_step": round(o_el / args.steps * 1e3, 4), "frac": fr["frac"], "avg_launch_ms": fr["avg_launch_ms"],
+                               "fused_time_over_s_scene": None, "valid_pixels_per_scan": o_valid, "guard_flagged_pixels": o_flag, "executed": o_exec,
+                               "roofline": fr, "decode_kernel": {"frac": dr["frac"], "avg_launch_ms": dr["avg_launch_ms"], "roofline": dr}}
+                if acc is not None:
+                    table[name]["accuracy_vs_true_surface"] = acc
+            ref_ms = table.get("s-scene", {}).get("avg_launch_ms")
+            for name, row in table.items():
+                row["fused_time_over_s_scene"] = round(row["avg_launch_ms"] / ref_ms, 3) if ref_ms else None
+            out["scenes"] = table
+            if "s-scene" in scene_legs:                      # (kept under its old key as well)
+                row = table["s-scene"]
+                out["other_scene"] = {"scene": "s-scene", "value": row["value"], "unit": "Mpixels/s", "ms_per_step": row["ms_per_step"], "executed": row["executed"],
+                                      "roofline": row["roofline"], "valid_pixels_per_scan": row["valid_pixels_per_scan"],
+                                      "guard_flagged_pixels": row["guard_flagged_pixels"],
+                                      "note": "the headline step on SURVEY.md 8(d)'s S-scene with SURVEY.md 8(d)'s calibration, same run (the like-for-like figure of earlier rounds)"}
+            if head_acc is not None:
+                out["physical_scene_accuracy"] = head_acc
+        if two_runs is not None:
+            t_el, t_kms, t_kn, _, t_samples, t_exec = two_runs
+            out["two_runs"] = {"value": round(mpix_per_step * args.steps / t_el, 1), "unit": "Mpixels/s", "ms_per_step": round(t_el / args.steps * 1e3, 4), "executed": t_exec,
+                               "roofline": kernel_roofline("fused" if t_exec["path"] == "fused" else "split", t_kms, t_kn, t_samples, t_exec, n_runs=2),
+                               "note": "n_runs = 2: two captures of the headline scene (independent noise) per scan, max-merged per code bit inside the kernel "
+                                       "like the reference's MAX_NB_RUNS = 2 (src/3-capture_decode.py:48,95-96); 2 N + 12 algorithmic bytes per pixel"}
         if thr is not None:
             t_el, t_scans, t_mpix = thr
             t_steps = max(5, args.steps // 4)

@@ -3,7 +3,7 @@ import time
 
 import numpy as np
 
-from .common import digest64
+from .common import digest64, synth_into
 
 
 def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, cam_h, row0, proj_size, mode, elapsed):
@@ -45,10 +45,7 @@ def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plan
     allh = ctx.comm_allgather_i64(mine)                      # nranks = 1 (--force-sharded) included: the same calls as on a node
     ranks_equal = len(allh) == G and all(x == allh[0] for x in allh)
     full = ctx.alloc(N * px)
-    if scene == "physical":
-        ctx.synth_physical_dev(full.ptr, px, N, cam_h, cam_w, proj_size, row0=0, rows=cam_h, seed=seed, noise=3)
-    else:
-        ctx.synth_scene_dev(full.ptr, px, N, cam_h, cam_w, row0=0, rows=cam_h, seed=seed, noise=3, shadow=True)
+    synth_into(ctx, scene, full.ptr, px, N, cam_h, cam_w, proj_size, seed, row0=0, rows=cam_h)
     m1, x1 = ctx.alloc(px * 4), ctx.alloc(px * 12)
     ctx.scan_dev(full.ptr, 1, N * px, px, N, cam_h, cam_w, 0, proj_size, x1.ptr, None, m1.at(0), m1.at(px * 2), mode=_native.TRI_ALGEBRAIC)
     ctx.synchronize()
