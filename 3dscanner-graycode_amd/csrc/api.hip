@@ -1182,6 +1182,49 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     return SLGC_OK;
 }
 
+// The scan straight from the camera's BGR frames (src/3-capture_decode.py:66-70: cv2.cvtColor(BGR2GRAY) into the grey stack, :75 get_codes on it):
+// d_bgr = [n_runs][N][rows][W][3] uint8, plane_stride = bytes between consecutive frames (>= 3 * rows * W).  One kernel when the shape allows
+// (N = 42 / 44 / 46, 4-byte aligned planes, algebraic mode, no count): the luma is formed in registers inside the frame loads and the grey stack
+// never exists in HBM -- 3 N + 12 bytes per pixel instead of 3 N + N (written) + N (read back) + 12.  Any other shape: slgc_to_gray_dev into
+// scratch of the context, then slgc_scan_dev.  Maps and XYZ are bit-identical either way (same luma, same kernels behind it).
+extern "C" int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int row0,
+                                 int proj_w, int proj_h, int coeff_bits, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz,
+                                 unsigned long long *d_count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!d_bgr || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
+    if (mode < 0 || mode > 7) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    if (rows < 0 || W < 0 || plane_stride < 3 * (size_t)rows * W) return slgc_fail(ctx, SLGC_EINVAL, "plane_stride smaller than a BGR band");
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d", N, n_runs);
+    if (!decode_fast_eligible(eps, &e)) return slgc_fail(ctx, SLGC_EINVAL, "device-resident scans need an integer eps in [0,255] (got %g)", eps);
+    for (int r = 0; r < n_runs; ++r) runs.p[r] = d_bgr + (size_t)r * run_stride;
+    if (!d_h || !d_v) d_h = d_v = nullptr;
+    const size_t npix = (size_t)rows * W;
+    if ((mode & 3) == SLGC_TRI_ALGEBRAIC && !(mode & SLGC_TRI_SPLIT) && !d_count && proj_w >= 1 && proj_h >= 1 && (size_t)proj_w * proj_h < (1u << 28) &&
+        scan_bgr_eligible(ctx, g, runs, plane_stride, npix, d_h, d_v, d_xyz)) {
+        if ((rc = ensure_luts(ctx, rows, W, row0, proj_w, proj_h))) return rc;
+        if ((rc = prof_mark(ctx, 0))) return rc;
+        if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h, 1, 0, coeff_bits))) return rc;
+        ctx->last_scan_path = SLGC_PATH_FUSED_BGR;
+        return prof_mark(ctx, 1);
+    }
+    // grey stack in scratch, frames packed back to back, then the ordinary scan
+    void *gray;
+    const size_t gplane = (npix + 15) & ~(size_t)15;
+    if ((rc = slgc_ws(ctx, 11, (size_t)n_runs * N * gplane + 64, &gray))) return rc;
+    for (int r = 0; r < n_runs; ++r)
+        for (int f = 0; f < N; ++f)
+            if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)runs.p[r] + (size_t)f * plane_stride, (uint8_t *)gray + ((size_t)r * N + f) * gplane, npix, coeff_bits)))
+                return rc;
+    return slgc_scan_dev(ctx, (const uint8_t *)gray, n_runs, (size_t)N * gplane, gplane, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h, d_v, d_xyz, d_count);
+}
+
 // Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry, their stacks scan_stride bytes apart, in ONE
 // launch of the fused kernel when every scan is a whole number of its 512-pixel workgroups -- a 1920x1080 scan alone is one round of
 // resident waves (all of them in the same phase of the kernel at the same time); sixteen of them overlap like a large image does.
@@ -1355,6 +1398,16 @@ extern "C" int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t p
 {
     return slgc_synth_physical_ex_dev(ctx, d_stack, plane_stride, N, H, W, row0, rows, proj_w, proj_h, seed, noise, 140, 180, 0.16, d_h_true, d_v_true,
                                       d_truth_xyz);
+}
+
+extern "C" int slgc_synth_bgr_dev(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_plane_stride, int N, int H, int W, int row0, int rows, uint8_t *d_bgr,
+                                  size_t bgr_plane_stride)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_gray || !d_bgr || N < 1 || rows < 0 || W < 0 || row0 < 0 || row0 + rows > H || gray_plane_stride < (size_t)rows * W || bgr_plane_stride < 3 * (size_t)rows * W)
+        return slgc_fail(ctx, SLGC_EINVAL, "bad synth arguments");
+    return launch_synth_bgr(ctx, d_gray, gray_plane_stride, N, W, row0, rows, d_bgr, bgr_plane_stride);
 }
 
 extern "C" int slgc_synth_uniform_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed)

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(BLOCK) k_decode_fast(const FastArgs a)
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 typedef short v2ss __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 struct FuseArgs {            // triangulation appended to the decode kernel (slgc_scan_dev)
@@ -263,6 +264,29 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     double T[3], t_len;
 };
 
+// cv2.cvtColor(BGR2GRAY) on 8-bit pixels inside the frame load (src/3-capture_decode.py:66): Y = (B*BY + G*GY + R*RY + rnd) >> shift.
+// A lane's 4 pixels arrive as 12 bytes B0 G0 R0 B1 G1 R1 B2 G2 R2 B3 G3 R3 in three dwords; pixel 0 IS dword 0 with a zero coefficient for
+// its 4th byte, pixels 1 and 2 are two v_alignbyte_b32 away, pixel 3 is dword 2 with a zero coefficient for its 1st byte.  The 14 / 15-bit
+// coefficients are split into high and low bytes so that each pixel is two v_dot4_u32_u8 and one v_lshl_add_u32:
+//     Y * 2^shift + remainder = (dot(px, hi) << 8) + dot(px, lo) + rnd          (< 2^23)
+// -> the grey dword [Y0 Y1 Y2 Y3] the rest of the kernel works on (21 full-rate instructions per frame and lane).
+struct Luma {
+    uint32_t a_hi, a_lo;     // coefficient bytes [BY, GY, RY, 0], high / low byte of each
+    uint32_t z_hi, z_lo;     // [0, BY, GY, RY]
+    uint32_t rnd, shift;
+};
+
+__device__ __forceinline__ uint32_t bgr4_to_gray(uint32_t w0, uint32_t w1, uint32_t w2, const Luma &c)
+{
+    const uint32_t p1 = __builtin_amdgcn_alignbyte(w1, w0, 3), p2 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+    const uint32_t y0 = (__builtin_amdgcn_udot4(w0, c.a_hi, 0u, false) << 8) + __builtin_amdgcn_udot4(w0, c.a_lo, c.rnd, false);
+    const uint32_t y1 = (__builtin_amdgcn_udot4(p1, c.a_hi, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, c.a_lo, c.rnd, false);
+    const uint32_t y2 = (__builtin_amdgcn_udot4(p2, c.a_hi, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, c.a_lo, c.rnd, false);
+    const uint32_t y3 = (__builtin_amdgcn_udot4(w2, c.z_hi, 0u, false) << 8) + __builtin_amdgcn_udot4(w2, c.z_lo, c.rnd, false);
+    const uint32_t e = (y0 >> c.shift) | ((y2 >> c.shift) << 16), o = (y1 >> c.shift) | ((y3 >> c.shift) << 16);
+    return e | (o << 8);
+}
+
 struct PkArgs {
     FuseArgs f;
     const uint8_t *run[SLGC_MAX_RUNS];
@@ -273,6 +297,7 @@ struct PkArgs {
     int16_t *v;
     DecodeGeom g;
     int e;
+    Luma lum;                // BGR kernels only (slgc_scan_bgr_dev): cv2.cvtColor's fixed-point luma
 };
 
 __device__ __forceinline__ v2us as_us(uint32_t x) { return __builtin_bit_cast(v2us, x); }
@@ -300,6 +325,9 @@ __device__ __forceinline__ Frame<NW, NT> load_frame(__amdgpu_buffer_rsrc_t rs, u
     } else if constexpr (NW == 2) {
         const v2u t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux);
         f.w[0] = t.x; f.w[1] = t.y;
+    } else if constexpr (NW == 3) {           // four BGR pixels: 12 bytes, 4-byte aligned
+        const v3u t = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, aux);
+        f.w[0] = t.x; f.w[1] = t.y; f.w[2] = t.z;
     } else {
         const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux);
         f.w[0] = t.x; f.w[1] = t.y; f.w[2] = t.z; f.w[3] = t.w;
@@ -395,10 +423,15 @@ constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pi
 // per-pixel thresholds are parked in lane-private LDS words after their first use, so the bit loop reads them from LDS instead of
 // fetching them a second time (the re-reads are L2 hits, but each still costs a vector-memory instruction and its L2 -> CU trip:
 // 11 of the 54 loads per lane at N = 44).  The parked words are read back by the lane that wrote them: no synchronisation.
-template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0>
-__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
+// BGR = 1 (slgc_scan_bgr_dev): the planes hold the camera's BGR frames, 3 bytes per pixel; a lane loads its four pixels as one dwordx3 and forms
+// OpenCV's 8-bit luma in registers -- the grey stack of src/3-capture_decode.py:66-70 never exists in HBM.  Raw frames in flight are three
+// registers each: 4 waves per SIMD (<= 128 VGPRs), every wave with three times the bytes in flight.
+template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0, int BGR = 0>
+__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : 8) : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
+    constexpr int NR = BGR ? 3 : NW;      // ... as loaded
+    static_assert(!BGR || (NS > 0 && NW == 1), "the BGR kernels are the specialised ones");
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
     constexpr bool SPEC = NS > 0;
     using FS = FrameSpec<SPEC ? NS : 14>;
@@ -414,6 +447,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         }
     }
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
+    const uint32_t voff = BGR ? 3u * off : off;      // byte offset of the lane's pixels inside a plane
     const uint32_t ps = a.plane_stride;
     const int L = SPEC ? FS::L : a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
@@ -425,15 +459,24 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
         uint32_t KA[NP], KB[NP], C1[NP], C2[NP];      // C1 / C2 hold K1 / K2 of pack_pair_consts
         // specialised kernels: DEPTH steps of frame loads stay in flight ahead of the step being classified
         constexpr int DEPTH = SLGC_PARK_DEPTH;
-        Frame<NW, NT> ring[SPEC ? DEPTH + 1 : 1][4];
+        Frame<NR, NT> ring[SPEC ? DEPTH + 1 : 1][4];
         auto fetch = [&](int f) {                   // f is a constant once the loop is unrolled: the choice below folds away
-            Frame<NW, NT> fr;
+            Frame<NR, NT> fr;
             const int slot = FS::table.slot[f];
             if (slot >= 0) fr.w[0] = park[slot * 64];
-            else fr = load_frame<NW, NT>(rs, off, (uint32_t)f * ps);
+            else fr = load_frame<NR, NT>(rs, voff, (uint32_t)f * ps);
             return fr;
         };
-        auto fetch_step = [&](int t, Frame<NW, NT> (&fr)[4]) {
+        auto gray_of = [&](const Frame<NR, NT> &fr, int f) -> Frame<NW, NT> {      // the grey dword(s) of a fetched frame (parked frames were converted before they were parked)
+            if constexpr (BGR) {
+                Frame<NW, NT> g;
+                g.w[0] = FS::table.slot[f] >= 0 ? fr.w[0] : bgr4_to_gray(fr.w[0], fr.w[1], fr.w[2], a.lum);
+                return g;
+            } else {
+                return fr;
+            }
+        };
+        auto fetch_step = [&](int t, Frame<NR, NT> (&fr)[4]) {
             const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
             fr[0] = fetch(f_hn); fr[1] = fetch(f_hn + 2 * FS::L); fr[2] = fetch(f_vn); fr[3] = fetch(f_vn + 2 * FS::L);
         };
@@ -442,12 +485,31 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
         } else {
             constexpr int TNT = SPEC ? NT : 0;      // parked frames are fetched once: streaming policy; otherwise cacheable (re-read from L2)
-            const Frame<NW, TNT> bl = load_frame<NW, TNT>(rs, off, 0), wh = load_frame<NW, TNT>(rs, off, ps);
-            Frame<NW, TNT> hm[6], vm[6];
+            Frame<NW, TNT> bl, wh, hm[6], vm[6];
+            {
+                const Frame<NR, TNT> r_bl = load_frame<NR, TNT>(rs, voff, 0), r_wh = load_frame<NR, TNT>(rs, voff, ps);
+                Frame<NR, TNT> r_hm[6], r_vm[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                hm[k] = load_frame<NW, TNT>(rs, off, (uint32_t)(SPEC ? FS::thr(k) : a.g.hid[k]) * ps);
-                vm[k] = load_frame<NW, TNT>(rs, off, (uint32_t)(SPEC ? FS::thr(6 + k) : a.g.vid[k]) * ps);
+                for (int k = 0; k < 6; ++k) {
+                    r_hm[k] = load_frame<NR, TNT>(rs, voff, (uint32_t)(SPEC ? FS::thr(k) : a.g.hid[k]) * ps);
+                    r_vm[k] = load_frame<NR, TNT>(rs, voff, (uint32_t)(SPEC ? FS::thr(6 + k) : a.g.vid[k]) * ps);
+                }
+                if constexpr (BGR) {
+                    bl.w[0] = bgr4_to_gray(r_bl.w[0], r_bl.w[1], r_bl.w[2], a.lum);
+                    wh.w[0] = bgr4_to_gray(r_wh.w[0], r_wh.w[1], r_wh.w[2], a.lum);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        hm[k].w[0] = bgr4_to_gray(r_hm[k].w[0], r_hm[k].w[1], r_hm[k].w[2], a.lum);
+                        vm[k].w[0] = bgr4_to_gray(r_vm[k].w[0], r_vm[k].w[1], r_vm[k].w[2], a.lum);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        bl.w[q] = r_bl.w[q]; wh.w[q] = r_wh.w[q];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { hm[k].w[q] = r_hm[k].w[q]; vm[k].w[q] = r_vm[k].w[q]; }
+                    }
+                }
             }
             if constexpr (SPEC) {
 #pragma unroll
@@ -521,8 +583,9 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? 8 : 1) k_decode
 #pragma unroll
             for (int t = 0; t < FS::L; ++t) {
                 if (t + DEPTH < FS::L) fetch_step(t + DEPTH, ring[(t + DEPTH) % (DEPTH + 1)]);
-                Frame<NW, NT> (&cur)[4] = ring[t % (DEPTH + 1)];
-                step(cur[0], cur[1], cur[2], cur[3], (uint32_t)t);
+                Frame<NR, NT> (&cur)[4] = ring[t % (DEPTH + 1)];
+                const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
+                step(gray_of(cur[0], f_hn), gray_of(cur[1], f_hn + 2 * FS::L), gray_of(cur[2], f_vn), gray_of(cur[3], f_vn + 2 * FS::L), (uint32_t)t);
                 // pin the accumulators here: left alone, the optimiser defers the whole "classified?" chain of every unrolled step to the
                 // end of the loop and keeps each step's intermediates alive until then (230+ registers)
                 asm volatile("" : "+v"(aB_h[0]), "+v"(aB_h[1]), "+v"(aB_v[0]), "+v"(aB_v[1]), "+v"(aV_h[0]), "+v"(aV_h[1]), "+v"(aV_v[0]), "+v"(aV_v[1]));
@@ -1017,13 +1080,23 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
 
 // Fused decode + triangulate (K1a-pk + K3 tail), 4 px/lane, 128-thread workgroups, NT loads.  Preconditions are checked by the caller.
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
-                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch, size_t batch_stride)
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch, size_t batch_stride,
+                      int bgr_bits)
 {
     PkArgs b{};
     for (int r = 0; r < g.n_runs; ++r) b.run[r] = (const uint8_t *)runs.p[r];
     b.plane_stride = (uint32_t)plane_stride;
     b.npix = (uint32_t)npix4;
-    b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + npix4);
+    b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + (bgr_bits ? 3 : 1) * npix4);
+    if (bgr_bits) {              // OpenCV's fixed-point BGR2GRAY coefficients (ingest.hip has the same two sets), split into bytes for v_dot4_u32_u8
+        const uint32_t ry = bgr_bits == 14 ? 4899 : 9798, gy = bgr_bits == 14 ? 9617 : 19235, by = bgr_bits == 14 ? 1868 : 3735;
+        b.lum.a_hi = (by >> 8) | ((gy >> 8) << 8) | ((ry >> 8) << 16);
+        b.lum.a_lo = (by & 255u) | ((gy & 255u) << 8) | ((ry & 255u) << 16);
+        b.lum.z_hi = b.lum.a_hi << 8;
+        b.lum.z_lo = b.lum.a_lo << 8;
+        b.lum.rnd = 1u << (bgr_bits - 1);
+        b.lum.shift = (uint32_t)bgr_bits;
+    }
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
     b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
     const int lut_w = ctx->lut_cam_W;
@@ -1064,6 +1137,18 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         ctx->last_nodes = b.f.cn.nodes ? 1 : 0;
         ctx->last_guard = 1;
         ctx->last_ragged = 0;
+        if (bgr_bits) {          // the caller has checked scan_bgr_eligible: a specialised frame count, wave-local tail
+#define SLGC_BGR(NSV)                                                                                              \
+            if (ns == NSV) {                                                                                       \
+                if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 3, NSV, 1>), dim3(blocks), dim3(128), b);    \
+                else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 3, NSV, 1>), dim3(blocks), dim3(128), b);                \
+            }
+            SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42)
+#undef SLGC_BGR
+            if (ns == 0) return slgc_fail(ctx, SLGC_EINVAL, "internal: BGR scan launched without a specialised frame count");
+            HIP_TRY(ctx, hipGetLastError());
+            return SLGC_OK;
+        }
         const bool glist = ctx->tune_guard_list != 0;       // flat triangles compacted over the wave (default) or redone lane by lane (A/B)
 #define SLGC_SPEC(NSV)                                                                                             \
         if (ns == NSV) {                                                                                           \
@@ -1100,6 +1185,16 @@ bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_
     for (int r = 0; r < g.n_runs; ++r) align_or |= (uintptr_t)runs.p[r];
     return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && (uint64_t)g.N * plane_stride + npix < 0xfffffff0ull &&
            npix < 0x7fffffffull;
+}
+
+// The BGR form of the fused scan (slgc_scan_bgr_dev): planes of 3 bytes per pixel, 4-byte aligned, 32-bit offsets, one of the specialised frame counts.
+bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
+                       const float *d_xyz)
+{
+    uintptr_t align_or = (uintptr_t)plane_stride | ((uintptr_t)d_h >> 1) | ((uintptr_t)d_v >> 1);
+    for (int r = 0; r < g.n_runs; ++r) align_or |= (uintptr_t)runs.p[r];
+    return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && npix % 4 == 0 && (uint64_t)g.N * plane_stride + 3 * (uint64_t)npix < 0xfffffff0ull &&
+           npix < 0x7fffffffull && ctx->tune_fuse_tail && spec_frames(ctx, g) != 0;
 }
 
 // variant: 0 = library default; otherwise ABL*10000000 + NT*1000000 + ALG*100000 + PX*1000 + BLOCK, e.g. 104128 = packed-16 kernel,

@@ -147,7 +147,10 @@ bool decode_fast_eligible(double eps, int *e_out);
 int launch_selftest_thresholds(slgc_ctx *ctx, int e, int black0, int n_black, unsigned long long *d_bad, int skew);
 int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew);
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
-                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch = 1, size_t batch_stride = 0);
+                      int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch = 1, size_t batch_stride = 0,
+                      int bgr_bits = 0);
+bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
+                       const float *d_xyz);
 inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj_tile ? (proj_w + 15) / 16 : (proj_w + 7) / 8; }
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz);
@@ -179,6 +182,7 @@ int launch_synth(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, in
 int launch_move_only(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz);
 int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w, int proj_h,
                           uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h, int16_t *d_v, float *d_truth);
+int launch_synth_bgr(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_stride, int N, int W, int row0, int rows, uint8_t *d_bgr, size_t bgr_stride);
 int launch_synth_uniform(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int W, int row0, int rows, uint32_t seed);
 // ingest.hip
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);

@@ -199,6 +199,24 @@ __global__ void __launch_bounds__(256) k_synth_uniform(uint8_t *__restrict__ sta
     *reinterpret_cast<uint32_t *>(stack + (size_t)f * plane_stride + (size_t)q * 4) = r;
 }
 
+// A BGR capture of a grey stack (the camera frames src/3-capture_decode.py:66 converts): per-pixel channel offsets so that the luma conversion
+// has something to do -- B = clip(g + ((7 x + 3 y) mod 11) - 5), G = g, R = clip(g - (((5 x + 11 y) mod 9) - 4)).  One thread = one pixel of one
+// frame; grid.y = frame.  Twin: oracle_np.gray_to_bgr_capture.
+__global__ void __launch_bounds__(256) k_synth_bgr(const uint8_t *__restrict__ gray, size_t gray_stride, int W, int row0, size_t npix, uint8_t *__restrict__ bgr,
+                                                   size_t bgr_stride)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int f = blockIdx.y;
+    const int x = (int)(p % (size_t)W), y = row0 + (int)(p / (size_t)W);
+    const int g = gray[(size_t)f * gray_stride + p];
+    const int b = g + ((7 * x + 3 * y) % 11) - 5, r = g - (((5 * x + 11 * y) % 9) - 4);
+    uint8_t *dst = bgr + (size_t)f * bgr_stride + 3 * p;
+    dst[0] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    dst[1] = (uint8_t)g;
+    dst[2] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
 // ---- the yardstick of the roofline fractions: a kernel that ONLY moves a scan's bytes -------------------------------------------------
 // N frame planes read 4 bytes per lane and plane (the scan kernels' loads), folded with one rotate-xor each so that no load can be dropped;
 // written: the two int16 maps 8 bytes per lane each (if asked for) and 48 bytes of "XYZ" per 4 pixels laid out wave-contiguously, 16 bytes
@@ -259,6 +277,15 @@ int launch_synth_physical(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, 
     hipLaunchKernelGGL(k_synth_physical_codes, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, W, row0, npix, proj_w, proj_h,
                        a.L, r2_max, d_h, d_v, d_truth);
     if (d_stack) hipLaunchKernelGGL(k_synth_render, dim3((unsigned)(((npix + 3) / 4 + 255) / 256), N), dim3(256), 0, ctx->stream, a, d_h, d_v);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+int launch_synth_bgr(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_stride, int N, int W, int row0, int rows, uint8_t *d_bgr, size_t bgr_stride)
+{
+    const size_t npix = (size_t)rows * W;
+    if (npix == 0) return SLGC_OK;
+    hipLaunchKernelGGL(k_synth_bgr, dim3((unsigned)((npix + 255) / 256), N), dim3(256), 0, ctx->stream, d_gray, gray_stride, W, row0, npix, d_bgr, bgr_stride);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

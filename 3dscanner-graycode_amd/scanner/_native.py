@@ -72,6 +72,7 @@ SIGNATURES = {
     "slgc_dev_memset": (_i, [_vp, _vp, _i, _sz]),
     "slgc_decode_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _d, _d, _vp, _vp, _i]),
     "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
+    "slgc_scan_bgr_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "slgc_selftest_thresholds": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "slgc_selftest_classify": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "slgc_synth_scene_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32, _i, _i]),
     "slgc_synth_physical_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.c_uint32, _i, _vp, _vp, _vp]),
     "slgc_synth_physical_ex_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, C.c_uint32, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "slgc_synth_bgr_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, _vp, _sz]),
     "slgc_synth_uniform_dev": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _i, C.c_uint32]),
     "slgc_event_record": (_i, [_vp, _i]),
     "slgc_event_elapsed_ms": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
@@ -337,7 +339,7 @@ class Context:
         """0 = uint8 stack as given, 1 = float64 stack narrowed to uint8 on the host, 2 = float64 kernel (slgc_last_input_path)."""
         return int(lib().slgc_last_input_path(self._h))
 
-    SCAN_PATHS = {0: "none", 1: "fused", 2: "split", 3: "split-ragged", 4: "batch-fused", 5: "cloud"}
+    SCAN_PATHS = {0: "none", 1: "fused", 2: "split", 3: "split-ragged", 4: "batch-fused", 5: "cloud", 6: "fused-bgr"}
 
     def last_scan_path(self) -> dict:
         """Which kernels the last scan_dev / scan_batch_dev call launched (slgc_last_scan_path): {"path": "fused" | "split" |
@@ -588,6 +590,12 @@ class Context:
         self._ck(lib().slgc_scan_dev(self._h, d_stack, n_runs, run_stride, plane_stride, N, rows, W, row0, int(proj_size[0]),
                                      int(proj_size[1]), float(eps), float(m), int(mode), d_h, d_v, d_xyz, d_count))
 
+    def scan_bgr_dev(self, d_bgr: int, n_runs, run_stride, plane_stride, N, rows, W, row0, proj_size, d_xyz: int, d_count=None, d_h=None, d_v=None,
+                     coeff_bits=15, eps=1, m=10, mode=TRI_ALGEBRAIC):
+        """scan_dev straight from BGR frames [n_runs][N][rows][W][3] (plane_stride / run_stride in bytes): cv2.cvtColor's luma inside the frame loads."""
+        self._ck(lib().slgc_scan_bgr_dev(self._h, d_bgr, int(n_runs), int(run_stride), int(plane_stride), int(N), int(rows), int(W), int(row0),
+                                         int(proj_size[0]), int(proj_size[1]), int(coeff_bits), float(eps), float(m), int(mode), d_h, d_v, d_xyz, d_count))
+
     def selftest_thresholds(self, eps: int = 1, black_lo: int = 0, black_hi: int = 256) -> int:
         """Exhaustive check of the decode kernels' integer-threshold folding over the uint8 domain; returns the mismatch count."""
         bad = C.c_uint64()
@@ -663,6 +671,11 @@ class Context:
         self._ck(lib().slgc_synth_physical_ex_dev(self._h, d_stack, int(plane_stride), int(N), int(H), int(W), int(row0), int(rows), int(proj_size[0]),
                                                   int(proj_size[1]), int(seed), int(noise), int(lo), int(hi), float(0.16 if r2_max is None else r2_max),
                                                   d_h_true, d_v_true, d_truth_xyz))
+
+    def synth_bgr_dev(self, d_gray, gray_plane_stride, N, H, W, d_bgr, bgr_plane_stride, row0=0, rows=None):
+        """A BGR capture [N][rows][W][3] of a grey stack in HBM (channel offsets so that the luma has work to do; twin: oracle_np.gray_to_bgr_capture)."""
+        rows = H if rows is None else rows
+        self._ck(lib().slgc_synth_bgr_dev(self._h, d_gray, int(gray_plane_stride), int(N), int(H), int(W), int(row0), int(rows), d_bgr, int(bgr_plane_stride)))
 
     def synth_uniform_dev(self, d_stack, plane_stride, N, H, W, row0=0, rows=None, seed=0):
         """SURVEY.md 8(d) S-uniform: every byte uniform in 0..255 (counter hash; twin: oracle_np.synth_uniform)."""

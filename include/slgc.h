@@ -101,7 +101,8 @@ enum {
     SLGC_PATH_SPLIT = 2,        /* decode kernel + dense triangulation kernel, both on their vector paths */
     SLGC_PATH_SPLIT_RAGGED = 3, /* two kernels and a byte-wide / per-pixel fallback kernel took part (misaligned or ragged band) */
     SLGC_PATH_BATCH_FUSED = 4,  /* slgc_scan_batch_dev: all scans in one launch of the fused kernel */
-    SLGC_PATH_CLOUD = 5         /* slgc_cloud_dev: decode kernel + x-major list build that triangulates in-kernel (no dense XYZ) */
+    SLGC_PATH_CLOUD = 5,        /* slgc_cloud_dev: decode kernel + x-major list build that triangulates in-kernel (no dense XYZ) */
+    SLGC_PATH_FUSED_BGR = 6     /* slgc_scan_bgr_dev: the fused kernel reading the camera's BGR frames (luma formed inside the frame loads) */
 };
 int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard);
 /* Which scatter kernel the last x-major list build on this context (slgc_cloud_dev, slgc_cloud_lists_dev, slgc_correspond with
@@ -224,6 +225,15 @@ int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t ru
 int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N,
                   int rows, int W, int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h,
                   int16_t *d_v, float *d_xyz, unsigned long long *d_count);
+/* slgc_scan_dev straight from the camera's BGR frames -- replaces the cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) + grey-stack fill of
+ * src/3-capture_decode.py:66-70 together with :75 (get_codes) and src/4-triangulate.py:50-64.  d_bgr: uint8 [n_runs][N][rows][W][3] (OpenCV's
+ * pixel order), plane_stride = BYTES between consecutive frames (>= 3 * rows * W), run_stride = bytes between runs; coeff_bits as slgc_to_gray.
+ * With N = 42 / 44 / 46, 4-byte aligned planes, SLGC_TRI_ALGEBRAIC and no count: ONE kernel, the luma formed in registers inside the frame
+ * loads (3 N + 12 bytes per pixel; the grey stack never exists in HBM; slgc_last_scan_path = SLGC_PATH_FUSED_BGR).  Otherwise
+ * slgc_to_gray_dev into scratch of the context + slgc_scan_dev.  Results bit-identical with that chain either way. */
+int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int row0,
+                      int proj_w, int proj_h, int coeff_bits, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz,
+                      unsigned long long *d_count);
 /* Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry in one launch -- stacks scan_stride bytes
  * apart, d_h / d_v [n_scans][rows * W] int16 and d_xyz [n_scans][rows * W][3] float32 back to back.  Same results as n_scans calls of
  * slgc_scan_dev (which is what shapes that are not a whole number of 512-pixel workgroups, and the other modes, fall back to).
@@ -343,6 +353,12 @@ int slgc_synth_physical_ex_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_str
 /* SURVEY.md section 8(d) "S-uniform": every byte of every frame uniform in 0..255 (counter hash keyed by frame, dword of the whole image and
  * seed: a band holds the bytes of the same rows of the whole image).  W, plane_stride, d_stack multiples of 4.  Twin: oracle_np.synth_uniform. */
 int slgc_synth_uniform_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed);
+
+/* A synthetic BGR capture of a grey stack (what the camera hands src/3-capture_decode.py:66): B = clip(g + ((7 x + 3 y) mod 11) - 5), G = g,
+ * R = clip(g - (((5 x + 11 y) mod 9) - 4)) with y counted in the whole image.  d_bgr: [N][rows][W][3], bgr_plane_stride bytes between frames.
+ * Twin: oracle_np.gray_to_bgr_capture. */
+int slgc_synth_bgr_dev(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_plane_stride, int N, int H, int W, int row0, int rows, uint8_t *d_bgr,
+                       size_t bgr_plane_stride);
 
 /* HIP-event timing on the context's stream: id in [0,16). */
 int slgc_event_record(slgc_ctx *ctx, int id);

@@ -579,6 +579,17 @@ def synth_physical(n_frames, H, W, proj_size, calib, seed=1, noise=3, row0=0, ro
     return render_codes(n_frames, H, W, h, v, seed=seed, noise=noise, row0=row0, gains=gains), h, v, truth
 
 
+def gray_to_bgr_capture(stack, row0=0):
+    """[N,rows,W] grey frames -> [N,rows,W,3] BGR frames as csrc/synth.hip k_synth_bgr makes them: B = clip(g + ((7 x + 3 y) mod 11) - 5), G = g,
+    R = clip(g - (((5 x + 11 y) mod 9) - 4)), y counted in the whole image."""
+    n, rows, W = stack.shape
+    yy, xx = np.mgrid[row0:row0 + rows, 0:W]
+    g = stack.astype(np.int64)
+    b = np.clip(g + ((7 * xx + 3 * yy) % 11) - 5, 0, 255)
+    r = np.clip(g - (((5 * xx + 11 * yy) % 9) - 4), 0, 255)
+    return np.stack([b, g, r], axis=-1).astype(np.uint8)
+
+
 def synth_uniform(n_frames, H, W, seed=0, row0=0, rows=None):
     """SURVEY.md 8(d) S-uniform as the device generates it (csrc/synth.hip: k_synth_uniform): every byte uniform in 0..255 from a counter
     hash keyed by (frame, dword of the whole image, seed); little-endian bytes of one mix32 per 4 pixels.  W % 4 == 0."""

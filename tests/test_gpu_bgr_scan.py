@@ -1,0 +1,141 @@
+"""slgc_scan_bgr_dev (-m gpu): the scan straight from the camera's BGR frames.
+
+/root/reference/src/3-capture_decode.py:66-70 converts every camera frame with cv2.cvtColor(BGR2GRAY) and stores it into the grey stack that
+:75 hands to get_codes.  The fused kernel can form that luma inside its frame loads (3 N + 12 bytes per pixel instead of 3 N + N + N + 12).
+Checked here: maps and XYZ bit-identical with the chain slgc_to_gray_dev -> slgc_scan_dev on the same BGR capture (both coefficient sets,
+one and two runs, every shape that takes the one-kernel path and shapes that must fall back), and against the CPU oracle chain
+(oracle_np.bgr_to_gray -> oracle_c.scan_dense) every pixel; at BASELINE configs[2] and [1] sizes too."""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+import oracle_c as oc
+import oracle_np as onp
+from conftest import has_gpu
+from test_gpu_fullsize import compare_scan
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from scanner import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def oracle_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oc.set_threads(max(1, min(64, n)))
+    yield
+    oc.set_threads(1)
+
+
+def make_capture(ctx, scene, N, H, W, psize, n_runs=1, pad=0, row0=0, rows=None, Himg=None):
+    """-> (bgr device buffer [n_runs][N][rows][W][3] with `pad` bytes between planes, grey device buffer the generator made)"""
+    rows = H if rows is None else rows
+    px = rows * W
+    gray = ctx.alloc(max(16, n_runs * N * px))
+    plane = 3 * px + pad
+    bgr = ctx.alloc(max(16, n_runs * N * plane)).zero()
+    for r in range(n_runs):
+        bench.synth_into(ctx, scene, gray.at(r * N * px) if r else gray.ptr, px, N, Himg or H, W, psize, 5 + 3 * r, row0=row0, rows=rows)
+        ctx.synth_bgr_dev(gray.at(r * N * px) if r else gray.ptr, px, N, Himg or H, W, bgr.at(r * N * plane) if r else bgr.ptr, plane, row0=row0, rows=rows)
+    ctx.synchronize()
+    return bgr, gray, plane
+
+
+def test_bgr_capture_generator_equals_numpy_twin(ctx):
+    N, H, W = 14, 37, 64
+    ctx.set_calibration(*bench.calibration(W, H, 64, 48))
+    bgr, gray, plane = make_capture(ctx, "s-scene", N, H, W, (64, 48), pad=8, row0=5, rows=20, Himg=H)
+    g = gray.download((N, 20, W), np.uint8)
+    got = bgr.download((N, plane), np.uint8)
+    ref = onp.gray_to_bgr_capture(g, row0=5)
+    assert np.array_equal(got[:, :3 * 20 * W].reshape(N, 20, W, 3), ref) and not got[:, 3 * 20 * W:].any()
+    assert (ref[..., 0] != ref[..., 1]).mean() > 0.5 and (ref[..., 2] != ref[..., 1]).mean() > 0.5
+    bgr.free()
+    gray.free()
+
+
+CASES = [
+    # W, H, N, runs, pad, coeff_bits, scene, expect one kernel
+    (256, 64, 44, 1, 0, 15, "s-scene", True),
+    (256, 64, 44, 2, 0, 15, "s-scene", True),
+    (260, 33, 42, 1, 12, 15, "s-uniform", True),
+    (512, 96, 46, 1, 0, 14, "s-scene", True),
+    (512, 96, 46, 2, 4, 14, "s-uniform", True),
+    (130, 31, 44, 1, 0, 15, "s-scene", False),      # 130 * 31 is not a multiple of 4 pixels
+    (256, 64, 26, 1, 0, 15, "s-scene", False),      # no specialised kernel for 26 frames
+    (256, 64, 44, 1, 2, 15, "s-scene", False),      # planes not 4-byte aligned
+]
+
+
+@pytest.mark.parametrize("W,H,N,runs,pad,bits,scene,fused", CASES)
+def test_bgr_scan_equals_to_gray_then_scan_and_the_oracle(ctx, W, H, N, runs, pad, bits, scene, fused):
+    from scanner import _native
+    psize = (300, 200)
+    calib = bench.calibration(W, H, *psize)
+    calib = (calib[0].copy(),) + tuple(calib[1:])
+    calib[0][0, 2], calib[0][1, 2], calib[0][0, 0], calib[0][1, 1] = W / 2, H / 2, 1.2 * W, 1.2 * W
+    ctx.set_calibration(*calib)
+    if scene == "s-uniform" and W % 4:
+        pytest.skip("the uniform generator writes dwords")
+    px = W * H
+    bgr, gray, plane = make_capture(ctx, scene, N, H, W, psize, n_runs=runs, pad=pad)
+    maps, xyz = ctx.alloc(px * 4 + 64).zero(), ctx.alloc(px * 12).zero()
+    ctx.scan_bgr_dev(bgr.ptr, runs, N * plane, plane, N, H, W, 0, psize, xyz.ptr, None, maps.at(0), maps.at(px * 2), coeff_bits=bits)
+    ctx.synchronize()
+    path = ctx.last_scan_path()["path"]
+    assert (path == "fused-bgr") == fused, path
+    got = (maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32))
+    # the two-step chain on the device: grey stack through slgc_to_gray_dev, then the ordinary scan
+    g2 = ctx.alloc(runs * N * px)
+    lib = _native.lib()
+    for r in range(runs):
+        for f in range(N):
+            ctx._ck(lib.slgc_to_gray_dev(ctx._h, bgr.at((r * N + f) * plane) if (r or f) else bgr.ptr, px, bits, g2.at((r * N + f) * px) if (r or f) else g2.ptr))
+    m2, x2 = ctx.alloc(px * 4 + 64).zero(), ctx.alloc(px * 12).zero()
+    ctx.scan_dev(g2.ptr, runs, N * px, px, N, H, W, 0, psize, x2.ptr, None, m2.at(0), m2.at(px * 2))
+    ctx.synchronize()
+    chain = (m2.download((H, W), np.int16), m2.download((H, W), np.int16, px * 2), x2.download((H, W, 3), np.float32))
+    assert np.array_equal(got[0], chain[0]) and np.array_equal(got[1], chain[1])
+    assert np.array_equal(got[2].view(np.uint32), chain[2].view(np.uint32)), "XYZ must be bit-identical with to_gray + scan"
+    # the oracle chain on the CPU
+    raw = bgr.download((runs, N, plane), np.uint8)[:, :, :3 * px].reshape(runs, N, H, W, 3)
+    gref = onp.bgr_to_gray(raw, coeff_bits=bits)
+    assert np.array_equal(g2.download((runs, N, H, W), np.uint8), gref)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(gref if runs > 1 else gref[0], psize, *calib)
+    valid, worst = compare_scan(*got, ref_h, ref_v, ref_xyz, f"bgr scan {W}x{H}x{N} runs={runs}")
+    assert valid > 0
+    for b in (bgr, gray, maps, xyz, g2, m2, x2):
+        b.free()
+
+
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44"])
+def test_bgr_scan_at_bench_sizes_every_pixel(ctx, workload):
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
+    scene = "physical"
+    calib = bench.calibration(W, H, pw, ph, rig=bench.SCENES[scene]["rig"])
+    ctx.set_calibration(*calib)
+    px = W * H
+    bgr, gray, plane = make_capture(ctx, scene, N, H, W, (pw, ph))
+    gray.free()
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.scan_bgr_dev(bgr.ptr, 1, N * plane, plane, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2))
+    ctx.synchronize()
+    assert ctx.last_scan_path()["path"] == "fused-bgr"
+    raw = bgr.download((N, H, W, 3), np.uint8)
+    gref = onp.bgr_to_gray(raw)
+    del raw
+    ref_h, ref_v, ref_xyz = oc.scan_dense(gref, (pw, ph), *calib)
+    valid, worst = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32), ref_h, ref_v, ref_xyz,
+                                f"{workload} bgr scan")
+    assert valid > 0.8 * px
+    print(f"\n{workload} from BGR frames: {valid} / {px} decodable, worst rel. XYZ error {worst:.2e}")
+    for b in (bgr, maps, xyz):
+        b.free()

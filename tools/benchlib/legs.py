@@ -109,6 +109,73 @@ def throughput_mode(ctx, _native, G, steps, mode, device, n_streams=2, collectiv
 
 
 
+def ingest_leg(ctx, scene, N, H, W, proj_size, steps, mode_fused, maps, xyz, buffers=2):
+    """The scan from the camera's BGR frames (src/3-capture_decode.py:66-70 + :75): slgc_scan_bgr_dev -- one kernel, luma inside the frame loads, 3 N + 12
+    algorithmic bytes per pixel -- against the chain slgc_to_gray_dev (per frame, into a grey stack) + slgc_scan_dev, which moves 3 N + N + N + 12.  Rotated
+    BGR captures; the ordinary scan's kernel time comes from HIP events bound to the dispatch, the chain's from events around the whole step."""
+    px = H * W
+    plane = 3 * px
+    caps = []
+    gray = ctx.alloc(N * px)
+    for b in range(max(2, buffers)):
+        synth_into(ctx, scene, gray.ptr, px, N, H, W, proj_size, 31 + b)
+        c = ctx.alloc(N * plane)
+        ctx.synth_bgr_dev(gray.ptr, px, N, H, W, c.ptr, plane)
+        caps.append(c)
+    from scanner import _native
+    lib = _native.lib()
+
+    def fused(i):
+        ctx.scan_bgr_dev(caps[i % len(caps)].ptr, 1, N * plane, plane, N, H, W, 0, proj_size, xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode_fused)
+
+    def separate(i):
+        c = caps[i % len(caps)]
+        ctx._ck(lib.slgc_to_gray_dev(ctx._h, c.ptr, N * px, 15, gray.ptr))          # the whole capture in one launch: frames are contiguous
+        ctx.scan_dev(gray.ptr, 1, N * px, px, N, H, W, 0, proj_size, xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode_fused)
+
+    K = max(5, steps)
+    for i in range(3):
+        fused(i)
+    ctx.synchronize()
+    ctx.prof_begin(K + 8, 1)
+    t0 = time.perf_counter()
+    for i in range(K):
+        fused(i)
+    ctx.synchronize()
+    el_f = time.perf_counter() - t0
+    kms, kn = ctx.prof_end()
+    samples = ctx.prof_samples()
+    path = ctx.last_scan_path()
+    for i in range(3):
+        separate(i)
+    ctx.synchronize()
+    ctx.event_record(2)
+    t0 = time.perf_counter()
+    for i in range(K):
+        separate(i)
+    ctx.event_record(3)
+    ctx.synchronize()
+    el_s = time.perf_counter() - t0
+    sep_ms = ctx.event_elapsed_ms(2, 3) / K
+    avg = kms / max(1, kn)
+    per_px = 3 * N + 12
+    out = {"scene": scene, "workload": f"{W}x{H} cam, {N} BGR frames", "executed": path,
+           "ingest_fused": {"value": round(px / 1e6 * K / el_f, 1), "unit": "Mpixels/s", "ms_per_step": round(el_f / K * 1e3, 4),
+                            "roofline": {"bound": "hbm", "achieved": round(per_px * px / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(per_px * px / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg, 5), "launches_timed": kn,
+                                         "algorithmic_bytes_per_px": per_px, "algorithmic_bytes_per_launch": per_px * px,
+                                         "kernel": "k_decode_pk<4,128,nt,FUSE,NS,BGR=1>: dwordx3 frame loads, cv2.cvtColor's 15-bit luma in registers (v_dot4_u32_u8)"}},
+           "ingest_separate": {"value": round(px / 1e6 * K / el_s, 1), "unit": "Mpixels/s", "ms_per_step": round(el_s / K * 1e3, 4), "device_ms_per_step": round(sep_ms, 4),
+                               "bytes_per_px_moved": 3 * N + N + N + 12,
+                               "frac_on_3N_plus_12": round(per_px * px / (sep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "slgc_to_gray_dev (grey stack written to HBM) + slgc_scan_dev (reads it back)"},
+           "speedup": round(el_s / el_f, 3)}
+    for c in caps:
+        c.free()
+    gray.free()
+    return out
+
+
 def small_image_legs(_native, device, steps, mode_fused, workloads=("c2_1920x1080x44", "c1_1280x720x42"),
                      scenes=("physical", "s-scene", "s-uniform", "noisy-physical")):
     """BASELINE configs[1] / configs[0] sizes (one round of resident waves: head and tail of the kernel stay exposed) through the fused kernel on

@@ -9,7 +9,7 @@ import numpy as np
 from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, SCENES, STAGE, WORKLOADS, calibration, csrc_fingerprint, digest64, launch_stats,
                      synth_into, workload_label)
 from .cpu import cpu_baseline
-from .legs import physical_accuracy, reference_product, small_image_legs, sustained_leg, throughput_batched, throughput_mode
+from .legs import ingest_leg, physical_accuracy, reference_product, small_image_legs, sustained_leg, throughput_batched, throughput_mode
 from .sharded_legs import sharded_report, verify_sharded
 
 
@@ -287,6 +287,13 @@ def run_rank(args, rank, local_rank, world):
         thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
         thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
 
+    ingest = None
+    if extras and row0 == 0 and N in (42, 44, 46) and band_px % 4 == 0:
+        STAGE[0] = "ingest"
+        use_rig(SCENES[args.scene]["rig"])
+        ingest = ingest_leg(ctx, args.scene, N, rows, cam_w, (proj_w, proj_h), max(5, args.steps // 2), mode_fused, maps, xyz)
+        STAGE[0] = "extras"
+
     small = None
     if extras and args.workload == "c3_4096x3000x44" and not args.no_small_images:
         STAGE[0] = "small images"
@@ -445,6 +452,8 @@ def run_rank(args, rank, local_rank, world):
             out["decode_kernel_alone"] = {"roofline": dr, "scene": "s-scene",
                                           "note": "decode kernel launched back to back on rotated S-scene stacks (~80 % of the pixels decodable: the decode "
                                                   "kernel's heavier input), same run (the north star's >= 60 % of HBM roofline on the decode kernel at 4096x3000x44)"}
+        if ingest is not None:
+            out["ingest"] = ingest
         if small is not None:
             out["small_images"] = small
         if ref_product is not None:
