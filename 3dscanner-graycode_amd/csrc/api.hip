@@ -192,13 +192,17 @@ int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs
     ctx->last_input_path = *dtype == SLGC_U8 ? 0 : 2;
     static const int pack = xcd_env("SLGC_F64_PACK", 1);          // 0: always ship float64 (A/B of the narrowing)
     bool plausible = *dtype == SLGC_F64 && pack && elems;
-    if (plausible) {              // a look at the head of every run before any page is pinned: a stack of fractions (a normalised capture) fails here
-        uint8_t probe[4096];
+    if (plausible) {              // a look at 16 pieces spread over every run before any page is pinned: a stack of fractions (a normalised capture) fails at
+                                  // the first piece, one whose late frames are not grey levels at one of the later ones -- not after a full narrowing pass
+        uint8_t probe[256];
+        constexpr size_t kPieces = 16;
         const size_t n = elems < sizeof probe ? elems : sizeof probe;
-        for (int r = 0; r < n_runs && plausible; ++r) {
-            const void *one = stacks[r];
-            plausible = slgc_host::narrow_f64_to_u8(&one, 1, n, probe, 1) == 1;
-        }
+        for (int r = 0; r < n_runs && plausible; ++r)
+            for (size_t k = 0; k < kPieces && plausible; ++k) {
+                const size_t at = elems > n ? (k + 1 == kPieces ? elems - n : (elems - n) / (kPieces - 1) * k) : 0;      // the last piece ends with the stack
+                const void *one = (const double *)stacks[r] + at;
+                plausible = slgc_host::narrow_f64_to_u8(&one, 1, n, probe, 1) == 1;
+            }
     }
     if (plausible) {
         void *st;
@@ -207,10 +211,12 @@ int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the staging buffer may still feed the previous call's copy
         const int narrowed = slgc_host::narrow_f64_to_u8(stacks, n_runs, elems, (uint8_t *)st);
         if (narrowed < 0) return slgc_fail(ctx, SLGC_ENOMEM, "host threads for the float64 -> uint8 narrowing");
-        if (!narrowed) {          // a late sample is not a grey level: this caller's stacks take the float64 kernel -- do not sit on the pinned pages
-            (void)hipHostFree(ctx->stage);
-            ctx->stage = nullptr;
-            ctx->stage_bytes = 0;
+        if (!narrowed) {          // a sample between the probes is not a grey level: this stack takes the float64 kernel
+            if (ctx->stage_bytes > ((size_t)256 << 20)) {      // do not sit on a large pinned buffer; a small one stays for the next well-formed stack
+                (void)hipHostFree(ctx->stage);
+                ctx->stage = nullptr;
+                ctx->stage_bytes = 0;
+            }
         }
         if (narrowed) {
             void *d;
@@ -368,6 +374,12 @@ extern "C" int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_tabl
 }
 
 extern "C" int slgc_last_list_kernel(slgc_ctx *ctx) { return ctx ? ctx->last_list_kernel : SLGC_EINVAL; }
+
+extern "C" int slgc_last_scan_ragged(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    return (ctx->last_ragged ? 1 : 0) | (ctx->last_tri_ragged ? 2 : 0);
+}
 
 extern "C" int slgc_synchronize(slgc_ctx *ctx)
 {
@@ -1049,6 +1061,7 @@ extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
     ctx->last_scan_path = SLGC_PATH_NONE;          // a decode alone is not a scan; slgc_triangulate_maps_dev after it completes the two-kernel path
     ctx->last_ragged = 0;
+    ctx->decode_pending = 1;
     return decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant);
 }
 
@@ -1092,7 +1105,8 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     if (!d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
-    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    ctx->last_scan_path = (ctx->last_tri_ragged || (ctx->decode_pending && ctx->last_ragged)) ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    ctx->decode_pending = 0;
     return SLGC_OK;
 }
 
@@ -1137,7 +1151,8 @@ extern "C" int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, i
     if (!d_wire || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 1) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count, d_wire))) return rc;
-    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    ctx->last_scan_path = ctx->last_tri_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;      // the maps came over the wire: no decode of this context is part of it
+    ctx->decode_pending = 0;
     return SLGC_OK;
 }
 
@@ -1166,10 +1181,12 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
         if ((rc = prof_mark(ctx, 0))) return rc;
         if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h))) return rc;
         ctx->last_scan_path = SLGC_PATH_FUSED;
+        ctx->decode_pending = 0;
         return prof_mark(ctx, 1);
     }
     ctx->last_scan_path = SLGC_PATH_NONE;
     ctx->last_ragged = 0;
+    ctx->decode_pending = 0;
     if (!d_h) {                                     // the two-kernel path hands the maps over through HBM: scratch of the context
         void *maps;
         if ((rc = slgc_ws(ctx, 3, (size_t)rows * W * 4 + 64, &maps))) return rc;
@@ -1178,7 +1195,7 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     }
     if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, 0))) return rc;
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
-    ctx->last_scan_path = ctx->last_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    ctx->last_scan_path = (ctx->last_ragged || ctx->last_tri_ragged) ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
     return SLGC_OK;
 }
 
@@ -1325,7 +1342,8 @@ extern "C" int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs,
     if ((rc = decode_fast_timed(ctx, g, runs, plane_stride, cam_h, cam_w, e, d_h, d_v, 0))) return rc;
     if ((rc = launch_cloud_tri(ctx, d_h, d_v, d_colors ? d_white_rgb : nullptr, cam_w, cam_h, proj_w, proj_h, d_cam_pts, d_proj_pts, d_pts, d_colors, d_total)))
         return rc;
-    ctx->last_scan_path = SLGC_PATH_CLOUD;
+    ctx->last_scan_path = SLGC_PATH_CLOUD;      // (slgc_last_scan_ragged tells whether the byte-wide decode kernel took part)
+    ctx->decode_pending = 0;
     return SLGC_OK;
 }
 

@@ -1137,6 +1137,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         ctx->last_nodes = b.f.cn.nodes ? 1 : 0;
         ctx->last_guard = 1;
         ctx->last_ragged = 0;
+        ctx->last_tri_ragged = 0;
         if (bgr_bits) {          // the caller has checked scan_bgr_eligible: a specialised frame count, wave-local tail
 #define SLGC_BGR(NSV)                                                                                              \
             if (ns == NSV) {                                                                                       \

@@ -68,7 +68,10 @@ struct slgc_ctx {
     int last_nodes;         // 1 = the triangulation read the camera node table, 0 = the per-pixel table (or evaluated the rays per pixel)
     int last_guard;         // 1 = float32 fast form with the flat-triangle guard, 0 = exact (acos / sin) mode, -1 = unguarded (diagnostic build only)
     int last_list_kernel;   // SLGC_LISTS_*: which scatter the last x-major list build launched
-    int last_ragged;        // 1 = a byte-wide / per-pixel fallback kernel took part (misaligned buffers, ragged tails)
+    int last_ragged;        // 1 = a byte-wide fallback DECODE kernel took part in the last decode launch (misaligned buffers, ragged tails)
+    int last_tri_ragged;    // 1 = the per-pixel fallback TRIANGULATION kernel took part in the last dense triangulation
+    int decode_pending;     // 1 = the last scan-related call was slgc_decode_dev: the slgc_triangulate_maps_dev / _wire_dev that follows completes a two-kernel
+                            // scan and inherits its raggedness; a triangulation on its own reports only its own
     int tune_guard_list;    // fused scan: 1 = flat triangles compacted over the wave and redone 64 per pass (default), 0 = redone lane by lane
     int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)

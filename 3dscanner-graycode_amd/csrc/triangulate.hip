@@ -561,6 +561,7 @@ int launch_triangulate_maps(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_
                             int proj_h, int mode, float *d_xyz, unsigned long long *d_count, const uint8_t *d_wire)
 {
     const size_t npix = (size_t)rows * W;
+    ctx->last_tri_ragged = 0;
     if (npix == 0) return SLGC_OK;
     if (proj_w < 1 || proj_h < 1) return slgc_fail(ctx, SLGC_EINVAL, "bad projector size");
     unsigned long long *slots = nullptr;
@@ -623,7 +624,7 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;
-        ctx->last_ragged = 1;
+        ctx->last_tri_ragged = 1;
         // ragged tail (< 4 pixels): direct-evaluation kernel on the remainder
         const int x0 = (int)(done % (size_t)W);
         (void)x0;
@@ -631,7 +632,7 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
     }
     ctx->last_nodes = 0;
     ctx->last_guard = mode == SLGC_TRI_EXACT ? 0 : 1;
-    ctx->last_ragged = 1;
+    ctx->last_tri_ragged = 1;
     return launch_triangulate_maps_direct(ctx, d_h, d_v, npix, 0, W, row0, proj_w, proj_h, mode, d_xyz, d_count);
 }
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "slgc_last_input_path": (_i, [_vp]),
     "slgc_last_scan_path": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "slgc_last_list_kernel": (_i, [_vp]),
+    "slgc_last_scan_ragged": (_i, [_vp]),
     "slgc_tune": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_name": (_i, [_vp, C.c_char_p, _i]),
     "slgc_device_pci_bus_id": (_i, [_vp, C.c_char_p, _i]),
@@ -343,12 +344,15 @@ class Context:
 
     def last_scan_path(self) -> dict:
         """Which kernels the last scan_dev / scan_batch_dev call launched (slgc_last_scan_path): {"path": "fused" | "split" |
-        "split-ragged" | "batch-fused" | "none", "ns_frames": 42 | 44 | 46 | 0 (generic kernel), "node_table": bool, "guard": bool}."""
+        "split-ragged" | "batch-fused" | "cloud" | "fused-bgr" | "none", "ns_frames": 42 | 44 | 46 | 0 (generic kernel), "node_table": bool, "guard": bool,
+        "fallback_kernels": {"decode": bool, "triangulation": bool} (slgc_last_scan_ragged: byte-wide / per-pixel fallback kernels took part)}."""
         ns, nodes, guard = C.c_int(), C.c_int(), C.c_int()
         rc = lib().slgc_last_scan_path(self._h, C.byref(ns), C.byref(nodes), C.byref(guard))
         if rc < 0:
             self._ck(rc)
-        return {"path": self.SCAN_PATHS.get(rc, str(rc)), "ns_frames": int(ns.value), "node_table": bool(nodes.value), "guard": guard.value == 1}
+        rg = int(lib().slgc_last_scan_ragged(self._h))
+        return {"path": self.SCAN_PATHS.get(rc, str(rc)), "ns_frames": int(ns.value), "node_table": bool(nodes.value), "guard": guard.value == 1,
+                "fallback_kernels": {"decode": bool(rg & 1), "triangulation": bool(rg & 2)}}
 
     LIST_KERNELS = {0: "none", 1: "tile-runs", 2: "whole-lines"}
 
@@ -500,6 +504,10 @@ class Context:
             raise ValueError("Pts must be (3,M)")
         M = x.shape[1]
         c = None if colors is None else np.ascontiguousarray(colors, dtype=np.float64)
+        if M == 0 and c is not None and c.size == 0:
+            # a scan with no decodable pixel: the reference's get_cam_proj_pts hands on colours of shape (0,) (triangulate.py:66-69), and its
+            # filter (:119-121) returns `colors[filter]` in whatever empty shape it was given
+            return np.empty((3, 0), np.float64), c.copy()
         if c is not None and c.shape != (M, 3):
             raise ValueError("colors must be (M,3)")
         kept = C.c_int64()

@@ -73,15 +73,21 @@ int slgc_synchronize(slgc_ctx *ctx);
  * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
  * to stay in the Infinity Cache between scans (> 64 MB; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
- * "lists_order" = workgroup -> tile order of the x-major list build: 1 column-major (default: a column's run continues in the tile below, so
- * the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000), 0 row-major, 2 column-major inside each XCD (no better).
+ * "lists_order" = workgroup -> tile order of the x-major list build, 0 .. 64, default 4: 0 row-major; 1 column-major (a column's run continues in the tile
+ * below, so the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000); 2 column-major inside each XCD (no better); n >= 3 (the
+ * whole-lines scatter k_xmajor_lines only) column-major in runs of n consecutive tiles per XCD, so that a tile and the tile below it -- whose rows it also
+ * reads -- share an L2 (n = 4: 218.8 -> 210.5 us).  The two scatter kernels read the value differently: the tile-run scatter k_xmajor_scatter treats
+ * every value other than 0 and 2 as plain column-major (1).
+ * "guard_list" 1 (default) = the fused scan kernel compacts its flat triangles over the wave and redoes 64 of them per float64 pass / 0 = redoes them lane by
+ * lane (bit-identical XYZ; scattered wrong codes make the lane-by-lane form walk the float64 path in nearly every wave).
  * "lists_lines" 1 (default) = slgc_cloud_dev's list build writes whole aligned 128-byte lines (k_xmajor_lines; see slgc_last_list_kernel) for images of at
  * least 2048 tiles of 64 x 32 pixels (below that the tile-run kernel is the faster one) / 2 = wherever the shape allows / 0 = tile runs (A/B).
  * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
  * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
  * scan its bands (0, the default: the band is the image).
  * Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD,
- * SLGC_FUSE_XCD, SLGC_CAM_NODES), read when the context is created. */
+ * SLGC_FUSE_XCD, SLGC_CAM_NODES, SLGC_LISTS_LINES, SLGC_LISTS_ORDER, SLGC_GUARD_LIST), read when the context is created.  Other environment
+ * switches (read once per process, A/B only): SLGC_FD_SEGS (segment count of the frame-difference kernel), SLGC_PAR_DOWNLOAD, SLGC_F64_PACK. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
@@ -105,6 +111,11 @@ enum {
     SLGC_PATH_FUSED_BGR = 6     /* slgc_scan_bgr_dev: the fused kernel reading the camera's BGR frames (luma formed inside the frame loads) */
 };
 int slgc_last_scan_path(slgc_ctx *ctx, int *ns_frames, int *node_table, int *guard);
+/* Fallback kernels of the last scan-related call, whatever SLGC_PATH_* it reports (slgc_cloud_dev and the fused paths included): bit 0 = the
+ * byte-wide decode kernel took part (misaligned buffers, a ragged tail), bit 1 = the per-pixel triangulation kernel did.  A
+ * slgc_triangulate_maps_dev call on its own reports only its own bit; directly after slgc_decode_dev it completes a two-kernel scan and
+ * SLGC_PATH_SPLIT_RAGGED then covers both. */
+int slgc_last_scan_ragged(slgc_ctx *ctx);
 /* Which scatter kernel the last x-major list build on this context (slgc_cloud_dev, slgc_cloud_lists_dev, slgc_correspond with
  * SLGC_ORDER_X) launched: SLGC_LISTS_TILE_RUNS = a tile writes its own run of every column (any shape, any map type);
  * SLGC_LISTS_WHOLE_LINES = slgc_cloud_dev's form that writes whole 16-record groups = aligned 128-byte lines (int16 maps, W % 4 == 0,

@@ -478,6 +478,16 @@ def test_golden_triangulate_cases(ctx, tri_cases):
         e_cam, e_proj, e_col = t0.get_cam_proj_pts(c["white"])
         assert e_cam.shape == (0,) and e_cam.dtype == np.float32 and e_proj.shape == (0,) and e_col.shape == (0,) and e_col.dtype == np.float64
         assert t0.triangulate(e_cam, e_proj).shape == (3, 0)
+        # ... and the box filter of that empty scan returns the colours in the empty shape it was given (triangulate.py:119-121), through the
+        # method and through the fused Triangulation.compute()
+        f_pts, f_col = t0.filter_3d_pts(t0.triangulate(e_cam, e_proj), e_col, 0.5)
+        assert f_pts.shape == (3, 0) and f_col.shape == (0,)
+        from scanner.triangulation.triangulate import Triangulation
+        tc = Triangulation(np.full_like(c["h"], -1), c["v"], tuple(int(x) for x in c["cam_size"]), c["cam_mtx"], c["cam_dist"],
+                           tuple(int(x) for x in c["proj_size"]), tuple(int(x) for x in c["proj_size"]), c["proj_mtx"].copy(), c["proj_dist"], c["R"], c["T"], None, ctx=ctx)
+        c_pts, c_col = tc.compute(c["white"], threshold=0.5)
+        assert c_pts.shape == (3, 0) and c_col.shape == (0,)
+        assert tc.compute(None, threshold=0.5)[0].shape == (3, 0)
 
 
 def test_cam_proj_pts_large_vs_oracle(ctx):
