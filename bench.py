@@ -52,6 +52,7 @@ def spawn_ranks(n, argv):
             # path then runs with nranks > 1 for real -- in-place ncclAllGather, grouped ncclBroadcast, the communication stream and its events --
             # at the speed of a TCP socket: a correctness mode, never a measurement.
             env.update(NCCL_HOSTID=f"slgc-rank-{r}-{key}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
+            env.setdefault("GPU_MAX_HW_QUEUES", "2")      # up to 8 processes share one device here: fewer hardware queues each (8 ranks: 7.8 -> 6.2 s per run, NOTES.md)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     deadline = time.time() + float(os.environ.get("SLGC_BENCH_TIMEOUT_S", "900")) + 15.0       # rank 0's own watchdog (same limit) prints its line first
     rcs = [None] * n

@@ -15,6 +15,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "rccl_one_gpu: several RCCL ranks share the one GPU of the test box over the loopback socket transport (test mode); run last")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The several-ranks-on-one-GPU cases go LAST: they use RCCL in a way only these tests do (SLGC_RANKS_AS_HOSTS=1), and under `pytest -x` a
+    stall there must not keep the rest of the suite from running."""
+    late = [it for it in items if it.get_closest_marker("rccl_one_gpu")]
+    if late:
+        items[:] = [it for it in items if not it.get_closest_marker("rccl_one_gpu")] + late
+
+
+RCCL_STALLS = []          # (test id, attempt, where the evidence was written): filled by tests/test_gpu_rccl_multi.py, reported below
+
+
+def pytest_terminal_summary(terminalreporter):
+    if RCCL_STALLS:
+        terminalreporter.section("RCCL ranks on one GPU: runs that stopped making progress and were repeated")
+        for tid, attempt, where in RCCL_STALLS:
+            terminalreporter.write_line(f"  {tid}: attempt {attempt} timed out -- stage line + per-rank Python stacks kept in {where}")
 
 
 def load_cases(fname):

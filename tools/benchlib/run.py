@@ -18,7 +18,11 @@ def run_rank(args, rank, local_rank, world):
     if os.environ.get("SLGC_RANKS_AS_HOSTS") == "1" and world > 1 and "NCCL_HOSTID" not in os.environ:
         # the same TEST MODE under an external launcher (torch.distributed.run gives every rank the same environment): see spawn_ranks
         os.environ.update(NCCL_HOSTID=f"slgc-rank-{rank}-{os.environ.get('MASTER_PORT', '0')}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_NET="Socket")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     from scanner import _native
+    if os.environ.get("SLGC_BENCH_FAULTHANDLER_S"):            # stall hunting (tools/jobs/rccl_hang_hunt.py): every rank's Python stacks after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SLGC_BENCH_FAULTHANDLER_S"]), exit=False, file=sys.stderr)
     cam_w, cam_h, proj_w, proj_h, N = WORKLOADS[args.workload]
     G = args.gpus
     use_comm = G > 1 or args.force_sharded
