@@ -319,13 +319,25 @@ def test_executed_path_is_observable(ctx, workload):
         return ctx.last_scan_path()
 
     big = W * H * 8 > 64 << 20
-    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": N, "node_table": big, "guard": True}
-    assert scan(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT) == {"path": "split", "ns_frames": N, "node_table": big, "guard": True}
+    clean = {"decode": False, "triangulation": False}
+    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": N, "node_table": big, "guard": True, "fallback_kernels": clean}
+    assert scan(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT) == {"path": "split", "ns_frames": N, "node_table": big, "guard": True, "fallback_kernels": clean}
     assert scan(_native.TRI_ALGEBRAIC, count=cnt.ptr)["path"] == "split"
-    assert scan(_native.TRI_EXACT) == {"path": "split", "ns_frames": N, "node_table": False, "guard": False}
-    assert scan(_native.TRI_ALGEBRAIC, xyz_ptr=xyz.ptr + 4)["path"] == "split-ragged"          # XYZ not 16-byte aligned: per-pixel triangulation kernel
+    assert scan(_native.TRI_EXACT) == {"path": "split", "ns_frames": N, "node_table": False, "guard": False, "fallback_kernels": clean}
+    ragged = scan(_native.TRI_ALGEBRAIC, xyz_ptr=xyz.ptr + 4)                                   # XYZ not 16-byte aligned: per-pixel triangulation kernel
+    assert ragged["path"] == "split-ragged" and ragged["fallback_kernels"] == {"decode": False, "triangulation": True}
+    # a triangulation on its own reports only its own fallback -- not the ragged state an earlier, unrelated decode left behind
+    ctx.decode_dev(stack.ptr + 1, 1, N * px, px, N, H - 1, W, maps.at(0), maps.at(px * 2))     # misaligned stack: the byte-wide decode kernel
+    assert ctx.last_scan_path()["fallback_kernels"]["decode"]
+    scan(_native.TRI_ALGEBRAIC)                                                                 # ... an unrelated fused scan in between
+    ctx.triangulate_maps_dev(maps.at(0), maps.at(px * 2), H, W, 0, (pw, ph), xyz.ptr)
+    alone = ctx.last_scan_path()
+    assert alone["path"] == "split" and alone["fallback_kernels"] == clean, alone
+    ctx.decode_dev(stack.ptr + 1, 1, N * px, px, N, H - 1, W, maps.at(0), maps.at(px * 2))
+    ctx.triangulate_maps_dev(maps.at(0), maps.at(px * 2), H - 1, W, 0, (pw, ph), xyz.ptr)       # directly after a decode: completes that two-kernel scan
+    assert ctx.last_scan_path()["path"] == "split-ragged"
     ctx.tune("park", 0)
-    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": 0, "node_table": big, "guard": True}
+    assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": 0, "node_table": big, "guard": True, "fallback_kernels": clean}
     ctx.tune("park", 1)
     ctx.synchronize()
     for b in (stack, maps, xyz, cnt):
