@@ -166,7 +166,8 @@ __device__ __forceinline__ double unit_of_byte(unsigned b)
 struct TriScatter {
     const float2 *cam_lut;     // [H][W] exact camera rays
     CamNodes cn;               // every-4th-column nodes (cn.nodes == nullptr: read cam_lut)
-    const float2 *proj_lut;
+    const float2 *proj_lut;      // projector rays (guarded redo)
+    const float2 *proj_cs;       // (cos(beta), sin(beta)) per projector pixel, same index (fast form)
     int ptiles_x, wide;
     TriF32 kf;
     double T[3], t_len;
@@ -334,7 +335,7 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
         for (int j = 0; j < CPH; ++j) {
             const unsigned hv = s_hv[r][hw + 16 * j];
             const bool ok = hv != kInvalidHV;
-            prj[j] = ts.proj_lut[ok ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+            prj[j] = ts.proj_cs[ok ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
         }
     }
 #pragma unroll
@@ -382,7 +383,7 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
                         cyr = cr.y;
                     }
                     const float2 pr = prj[j];
-                    const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix);
+                    const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
                     if (!LISTS_ABL(2)) {
                         pts[o] = (double)r3.x;                                       // Pts (3,M) float64, :95
                         pts[M + o] = (double)r3.y;
@@ -569,7 +570,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
         const int row = s_list[c][min(max(k, 0), TR - 1)];
         const unsigned hv = s_hv[row][c];
         rowk[j] = act ? row : -1;
-        prj[j] = ts.proj_lut[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+        prj[j] = ts.proj_cs[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
     }
     // (c) one record per lane and pass
     char *const cam_b = reinterpret_cast<char *>(cam), *const proj_b = reinterpret_cast<char *>(proj), *const col_b = reinterpret_cast<char *>(colors);
@@ -601,7 +602,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
                 *reinterpret_cast<float2 *>(cam_b + o8) = make_float2((float)x, (float)(y_tile + row));          // :59 [i, j] = (x, y)
                 *reinterpret_cast<float2 *>(proj_b + o8) = make_float2((float)pu, (float)pv);
             }
-            const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix);
+            const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
             if (!LISTS_ABL(2)) {
                 *reinterpret_cast<double *>(p0_b + o8) = (double)r3.x;                                          // Pts (3,M) float64, :95
                 *reinterpret_cast<double *>(p1_b + o8) = (double)r3.y;
@@ -634,7 +635,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
             const bool act = k >= ka && k < kb;
             const int row = s_list[c][min(max(k, 0), TR - 1)];
             const unsigned hv = s_hv[row][c];
-            const float2 pr = ts.proj_lut[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+            const float2 pr = ts.proj_cs[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
             emit(c, kp, ka, kb, act ? row : -1, pr);
         }
     }
@@ -913,9 +914,10 @@ int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, cons
     ts.cam_lut = (const float2 *)ctx->lut_cam;
     ts.cn = SLGC_CAM_NODES_FOR(ctx, cam_w, (size_t)cam_w * cam_h / 4 < (1u << 24));
     ts.proj_lut = (const float2 *)ctx->lut_proj;
+    ts.proj_cs = (const float2 *)ctx->lut_proj_cs;
     ts.ptiles_x = proj_tiles_x(ctx, proj_w);
     ts.wide = ctx->tune_proj_tile;
-    ts.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
+    ts.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     memcpy(ts.T, ctx->calib.T, sizeof ts.T);
     ts.t_len = ctx->calib.t_len;
     ctx->last_nodes = ts.cn.nodes ? 1 : 0;

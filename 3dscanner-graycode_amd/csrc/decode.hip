@@ -251,7 +251,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct FuseArgs {            // triangulation appended to the decode kernel (slgc_scan_dev)
     const float2 *cam_lut;    // [npix] camera rays of this band
     CamNodes cn;              // the same rays at every 4th column (cn.nodes == nullptr: read cam_lut)
-    const float2 *proj_lut;   // 8x8-tiled projector rays
+    const float2 *proj_lut;   // tiled projector rays (the guarded redo reads them)
+    const float2 *proj_cs;    // same index: (cos(beta), sin(beta)) per projector pixel -- what the fast form gathers
     float *xyz;               // [npix][3]
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads); bit 2: the maps are not stored at all
@@ -260,7 +261,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
     uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
     uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
-    TriF32 kf;                // T and |T|^2 in float32 for the fast form
+    TriF32 kf;                // T / |T| and |T| in float32 for the fast form
     double T[3], t_len;
 };
 
@@ -710,14 +711,14 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : 8) :
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
-                s_ray[it * SPAN + t] = (i != 0xffffffffu) ? a.f.proj_lut[i] : make_float2(0.1f, 0.2f);
+                s_ray[it * SPAN + t] = (i != 0xffffffffu) ? a.f.proj_cs[i] : make_float2(0.1f, 0.2f);
             }
         } else {
             float2 gr[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
-                gr[it] = (ABL != 6) ? a.f.proj_lut[i != 0xffffffffu ? i : 0u] : make_float2(0.1f, 0.2f);
+                gr[it] = (ABL != 6) ? a.f.proj_cs[i != 0xffffffffu ? i : 0u] : make_float2(0.1f, 0.2f);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) s_ray[it * SPAN + t] = gr[it];
@@ -735,7 +736,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : 8) :
             if (live) cam_rays_exact_where_tiny(fx, fy, a.f.cam_lut + off);
         }
         uint32_t ill = 0;
-        if constexpr (GLIST) ill = triangulate4_flag(fx, fy, px, py, valid, a.f.kf, out);
+        if constexpr (GLIST) ill = triangulate4_flag(fx, fy, px, py, valid, a.f.kf, out);      // px / py hold the gathered (cos(beta), sin(beta))
         else triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
@@ -1098,7 +1099,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         b.lum.shift = (uint32_t)bgr_bits;
     }
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
-    b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.xyz = d_xyz;
+    b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.proj_cs = (const float2 *)ctx->lut_proj_cs; b.f.xyz = d_xyz;
     const int lut_w = ctx->lut_cam_W;
     b.f.cn = SLGC_CAM_NODES_FOR(ctx, lut_w, cam_lut == ctx->lut_cam && npix4 / 4 < (1u << 24));
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;
@@ -1107,7 +1108,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const int nt_policy = ctx->tune_fuse_nt >= 0 ? (ctx->tune_fuse_nt & 3) : (npix4 * (size_t)(n_batch > 1 ? n_batch : 1) >= (4u << 20) ? 1 : 3);
     b.f.nt_store = nt_policy | ((d_h == nullptr || d_v == nullptr) ? 4 : 0);
     b.f.wave_tail = ctx->tune_fuse_tail;
-    b.f.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
+    b.f.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;
     const uint32_t groups = b.npix / 4;

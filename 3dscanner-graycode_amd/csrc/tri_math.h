@@ -53,80 +53,92 @@ __device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const do
 }
 
 // ---- the dense / fused fast form -------------------------------------------------------------------------------------------
-// triangulate.py:86-95 with the normalisations cancelled (c = camera ray [cx, cy, 1], p = projector ray [px, py, 1]):
-//   A = -T.c, B = T.p, Sa = |T x c| = |T||c| sin(alpha), Sb = |T x p| = |T||p| sin(beta), sin(gamma) = sin(alpha + beta)
-//   =>   Pts = c * |T|^2 * Sb / (Sa*B + A*Sb).
-// The sines come from CROSS products, not from sqrt(|T|^2|c|^2 - (T.c)^2): no subtraction of nearly equal numbers is left in them,
-// so float32 carries them to a few 2^-24 of |T||c| however small the angle, and the only cancellation that remains is the one the
-// geometry itself has, in D = Sa*B + A*Sb ~ sin(gamma).  That is what lets the whole form run in float32 -- on gfx950 float64 vector
-// instructions issue at half rate, v_rcp_f64 / v_rsq_f64 at an eighth (tools/ubench/valu_rates.hip), and a float64-heavy tail also
-// pulls the clock down: the float64 version of this tail (sqrt of differences, round 1) measured 141-147 us per 4096x3000x44
-// fused scan against 130-131 us for this one on the same box (gpurun_out/r2m/ab.log).
+// triangulate.py:86-95 with everything that depends on ONE ray only moved out of the per-pixel arithmetic.  With e = c / |c| the unit camera
+// ray (c = [cx, cy, 1]), t = T / |T|:
+//   cos(alpha) = -t.e      sin(alpha) = sqrt(1 - cos^2(alpha))      (alpha in (0, pi): the non-negative root, like arccos -> sin)
+//   cos(beta), sin(beta): per PROJECTOR PIXEL, evaluated once per calibration in float64 from the reference's float32 ray and float32 norm
+//                         (triangulate.py:92) and kept as float32 in the projector table the scan kernels gather from (ProjCs below)
+//   sin(gamma) = sin(alpha + beta) = sa cb + ca sb =: Dn             Pts = e * |T| sb / Dn                           (:93-95)
+// Per pixel that is one rsq, one sqrt, one rcp and ~20 multiply-adds; the flat-triangle test is three more (below).  (Rounds 1-3 formed
+// the same quantities un-normalised from cross products of T with both rays -- twice the arithmetic, and the projector's half of it
+// repeated for every camera pixel that sees the same projector pixel; at 1280x720 the fused kernel is bound by its vector ALU.)
+// Float32 suffices because no subtraction of nearly equal numbers is left except the one the geometry itself has, in Dn ~ sin(gamma):
+// sa comes from 1 - ca^2 with |ca| <= 0.6 for any camera ray a scanner uses (and a ray nearly parallel to the baseline is flagged flat).
+// On gfx950 float64 vector instructions issue at half rate, v_rcp_f64 / v_rsq_f64 at an eighth (tools/ubench/valu_rates.hip).
 // Error budget.  Each of cos(alpha), sin(alpha), cos(beta), sin(beta) carries an ABSOLUTE error <= ~4 * 2^-24 = 2.4e-7 from the
-// float32 arithmetic (+ 6e-8 from rounding T to float32): eps_f32 <= 3.0e-7; the reference's own float32 steps (NormedL: a sqrt and
-// three divisions, the projector norm: a sqrt -- triangulate.py:90,92) move ITS cosines by eps_ref <= 3 * 2^-24 = 1.8e-7, and
+// float32 arithmetic / the float32 table (+ 6e-8 from rounding T to float32): eps_f32 <= 3.0e-7; the reference's own float32 steps (NormedL: a
+// sqrt and three divisions -- the projector norm's rounding IS in the table) move ITS cos(alpha) by eps_ref <= 3 * 2^-24 = 1.8e-7, and
 //   |d len / len| <= eps_ref * [1/sin^2 b + (1/sin a + 1/sin b)/sin g]  +  eps_f32 * [1/sin b + 4/sin g].
-// A pixel is "flat" when a term can pass kGuardAmp = 60 (sin^2 b < 1/60, or min(sin a, sin b) * sin g < 2/60 -- which also gives
-// sin g >= 1/30 for the pixels that pass):  2 * 60 * 1.8e-7 + 3.0e-7 * (7.8 + 120) = 2.2e-5 + 3.8e-5 = 6.0e-5 < 1e-4 even if every
-// rounding aligns.  Flat pixels are redone by law_of_sines_mirror (float64 on the reference's float32 intermediates) -- in ONE
-// not-unrolled loop behind a lane-level "any of my four" test, so the common path pays for the comparisons only.
+// A pixel is "flat" when a term can pass kGuardAmp = 60 (sin^2 b < 1/60, or min(sin a, sin b) * |sin g| < 2/60 -- which also gives
+// |sin g| >= 1/30 for the pixels that pass):  2 * 60 * 1.8e-7 + 3.0e-7 * (7.8 + 120) = 2.2e-5 + 3.8e-5 = 6.0e-5 < 1e-4 even if every
+// rounding aligns.  Flat pixels are redone by law_of_sines_mirror (float64 on the reference's float32 intermediates).
 constexpr float kGuardAmp = 60.0f;
 
-struct TriF32 {               // per-launch constants of the fast form
-    float t0, t1, t2, tl2;
+struct TriF32 {               // per-launch constants of the fast form: T / |T| and |T|
+    float t0, t1, t2, tl;
 };
+
+__host__ __device__ inline TriF32 make_tri_f32(const double (&T)[3], double t_len)
+{
+    return TriF32{(float)(T[0] / t_len), (float)(T[1] / t_len), (float)(T[2] / t_len), (float)t_len};
+}
+
+// What the projector table holds per pixel for the fast form: (cos(beta), sin(beta)) of the pixel's ray against the baseline.
+__host__ __device__ inline void proj_cos_sin(float px, float py, const double (&T)[3], double t_len, float &cb, float &sb)
+{
+    const float qn = sqrtf((px * px + py * py) + 1.0f);                                                    // norm inside triangulate.py:92 (float32)
+    const double c = ((T[0] * (double)px + T[1] * (double)py) + T[2]) / (t_len * (double)qn);             // :92
+    cb = (float)c;
+    sb = (float)sqrt(fmax(0.0, 1.0 - c * c));
+}
 
 struct TriFastTerms {
-    float A, B, Sa2, Sb2, Sa, Sb, D;
+    float ex, ey, ez;         // unit camera ray
+    float ca, sa, Dn;         // cos(alpha), sin(alpha), sin(gamma)
 };
 
-__device__ __forceinline__ TriFastTerms tri_fast_terms(float cx, float cy, float px, float py, const TriF32 &k)
+__device__ __forceinline__ TriFastTerms tri_fast_terms(float cx, float cy, float cb, float sb, const TriF32 &k)
 {
     TriFastTerms t;
-    t.A = -fmaf(k.t0, cx, fmaf(k.t1, cy, k.t2));
-    t.B = fmaf(k.t0, px, fmaf(k.t1, py, k.t2));
-    // T x c and T x p with c = (cx, cy, 1), p = (px, py, 1)
-    const float ux = fmaf(-k.t2, cy, k.t1), uy = fmaf(k.t2, cx, -k.t0), uz = fmaf(k.t0, cy, -k.t1 * cx);
-    const float vx = fmaf(-k.t2, py, k.t1), vy = fmaf(k.t2, px, -k.t0), vz = fmaf(k.t0, py, -k.t1 * px);
-    t.Sa2 = fmaf(ux, ux, fmaf(uy, uy, uz * uz));
-    t.Sb2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
-    t.Sa = __builtin_amdgcn_sqrtf(t.Sa2);      // v_sqrt_f32 / v_rcp_f32: 1 ulp, inside eps_f32
-    t.Sb = __builtin_amdgcn_sqrtf(t.Sb2);
-    t.D = fmaf(t.Sa, t.B, t.A * t.Sb);
+    const float r = __builtin_amdgcn_rsqf(fmaf(cx, cx, fmaf(cy, cy, 1.0f)));      // v_rsq_f32 / v_sqrt_f32 / v_rcp_f32: 1 ulp, inside eps_f32
+    t.ex = cx * r;
+    t.ey = cy * r;
+    t.ez = r;
+    t.ca = -fmaf(k.t0, t.ex, fmaf(k.t1, t.ey, k.t2 * t.ez));
+    t.sa = __builtin_amdgcn_sqrtf(fmaf(-t.ca, t.ca, 1.0f));
+    t.Dn = fmaf(t.sa, cb, t.ca * sb);
     return t;
 }
 
-// sin^2(beta) < 1/A_g   <=>  Sb2 * A_g < tb ;   min(sin a, sin b) * sin g < 2/A_g  <=>  D^2 * min(Sa2*tb, Sb2*ta) < (2/A_g)^2 * (ta*tb)^2
-__device__ __forceinline__ bool tri_flat(const TriFastTerms &t, float cx, float cy, float px, float py, const TriF32 &k)
+// sin^2(beta) < 1/A_g,  or  min(sin a, sin b) * |sin g| < 2/A_g,  or a NaN anywhere
+__device__ __forceinline__ bool tri_flat(const TriFastTerms &t, float sb)
 {
-    const float ta = k.tl2 * fmaf(cx, cx, fmaf(cy, cy, 1.0f)), tb = k.tl2 * fmaf(px, px, fmaf(py, py, 1.0f));
-    const float tatb = ta * tb;
-    constexpr float k2 = (2.0f / kGuardAmp) * (2.0f / kGuardAmp);
-    return (t.Sb2 * kGuardAmp < tb) | ((t.D * t.D) * fminf(t.Sa2 * tb, t.Sb2 * ta) < (k2 * tatb) * tatb) | !(t.D == t.D);
+    return ((sb * sb) * kGuardAmp < 1.0f) | (fminf(t.sa, sb) * fabsf(t.Dn) < 2.0f / kGuardAmp) | !(t.Dn == t.Dn);
 }
 
-__device__ __forceinline__ bool tri_is_flat(float cx, float cy, float px, float py, const TriF32 &k)
+__device__ __forceinline__ bool tri_is_flat(float cx, float cy, float cb, float sb, const TriF32 &k)
 {
-    return tri_flat(tri_fast_terms(cx, cy, px, py, k), cx, cy, px, py, k);
+    return tri_flat(tri_fast_terms(cx, cy, cb, sb, k), sb);
 }
 
 // valid: bit j set = pixel j decodable; out = x0 y0 z0 x1 ... (NaN where not decodable).  GUARD = false: fast form everywhere (A/B).
-// cam4 / proj_lut + idx: where the lane's rays came from -- the rare path reads them again instead of keeping 16 registers alive.
+// cb / sb: the pixels' entries of the projector table's (cos, sin) half.  cam4 / proj_rays + idx: where the lane's exact float32 rays are --
+// the rare path reads them instead of keeping 16 registers alive.
 template <bool GUARD>
-__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&cb)[4], const float (&sb)[4],
                                                  uint32_t valid, const TriF32 &k, const double (&T)[3], double t_len, float (&out)[12],
-                                                 const float2 *__restrict__ cam4, const float2 *__restrict__ proj_lut, const uint32_t (&idx)[4])
+                                                 const float2 *__restrict__ cam4, const float2 *__restrict__ proj_rays, const uint32_t (&idx)[4])
 {
     uint32_t ill = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], px[j], py[j], k);
-        const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
-        if (GUARD) ill |= tri_flat(t, cx[j], cy[j], px[j], py[j], k) ? (1u << j) : 0u;
+        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], cb[j], sb[j], k);
         const bool ok = (valid >> j) & 1u;
-        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
-        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
-        out[3 * j + 2] = ok ? s : __builtin_nanf("");
+        const float s = ok ? (k.tl * sb[j]) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
+        if (GUARD) ill |= tri_flat(t, sb[j]) ? (1u << j) : 0u;
+        out[3 * j] = t.ex * s;
+        out[3 * j + 1] = t.ey * s;
+        out[3 * j + 2] = t.ez * s;
     }
     if (GUARD) {
         ill &= valid;
@@ -134,7 +146,7 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
 #pragma unroll 1
             for (int j = 0; j < 4; ++j) {
                 if (!((ill >> j) & 1u)) continue;
-                const float2 cr = cam4[j], pr = proj_lut[j == 0 ? idx[0] : j == 1 ? idx[1] : j == 2 ? idx[2] : idx[3]];
+                const float2 cr = cam4[j], pr = proj_rays[j == 0 ? idx[0] : j == 1 ? idx[1] : j == 2 ? idx[2] : idx[3]];
                 const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, T, t_len);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -150,35 +162,35 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
 // The fast pass alone: XYZ of the lane's four pixels by the float32 form, and which of them are flat (bit j of the result; decodable pixels
 // only).  The caller redoes the flagged pixels through law_of_sines_mirror -- the fused scan kernel compacts them over the WAVE first
 // (decode.hip), so a wave pays one pass per 64 flagged pixels instead of one pass per flagged position of its lanes.
-__device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], const float (&cy)[4], const float (&px)[4], const float (&py)[4],
+__device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], const float (&cy)[4], const float (&cb)[4], const float (&sb)[4],
                                                       uint32_t valid, const TriF32 &k, float (&out)[12])
 {
     uint32_t ill = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], px[j], py[j], k);
-        const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
-        ill |= tri_flat(t, cx[j], cy[j], px[j], py[j], k) ? (1u << j) : 0u;
+        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], cb[j], sb[j], k);
         const bool ok = (valid >> j) & 1u;
-        out[3 * j] = ok ? cx[j] * s : __builtin_nanf("");
-        out[3 * j + 1] = ok ? cy[j] * s : __builtin_nanf("");
-        out[3 * j + 2] = ok ? s : __builtin_nanf("");
+        const float s = ok ? (k.tl * sb[j]) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
+        ill |= tri_flat(t, sb[j]) ? (1u << j) : 0u;
+        out[3 * j] = t.ex * s;
+        out[3 * j + 1] = t.ey * s;
+        out[3 * j + 2] = t.ez * s;
     }
     return ill & valid;
 }
 
 // One pixel through the same arithmetic as triangulate4 (bit-identical results): the x-major scatter of slgc_cloud_dev triangulates a pixel where
-// it writes it.  cam_exact = this pixel's entry of the exact per-pixel camera table (read only on the guarded path).
+// it writes it.  cam_exact / proj_ray = this pixel's entries of the exact per-pixel camera table and of the projector RAY table (read only on the guarded path).
 template <bool GUARD>
-__device__ __forceinline__ Xyzf triangulate1(float cx, float cy, float px, float py, const TriF32 &k, const double (&T)[3], double t_len,
-                                             const float2 *__restrict__ cam_exact)
+__device__ __forceinline__ Xyzf triangulate1(float cx, float cy, float cb, float sb, const TriF32 &k, const double (&T)[3], double t_len,
+                                             const float2 *__restrict__ cam_exact, const float2 *__restrict__ proj_ray)
 {
-    const TriFastTerms t = tri_fast_terms(cx, cy, px, py, k);
-    const float s = (k.tl2 * t.Sb) * __builtin_amdgcn_rcpf(t.D);
-    Xyzf r{cx * s, cy * s, s};
-    if (GUARD && tri_flat(t, cx, cy, px, py, k)) {
-        const float2 cr = *cam_exact;
-        r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{px, py}, T, t_len);
+    const TriFastTerms t = tri_fast_terms(cx, cy, cb, sb, k);
+    const float s = (k.tl * sb) * __builtin_amdgcn_rcpf(t.Dn);
+    Xyzf r{t.ex * s, t.ey * s, t.ez * s};
+    if (GUARD && tri_flat(t, sb)) {
+        const float2 cr = *cam_exact, pr = *proj_ray;
+        r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, T, t_len);
     }
     return r;
 }

@@ -254,7 +254,9 @@ __global__ void __launch_bounds__(256) k_check_cam_nodes_direct(const Calib c, i
     if ((threadIdx.x & 63) == 0 && __float_as_uint(err) > *reinterpret_cast<volatile unsigned *>(worst)) atomicMax(worst, __float_as_uint(err));
 }
 
-__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, int proj_w, int proj_h, int tiles_x,
+// Both halves of the projector table, same tiled index: lut = the float32 rays cv2.undistortPoints returns (exact kernels, the guarded redo),
+// lut_cs = (cos(beta), sin(beta)) of each ray against the baseline (tri_math.h: what the fast form gathers).
+__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, float2 *__restrict__ lut_cs, int proj_w, int proj_h, int tiles_x,
                                                         size_t nslots, int wide)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -262,18 +264,20 @@ __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *_
     const int sh = wide ? 7 : 6, tw = wide ? 16 : 8;                        // slots per tile = 8 rows x tw pixels (proj_lut_index)
     const int tile = (int)(p >> sh), in = (int)(p & ((1u << sh) - 1u));
     const int pu = (tile % tiles_x) * tw + (in & (tw - 1)), pv = (tile / tiles_x) * 8 + (in / tw);
-    float2 o = make_float2(0.f, 0.f);
+    float2 o = make_float2(0.f, 0.f), cs = make_float2(0.f, 1.f);
     if (pu < proj_w && pv < proj_h) {
         const Ray2 b = undistort_point((float)pu, (float)pv, c.proj_k, c.proj_d, nullptr);
         o = make_float2(b.x, b.y);
+        proj_cos_sin(b.x, b.y, c.T, c.t_len, cs.x, cs.y);
     }
     lut[p] = o;
+    lut_cs[p] = cs;
 }
 
 struct TriConst {
     double T[3];
     double t_len;
-    TriF32 kf;               // T and |T|^2 in float32 for the fast form (tri_math.h)
+    TriF32 kf;               // T / |T| and |T| in float32 for the fast form (tri_math.h)
 };
 
 // Dense kernel.  Four pixels per lane (8-byte map loads, 32-byte ray loads).  The per-lane "4 consecutive pixels" layout is ideal for the streamed loads but makes
@@ -288,7 +292,7 @@ struct TriConst {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc, int16_t *__restrict__ h, int16_t *__restrict__ v,
                                                               const uint32_t *__restrict__ wire, const float2 *__restrict__ cam_lut,
-                                                              const float2 *__restrict__ proj_lut, size_t ngroups, int proj_w,
+                                                              const float2 *__restrict__ proj_lut, const float2 *__restrict__ proj_cs, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
                                                               unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store, int wide,
                                                               const CamNodes cn)
@@ -336,7 +340,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const uint32_t i = s_idx1[it * 256 + tid];
-        gr[it] = proj_lut[i != 0xffffffffu ? i : 0u];
+        gr[it] = (MODE == SLGC_TRI_EXACT ? proj_lut : proj_cs)[i != 0xffffffffu ? i : 0u];      // exact mode: the rays; fast form: their (cos, sin) against the baseline
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) s_ray[it * 256 + tid] = gr[it];
@@ -401,7 +405,7 @@ __global__ void __launch_bounds__(256) k_undistort_list(const Calib c, int which
 // Diagnostic: how many decodable pixels of a band take the guarded (float32-mirror) path of triangulate4 -- the same
 // tri_is_flat test on the same table rays.  counts[0] += decodable pixels, counts[1] += flagged pixels.
 __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const int16_t *__restrict__ h, const int16_t *__restrict__ v,
-                                                     const float2 *__restrict__ cam_lut, const float2 *__restrict__ proj_lut, size_t npix,
+                                                     const float2 *__restrict__ cam_lut, const float2 *__restrict__ proj_cs, size_t npix,
                                                      int proj_w, int proj_h, int tiles_x, int wide, unsigned long long *__restrict__ counts)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -410,7 +414,7 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
         const int hv = h[p], vv = v[p];
         if (!(hv == -1 || vv == -1)) {
             ok = 1;
-            const float2 c = cam_lut[p], q = proj_lut[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
+            const float2 c = cam_lut[p], q = proj_cs[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
             flat = tri_is_flat(c.x, c.y, q.x, q.y, tc.kf) ? 1u : 0u;
         }
     }
@@ -442,9 +446,9 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     TriConst tc;
     memcpy(tc.T, ctx->calib.T, sizeof tc.T);
     tc.t_len = ctx->calib.t_len;
-    tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
+    tc.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
-                       (const float2 *)ctx->lut_proj, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
+                       (const float2 *)ctx->lut_proj_cs, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -544,14 +548,16 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
             (void)hipFree(ctx->lut_proj);
             ctx->lut_proj = nullptr;
         }
-        void *proj = nullptr;
-        if (hipMalloc(&proj, nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
-        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)proj, proj_w, proj_h, tiles_x, nproj, wide);
+        void *proj = nullptr;                                  // one allocation: [rays | (cos, sin)], nproj entries each (nproj is a multiple of 64)
+        if (hipMalloc(&proj, 2 * nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
+        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)proj, (float2 *)proj + nproj, proj_w,
+                           proj_h, tiles_x, nproj, wide);
         if (hipGetLastError() != hipSuccess) {
             (void)hipFree(proj);
             return slgc_fail(ctx, SLGC_EHIP, "projector ray table build failed to launch");
         }
         ctx->lut_proj = proj;
+        ctx->lut_proj_cs = (float2 *)proj + nproj;
         ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h; ctx->lut_proj_tile = wide;
     }
     return SLGC_OK;
@@ -602,7 +608,7 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         TriConst tc;
         memcpy(tc.T, ctx->calib.T, sizeof tc.T);
         tc.t_len = ctx->calib.t_len;
-        tc.kf = TriF32{(float)ctx->calib.T[0], (float)ctx->calib.T[1], (float)ctx->calib.T[2], (float)(ctx->calib.t_len * ctx->calib.t_len)};
+        tc.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
         const size_t groups = npix / 4;
         const unsigned blocks = (unsigned)((groups + 255) / 256);
         const int tri_nt = ctx->tune_tri_nt;                     // XYZ leaves with non-temporal stores (A/B: slgc_tune "tri_nt")
@@ -612,15 +618,15 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         ctx->last_guard = mode == SLGC_TRI_EXACT ? 0 : 1;
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #ifdef SLGC_DIAG      // A/B of the guard's cost: only in the diagnostic build
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
             hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #endif
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;
