@@ -169,6 +169,7 @@ struct TriScatter {
     const float2 *proj_lut;      // projector rays (guarded redo)
     const float2 *proj_cs;       // (cos(beta), sin(beta)) per projector pixel, same index (fast form)
     int ptiles_x, wide;
+    int f32;                   // slgc_cloud32_dev: points and colours leave as float32 (12 instead of 24 bytes each per point) -- NOT the reference's dtypes
     TriF32 kf;
     double T[3], t_len;
 };
@@ -385,9 +386,16 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
                     const float2 pr = prj[j];
                     const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
                     if (!LISTS_ABL(2)) {
-                        pts[o] = (double)r3.x;                                       // Pts (3,M) float64, :95
-                        pts[M + o] = (double)r3.y;
-                        pts[2 * M + o] = (double)r3.z;
+                        if (ts.f32) {                                                // (3,M) float32 (slgc_cloud32_dev)
+                            float *p32 = reinterpret_cast<float *>(pts);
+                            p32[o] = r3.x;
+                            p32[M + o] = r3.y;
+                            p32[2 * M + o] = r3.z;
+                        } else {
+                            pts[o] = (double)r3.x;                                   // Pts (3,M) float64, :95
+                            pts[M + o] = (double)r3.y;
+                            pts[2 * M + o] = (double)r3.z;
+                        }
                     }
                 }
             }
@@ -400,7 +408,11 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const unsigned px = (unsigned)__builtin_amdgcn_ds_bpermute(rec_lane[k], (int)packed);
-                    if ((unsigned)(k * 32 + r) < 3 * n) colors[3 * o0 + k * 32 + r] = unit_of_byte((px >> ch_shift[k]) & 0xffu);   // :64, :69
+                    if ((unsigned)(k * 32 + r) < 3 * n) {
+                        const double u = unit_of_byte((px >> ch_shift[k]) & 0xffu);                             // :64, :69
+                        if (TRI && ts.f32) reinterpret_cast<float *>(colors)[3 * o0 + k * 32 + r] = (float)u;
+                        else colors[3 * o0 + k * 32 + r] = u;
+                    }
                 }
             }
         }
@@ -604,9 +616,16 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
             }
             const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
             if (!LISTS_ABL(2)) {
-                *reinterpret_cast<double *>(p0_b + o8) = (double)r3.x;                                          // Pts (3,M) float64, :95
-                *reinterpret_cast<double *>(p1_b + o8) = (double)r3.y;
-                *reinterpret_cast<double *>(p2_b + o8) = (double)r3.z;
+                if (ts.f32) {                                                                                   // (3,M) float32 (slgc_cloud32_dev): a group of 16 records = one 64-byte piece
+                    const unsigned o4 = o8 >> 1;
+                    *reinterpret_cast<float *>(p0_b + o4) = r3.x;
+                    *reinterpret_cast<float *>(p0_b + (size_t)M * 4 + o4) = r3.y;
+                    *reinterpret_cast<float *>(p0_b + (size_t)M * 8 + o4) = r3.z;
+                } else {
+                    *reinterpret_cast<double *>(p0_b + o8) = (double)r3.x;                                      // Pts (3,M) float64, :95
+                    *reinterpret_cast<double *>(p1_b + o8) = (double)r3.y;
+                    *reinterpret_cast<double *>(p2_b + o8) = (double)r3.z;
+                }
             } else if (r3.x == 12345.678f) {
                 *reinterpret_cast<double *>(p0_b + o8) = 0.0;
             }
@@ -618,7 +637,8 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
                 if (kc >= ka && kc < kb) {
                     const int rowc = s_list[c][min(max(kc, 0), TR - 1)];
                     const unsigned byte = reinterpret_cast<const uint8_t *>(&s_white[rowc][0])[3 * c + ch_of[q]];
-                    *reinterpret_cast<double *>(col_b + ((B0 + (unsigned)kp) * 24u + (unsigned)(32 * q + r) * 8u)) = unit_of_byte(byte);          // :64, :69
+                    if (ts.f32) *reinterpret_cast<float *>(col_b + ((B0 + (unsigned)kp) * 12u + (unsigned)(32 * q + r) * 4u)) = (float)unit_of_byte(byte);
+                    else *reinterpret_cast<double *>(col_b + ((B0 + (unsigned)kp) * 24u + (unsigned)(32 * q + r) * 8u)) = unit_of_byte(byte);          // :64, :69
                 }
             }
         }
@@ -906,7 +926,7 @@ int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, co
 // slgc_cloud_dev: the same lists straight from the int16 maps -- every valid pixel triangulated inside the scatter (no dense XYZ anywhere).
 // The ray tables of the whole image must be in place (ensure_luts(cam_h, cam_w, 0, ...), done by the caller).
 int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const uint8_t *d_white, int cam_w, int cam_h, int proj_w, int proj_h,
-                     float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total)
+                     float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total, int f32)
 {
     if (!d_pts)                      // lists only: nothing to triangulate
         return xmajor_lists<int16_t, 0>(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, d_white, d_cam, d_proj, d_white ? d_colors : nullptr, nullptr, nullptr, d_total);
@@ -917,6 +937,7 @@ int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, cons
     ts.proj_cs = (const float2 *)ctx->lut_proj_cs;
     ts.ptiles_x = proj_tiles_x(ctx, proj_w);
     ts.wide = ctx->tune_proj_tile;
+    ts.f32 = f32;
     ts.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     memcpy(ts.T, ctx->calib.T, sizeof ts.T);
     ts.t_len = ctx->calib.t_len;

@@ -167,7 +167,7 @@ int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int
 int launch_cloud_lists(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const float *d_xyz, const uint8_t *d_white, int cam_w, int cam_h,
                        int proj_w, int proj_h, float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total);
 int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, const uint8_t *d_white, int cam_w, int cam_h, int proj_w, int proj_h,
-                     float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total);
+                     float *d_cam, float *d_proj, double *d_pts, double *d_colors, unsigned long long *d_total, int f32 = 0);
 int launch_filter(slgc_ctx *ctx, const double *d_xyz, const double *d_colors, int64_t M, double thr, double *d_xyz_out,
                   double *d_colors_out, unsigned long long *d_total, int pass);
 int launch_compact_dense(slgc_ctx *ctx, const float *d_xyz, int rows, int W, int row0, float *d_points, uint32_t *d_keys,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slgc_cloud_lists_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "slgc_cloud_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slgc_cloud32_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slgc_compact_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "slgc_compact_records_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slgc_pack_hv24_dev": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
@@ -259,12 +260,12 @@ class DeviceBuffer:
 class CloudLists:
     """Device buffers of the reference-shaped product (slgc_cloud_lists_dev): capacity ``npix`` entries each."""
 
-    def __init__(self, ctx: "Context", npix: int, colors: bool = True, points: bool = True, lists: bool = True):
-        self.ctx, self.npix = ctx, int(npix)
+    def __init__(self, ctx: "Context", npix: int, colors: bool = True, points: bool = True, lists: bool = True, f32: bool = False):
+        self.ctx, self.npix, self.f32 = ctx, int(npix), bool(f32)      # f32: points / colours as float32 (slgc_cloud32_dev only; NOT the reference's dtypes)
         self.cam = ctx.alloc(max(16, self.npix * 8)) if lists else None           # lists=False (slgc_cloud_dev only): points + colours, no correspondence lists
         self.proj = ctx.alloc(max(16, self.npix * 8)) if lists else None
-        self.pts = ctx.alloc(max(16, self.npix * 24)) if points else None
-        self.colors = ctx.alloc(max(16, self.npix * 24)) if colors else None
+        self.pts = ctx.alloc(max(16, self.npix * (12 if f32 else 24))) if points else None
+        self.colors = ctx.alloc(max(16, self.npix * (12 if f32 else 24))) if colors else None
         self.count = ctx.alloc(8).zero()
 
     def total(self) -> int:
@@ -277,8 +278,9 @@ class CloudLists:
         M = self.total()
         cam = self.cam.download((M, 2), np.float32) if self.cam is not None else None
         proj = self.proj.download((M, 2), np.float32) if self.proj is not None else None
-        pts = self.pts.download((3, M), np.float64) if self.pts is not None else None
-        col = self.colors.download((M, 3), np.float64) if self.colors is not None else None
+        ft = np.float32 if self.f32 else np.float64
+        pts = self.pts.download((3, M), ft) if self.pts is not None else None
+        col = self.colors.download((M, 3), ft) if self.colors is not None else None
         return cam, proj, pts, col
 
     def free(self):
@@ -620,14 +622,14 @@ class Context:
         self._ck(lib().slgc_triangulate_maps_dev(self._h, d_h, d_v, rows, W, row0, int(proj_size[0]), int(proj_size[1]),
                                                  int(mode), d_xyz, d_count))
 
-    def alloc_cloud_lists(self, npix: int, colors: bool = True, points: bool = True, lists: bool = True) -> CloudLists:
-        return CloudLists(self, npix, colors, points, lists)
+    def alloc_cloud_lists(self, npix: int, colors: bool = True, points: bool = True, lists: bool = True, f32: bool = False) -> CloudLists:
+        return CloudLists(self, npix, colors, points, lists, f32)
 
     def cloud_lists_dev(self, d_h: int, d_v: int, d_xyz, d_white, cam_w, cam_h, proj_size, lists: CloudLists):
         """int16 maps + dense float32 XYZ (+ device-resident uint8 RGB white image) -> the reference's x-major lists, float64 (3,M)
         points and colours, all in HBM (asynchronous).  d_xyz / d_white may be None."""
-        if lists.cam is None:
-            raise ValueError("cloud_lists_dev always writes the correspondence lists: allocate the CloudLists with lists=True (only cloud_dev can leave them out)")
+        if lists.cam is None or lists.f32:
+            raise ValueError("cloud_lists_dev always writes the correspondence lists and float64 products: allocate the CloudLists with lists=True, f32=False")
         self._ck(lib().slgc_cloud_lists_dev(self._h, d_h, d_v, d_xyz if lists.pts is not None else None,      # d_xyz None + points wanted: triangulated in-kernel
                                             d_white if lists.colors is not None else None, int(cam_w), int(cam_h), int(proj_size[0]),
                                             int(proj_size[1]), lists.cam.ptr, lists.proj.ptr, lists.pts.ptr if lists.pts is not None else None,
@@ -637,7 +639,8 @@ class Context:
                   eps=1, m=10):
         """Whole scan -> the reference-shaped lists in one call (slgc_cloud_dev): decode kernel, then the x-major list build with the
         triangulation inside it -- no dense XYZ.  lists.pts / lists.colors may be absent."""
-        self._ck(lib().slgc_cloud_dev(self._h, d_stack, int(n_runs), int(run_stride), int(plane_stride), int(N), int(cam_h), int(cam_w),
+        fn = lib().slgc_cloud32_dev if lists.f32 else lib().slgc_cloud_dev      # lists.f32: float32 points / colours (not the reference's dtypes)
+        self._ck(fn(self._h, d_stack, int(n_runs), int(run_stride), int(plane_stride), int(N), int(cam_h), int(cam_w),
                                       int(proj_size[0]), int(proj_size[1]), float(eps), float(m), d_white if lists.colors is not None else None, d_h, d_v,
                                       lists.cam.ptr if lists.cam is not None else None, lists.proj.ptr if lists.proj is not None else None,
                                       lists.pts.ptr if lists.pts is not None else None,

@@ -312,6 +312,12 @@ int slgc_cloud_lists_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, 
 int slgc_cloud_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int cam_h, int cam_w,
                    int proj_w, int proj_h, double eps, double m, const uint8_t *d_white_rgb, int16_t *d_h, int16_t *d_v, float *d_cam_pts,
                    float *d_proj_pts, double *d_pts, double *d_colors, unsigned long long *d_total);
+/* slgc_cloud_dev with the points as float32 (3,M) and the colours as float32 [M][3]: an explicitly NON-reference product (the reference returns float64,
+ * triangulate.py:95, :69) for callers that do not need float64 -- the same values rounded to float32 (the points are float32 inside the kernels
+ * already), 40 instead of 64 bytes written per point with the correspondence lists, 24 instead of 48 without them.  d_pts32 is required. */
+int slgc_cloud32_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int cam_h, int cam_w,
+                     int proj_w, int proj_h, double eps, double m, const uint8_t *d_white_rgb, int16_t *d_h, int16_t *d_v, float *d_cam_pts,
+                     float *d_proj_pts, float *d_pts32, float *d_colors32, unsigned long long *d_total);
 
 /* Row-major compaction of a dense band: keeps pixels with finite XYZ; writes float32 [M][3] points and uint32
  * linear pixel keys ((row0+y)*W + x); *d_count (device) receives M.  Capacity of outputs: rows*W records. */

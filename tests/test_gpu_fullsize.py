@@ -446,6 +446,15 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     n3, n4, pts3, col3 = prod.download()
     assert n3 is None and n4 is None and np.array_equal(pts3, pts) and np.array_equal(col3, col)
     prod.free()
+    # slgc_cloud32_dev, the explicitly non-reference float32 product: exactly the float64 arrays rounded to float32, with and without the lists
+    for with_lists in (True, False):
+        p32 = ctx.alloc_cloud_lists(px, colors=True, lists=with_lists, f32=True)
+        ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, p32)
+        c5, p5, pts5, col5 = p32.download()
+        assert pts5.dtype == np.float32 and col5.dtype == np.float32 and pts5.shape == pts.shape and col5.shape == col.shape
+        assert np.array_equal(pts5, pts.astype(np.float32), equal_nan=True) and np.array_equal(col5, col.astype(np.float32))
+        assert (c5 is None and p5 is None) if not with_lists else (np.array_equal(c5, rcam) and np.array_equal(p5, rproj))
+        p32.free()
     print(f"\n{workload}: {len(rcam)} points, worst rel. XYZ error vs the oracle {float(err.max()):.2e}, {path}")
     for b in (stack, maps, maps2, xyz, white):
         b.free()

@@ -351,8 +351,15 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
         s = stacks[i % len(stacks)]
         ctx.cloud_dev(s.ptr, 1, N * plane, plane, N, rows, W, proj_size, white.ptr, prod, d_h=maps.at(0), d_v=maps.at(band_px * 2))
 
+    prod32 = ctx.alloc_cloud_lists(band_px, colors=True, lists=True, f32=True)
+
+    def via_cloud32(i):
+        s = stacks[i % len(stacks)]
+        ctx.cloud_dev(s.ptr, 1, N * plane, plane, N, rows, W, proj_size, white.ptr, prod32, d_h=maps.at(0), d_v=maps.at(band_px * 2))
+
     el_dense = run(via_dense)
     el_points = run(via_cloud_points)
+    el_f32 = run(via_cloud32)
     el = run(via_cloud)
     executed = ctx.last_scan_path()
     list_kernel = ctx.last_list_kernel()
@@ -377,6 +384,9 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
            "points_and_colours_only": {"value": round(band_px / 1e6 * K / el_points, 1), "ms_per_scan": round(el_points / K * 1e3, 4),
                                        "note": "slgc_cloud_dev without the two correspondence lists (intermediates of src/4-triangulate.py:62-64; the script keeps "
                                                "pts_3d and colors, :67-68): 48 instead of 64 bytes written per point"},
+           "float32_product": {"value": round(band_px / 1e6 * K / el_f32, 1), "ms_per_scan": round(el_f32 / K * 1e3, 4),
+                               "note": "slgc_cloud32_dev: the same lists with the points and colours as float32 -- NOT the reference's dtypes -- 40 instead of 64 "
+                                       "bytes written per point; for callers that do not need float64"},
            "via_dense_xyz": {"value": round(band_px / 1e6 * K / el_dense, 1), "ms_per_scan": round(el_dense / K * 1e3, 4),
                              "note": "round 2's route: fused scan (writes 12 B/pixel of dense XYZ) + slgc_cloud_lists_dev (reads it back)"},
            "note": "slgc_cloud_dev: decode kernel + x-major list build (count, column prefix, LDS-transposed scatter that triangulates each valid "
@@ -385,6 +395,7 @@ def reference_product(ctx, _native, stacks, N, plane, rows, W, row0, proj_size, 
     white.free()
     lists.free()
     prod.free()
+    prod32.free()
     return out
 
 
