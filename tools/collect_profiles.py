@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 src = os.path.join(ROOT, "gpurun_out", "final")
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 C3_GRID = 4096 * 3000 // 4          # threads of a 4-pixels-per-lane kernel over 4096x3000
 
 
@@ -42,36 +42,32 @@ with open(os.path.join(dst, f"{tag}_pmc_raw_c3.csv"), "w", newline="") as out:
 d = json.load(open(os.path.join(dst, f"{tag}_pmc_summary_c3.json")))
 
 
-def kernel_key(fused):
-    """k_decode_pk<PX, BLOCK, NT, MULTI, ABL, FUSE, NS> @grid: FUSE = 0 is the decode kernel, 1 / 2 the fused scan kernel."""
+def kernel_key(fused, grid=C3_GRID, variant="", bgr=False):
+    """k_decode_pk<PX, BLOCK, NT, MULTI, ABL, FUSE, NS, BGR> @grid [variant]: FUSE = 0 is the decode kernel, 1 / 2 / 3 the fused scan kernel, BGR = 1 its BGR-reading form."""
     for k in d:
-        m = re.match(r"k_decode_pk<([^>]*)> @grid=(\d+)$", k)                 # (keys ending in " [s-scene]" are the other capture: reported beside it)
-        if m and int(m.group(2)) == C3_GRID and "FETCH_SIZE" in d[k]:
+        m = re.match(r"k_decode_pk<([^>]*)> @grid=(\d+)( \[[a-z-]+\])?$", k)
+        if m and int(m.group(2)) == grid and (m.group(3) or "").strip() == variant and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]:
             args = [a.strip() for a in m.group(1).split(",")]
-            if (int(args[5]) != 0) == fused:
+            if (int(args[5]) != 0) == fused and ((len(args) > 7 and args[7] == "1") == bgr):
                 return k
-    raise SystemExit(f"no {'fused' if fused else 'decode'} kernel at grid {C3_GRID} in the PMC summary")
+    return None
 
 
-dec, fus = kernel_key(False), kernel_key(True)
 traffic = lambda k: int(round((2 * d[k]["FETCH_SIZE"]["mean"] + d[k]["WRITE_SIZE"]["mean"]) * 1024))   # noqa: E731
 note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh), profiles/%s_pmc_summary_c3.json + %s_pmc_raw_c3.csv; bytes = "
         "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)" % (tag, tag))
 fp = bench.csrc_fingerprint()
-t = {"c3_4096x3000x44/g1/split": {"kernel": dec, "hbm_bytes_per_launch": traffic(dec), "fetch_size_kb": d[dec]["FETCH_SIZE"]["mean"],
-                                  "write_size_kb": d[dec]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp, "source": note},
-     "c3_4096x3000x44/g1/fused": {"kernel": fus, "hbm_bytes_per_launch": traffic(fus), "fetch_size_kb": d[fus]["FETCH_SIZE"]["mean"],
-                                  "write_size_kb": d[fus]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
-                                  "source": note + "; includes the projector-ray gathers and the 4 B/pixel maps, which SURVEY 8(d)'s N + 12 does not count"}}
 C2_GRID = 1920 * 1080 // 4
-c2k = next((k for k in d if re.match(r"k_decode_pk<[^>]*, 2, 44> @grid=%d$" % C2_GRID, k) and "FETCH_SIZE" in d[k] and "WRITE_SIZE" in d[k]), None)
-if c2k:
-    t["c2_1920x1080x44/g1/fused"] = {"kernel": c2k, "hbm_bytes_per_launch": traffic(c2k), "fetch_size_kb": d[c2k]["FETCH_SIZE"]["mean"],
-                                     "write_size_kb": d[c2k]["WRITE_SIZE"]["mean"], "csrc_fingerprint": fp,
-                                     "source": note + "; 1920x1080 physical scene: the per-pixel camera table (16.6 MB) and the projector table are read through L2 from the Infinity Cache"}
-ss = fus + " [s-scene]"
-if ss in d and "FETCH_SIZE" in d[ss]:
-    t["c3_4096x3000x44/g1/fused"]["s_scene_hbm_bytes_per_launch"] = traffic(ss)
+t = {}
+# key = workload / g1 / pipeline / scene (bench.py: roofline.traffic falls back to these when it could not collect its own counters)
+for key, k in (("c3_4096x3000x44/g1/split/s-scene", kernel_key(False)), ("c3_4096x3000x44/g1/fused/physical", kernel_key(True)),
+               ("c3_4096x3000x44/g1/fused/s-scene", kernel_key(True, variant="[s-scene]")), ("c3_4096x3000x44/g1/fused/s-uniform", kernel_key(True, variant="[s-uniform]")),
+               ("c2_1920x1080x44/g1/fused/physical", kernel_key(True, grid=C2_GRID)), ("c3_4096x3000x44/g1/fused-bgr/physical", kernel_key(True, bgr=True))):
+    if k is None:
+        print("no PMC rows for", key)
+        continue
+    t[key] = {"kernel": k, "hbm_bytes_per_launch": traffic(k), "fetch_size_kb": d[k]["FETCH_SIZE"]["mean"], "write_size_kb": d[k]["WRITE_SIZE"]["mean"],
+              "csrc_fingerprint": fp, "source": note}
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
 line = [ln for ln in open(os.path.join(src, "bench_under_rocprof.log")) if ln.startswith("{")][0]
@@ -84,8 +80,9 @@ for name, j in (("plain", b), ("under rocprof", p)):
     print(f"{name:14s} value {j['value']:9.1f}  fused kernel {j['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['roofline']['frac']:.3f} | split decode "
           f"{j['split_pipeline']['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['split_pipeline']['roofline']['frac']:.3f} | decode alone "
           f"{j['decode_kernel_alone']['roofline']['frac']:.3f} | throughput {j.get('throughput_mode', {}).get('value')}")
-alg = {"split": 48 * 4096 * 3000, "fused": 56 * 4096 * 3000}
-print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / alg[k.rsplit("/", 1)[1]], 3)) for k, v in t.items()}, "fingerprint", fp)
+alg = {"split": 48, "fused": 56, "fused-bgr": 144}
+print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / (alg[k.split("/")[2]] * (1920 * 1080 if k.startswith("c2") else 4096 * 3000)), 3)) for k, v in t.items()},
+      "fingerprint", fp)
 
 # the "next" rows, the list stage, the host API and the store-pattern microbenchmark of the same box
 try:
@@ -101,7 +98,8 @@ for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_st
     except ValueError:
         print("no", sub)
 for f, name in (("next_rows.log", "next_rows.txt"), ("lists_plain.log", "list_stage.txt"), ("host_api.log", "host_api.txt"), ("dropin.log", "dropin.txt"), ("write_patterns.txt", "write_patterns.txt"),
-                ("cloud.log", "reference_product.txt"), ("pmc_lists/summary.txt", "pmc_list_stage.txt"), ("stream_rates.txt", "stream_rates.txt")):
+                ("cloud.log", "reference_product.txt"), ("pmc_lists/summary.txt", "pmc_list_stage.txt"), ("stream_rates.txt", "stream_rates.txt"),
+                ("ingest.log", "ingest.txt"), ("batch_rounds.log", "batch_rounds.txt"), ("ab_guard.log", "guard_forms.txt")):
     if os.path.exists(os.path.join(src, f)):
         keep = [ln for ln in open(os.path.join(src, f), errors="replace") if not re.match(r"^(RCCL|HIP|ROCm|Hostname|Librccl|[WEI]\d{8}) ", ln)]
         open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)

@@ -17,7 +17,8 @@ for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
   python3 bench.py --workload $w --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > "$out/bench_$w.json"
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --no-cpu-baseline --no-throughput-mode > "$out/bench_c2_under_rocprof.log" 2>&1
-python3 bench.py --scene s-scene --no-cpu-baseline --no-throughput-mode 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sscene_headline.json"
+python3 bench.py --scene s-scene --no-cpu-baseline --no-throughput-mode --no-small-images 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sscene_headline.json"
+python3 bench.py --scene physical-survey --no-cpu-baseline --no-throughput-mode --no-small-images 2>/dev/null | grep '^{' | tail -1 > "$out/bench_physical_survey_headline.json"
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$out/bench_steps20.json"      # what the driver runs
 python3 bench.py --force-sharded --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
 python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_xyz.json"
@@ -29,6 +30,10 @@ python3 tools/time_lists.py --knobs route=0,1 2>/dev/null | grep "list stage" > 
 LISTS_ROUTE=1 python3 tools/time_lists.py --knobs lists_lines=0,1 2>/dev/null | grep "list stage" >> "$out/lists_plain.log"
 bash tools/jobs/pmc_lists.sh "$out/pmc_lists" > "$out/pmc_lists.log" 2>&1
 for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_cloud.py --workload $w 2>/dev/null | grep "per scan"; done > "$out/cloud.log"
+for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_ingest.py --workload $w 2>/dev/null | grep "scan from BGR"; done > "$out/ingest.log"
+python3 tools/time_batch_rounds.py 2>/dev/null | grep "batch of" > "$out/batch_rounds.log"
+for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do for sc in physical s-scene s-uniform noisy-physical; do
+  python3 tools/ab_fused.py --knobs "guard_list=0,1" --workload $w --scene $sc --rounds 4 --iters 30 2>/dev/null | grep -E "scene=|guard_list="; done; done > "$out/ab_guard.log"
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
 python3 tools/time_dropin.py 2>/dev/null | grep -E "^pass|^c3|^  " > "$out/dropin.log"
 [ -x tools/ubench/write_patterns ] && tools/ubench/write_patterns > "$out/write_patterns.txt" 2>&1

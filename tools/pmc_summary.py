@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
         short = m.group(1) if m else name.split("(")[0].strip()
         rel = os.path.relpath(f, out).split(os.sep)[0]
-        variant = " [s-scene]" if rel.endswith("_sscene") else ""              # tools/pmc.sh: the fused kernel on the other synthetic capture
+        variant = " [s-scene]" if rel.endswith("_sscene") else " [s-uniform]" if rel.endswith("_suniform") else ""      # tools/pmc.sh: the fused kernel on the other synthetic captures
         acc[f"{short} @grid={row['Grid_Size']}{variant}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary = {}
 for k, ctrs in sorted(acc.items()):
