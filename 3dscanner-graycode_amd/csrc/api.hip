@@ -326,7 +326,6 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
     }
     if (ctx->lut_proj) (void)hipFree(ctx->lut_proj);
     if (ctx->count_slots) (void)hipFree(ctx->count_slots);
-    if (ctx->list_ticket) (void)hipFree(ctx->list_ticket);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int i = 0; i < SLGC_MAX_EVENTS; ++i)
         if (ctx->events[i]) (void)hipEventDestroy(ctx->events[i]);

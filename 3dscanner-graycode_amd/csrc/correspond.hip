@@ -61,10 +61,42 @@ __global__ void __launch_bounds__(256) k_xmajor_count(const MapT *__restrict__ h
 // A workgroup = 64 columns x 16 groups of consecutive chunks (lanes along x: coalesced).  Every thread sums its group, the groups meet in
 // LDS, then every thread rewrites its group's counts as "valid pixels above this chunk in column x".
 constexpr int kPrefixGroups = 16;
-
-// ---- x-major: pass B2: exclusive scan of the column totals by ONE workgroup of 1024 threads ----
-__device__ __forceinline__ void colscan_body(int W, unsigned long long *__restrict__ colstart, unsigned long long *__restrict__ total, unsigned long long (&wsum)[16])
+__global__ void __launch_bounds__(64 * kPrefixGroups) k_xmajor_colprefix(unsigned *__restrict__ counts, int W, int nchunks,
+                                                                         unsigned long long *__restrict__ colstart)
 {
+    __shared__ unsigned part[kPrefixGroups][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int per = (nchunks + kPrefixGroups - 1) / kPrefixGroups;
+    const int c0 = min(nchunks, g * per), c1 = min(nchunks, c0 + per);
+    unsigned sum = 0;
+    if (x < W) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) sum += counts[(size_t)c * W + x];
+    }
+    part[g][lane] = sum;
+    __syncthreads();
+    unsigned run = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kPrefixGroups; ++i) {
+        const unsigned n = part[i][lane];
+        run += i < g ? n : 0u;
+        all += n;
+    }
+    if (x >= W) return;
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+        const unsigned n = counts[(size_t)c * W + x];
+        counts[(size_t)c * W + x] = run;  // valid pixels above this chunk in column x
+        run += n;
+    }
+    if (g == 0) colstart[x] = all;  // column total for now
+}
+
+// ---- x-major: pass B2, one workgroup: exclusive scan of the column totals ----
+__global__ void __launch_bounds__(1024) k_xmajor_colscan(int W, unsigned long long *__restrict__ colstart, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (W + 1023) / 1024;                 // each thread owns a contiguous slab of columns: the scan stays ordered
     const int x0 = min(W, t * per), x1 = min(W, x0 + per);
@@ -92,55 +124,6 @@ __device__ __forceinline__ void colscan_body(int W, unsigned long long *__restri
         colstart[x] = acc;
         acc += n;
     }
-}
-
-// Pass B1 + B2 in one launch (round 4: the separate one-workgroup scan kernel cost 5 us of launch latency per list build): every workgroup writes
-// its 64 column totals, the LAST one to finish -- an agent-scope ticket -- scans all W of them.  ticket: one zeroed word of the context, reset by
-// its last user.
-__global__ void __launch_bounds__(64 * kPrefixGroups) k_xmajor_colprefix(unsigned *__restrict__ counts, int W, int nchunks,
-                                                                         unsigned long long *__restrict__ colstart, unsigned long long *__restrict__ total,
-                                                                         unsigned *__restrict__ ticket)
-{
-    static_assert(64 * kPrefixGroups == 1024, "the scan of the column totals runs on this workgroup's 1024 threads");
-    __shared__ unsigned part[kPrefixGroups][64];
-    __shared__ unsigned long long wsum[16];
-    __shared__ unsigned s_last;
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const int per = (nchunks + kPrefixGroups - 1) / kPrefixGroups;
-    const int c0 = min(nchunks, g * per), c1 = min(nchunks, c0 + per);
-    unsigned sum = 0;
-    if (x < W) {
-#pragma unroll 8
-        for (int c = c0; c < c1; ++c) sum += counts[(size_t)c * W + x];
-    }
-    part[g][lane] = sum;
-    __syncthreads();
-    unsigned run = 0, all = 0;
-#pragma unroll
-    for (int i = 0; i < kPrefixGroups; ++i) {
-        const unsigned n = part[i][lane];
-        run += i < g ? n : 0u;
-        all += n;
-    }
-    if (x < W) {
-#pragma unroll 8
-        for (int c = c0; c < c1; ++c) {
-            const unsigned n = counts[(size_t)c * W + x];
-            counts[(size_t)c * W + x] = run;  // valid pixels above this chunk in column x
-            run += n;
-        }
-        if (g == 0) colstart[x] = all;  // column total for now
-    }
-    // hand-over to the last workgroup: every storing wave's stores are drained and released at agent scope before the ticket is taken
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                       // acquire: the other workgroups' column totals, not this CU's stale lines
-    colscan_body(W, colstart, total, wsum);
-    if (threadIdx.x == 0) *ticket = 0u;                    // ready for the next list build on this context
 }
 
 // ---- x-major: pass C, scatter through an LDS transpose ----
@@ -877,15 +860,10 @@ int xmajor_lists(slgc_ctx *ctx, const MapT *d_h, const MapT *d_v, int cam_w, int
     if (rc) return rc;
     const int groups_x = (cam_w + 63) / 64;
     if (npix) hipLaunchKernelGGL(k_xmajor_count<MapT>, dim3(groups_x, nchunks), dim3(256), 0, ctx->stream, d_h, d_v, cam_w, cam_h, (unsigned *)counts);
-    if (!ctx->list_ticket) {                            // the ticket word of k_xmajor_colprefix: zeroed once, reset by every build
-        HIP_TRY(ctx, hipMalloc(&ctx->list_ticket, 64));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->list_ticket, 0, 64, ctx->stream));
-    }
     if (cam_w)
         hipLaunchKernelGGL(k_xmajor_colprefix, dim3(groups_x), dim3(64 * kPrefixGroups), 0, ctx->stream, (unsigned *)counts, cam_w, npix ? nchunks : 0,
-                           (unsigned long long *)colstart, d_total, (unsigned *)ctx->list_ticket);
-    else
-        HIP_TRY(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream));
+                           (unsigned long long *)colstart);
+    hipLaunchKernelGGL(k_xmajor_colscan, dim3(1), dim3(1024), 0, ctx->stream, cam_w, (unsigned long long *)colstart, d_total);
     if constexpr (SRC == 2 && sizeof(MapT) == 2 && TC == 64) {
         // slgc_cloud_dev's scatter in whole 128-byte lines (k_xmajor_lines) when the shape allows its dword loads; "lists_lines" 0 = the tile-run kernel (A/B)
         // ("lists_lines" 1 = where it pays: the tile-run kernel is the faster one while the image is only one or two rounds of resident workgroups --

@@ -95,7 +95,6 @@ struct slgc_ctx {
     unsigned img_err_ver;
     int img_err_W, img_err_rows;
     void *count_slots;  // hashed valid-pixel counters (triangulate.hip)
-    void *list_ticket;  // one zeroed word: the last-workgroup ticket of the x-major list build's prefix pass (correspond.hip)
     unsigned lut_cam_ver, lut_proj_ver;
     int lut_cam_W, lut_cam_row0, lut_cam_rows, lut_proj_w, lut_proj_h, lut_proj_tile;
     // results kept on the device between *_count and *_fetch
