@@ -367,12 +367,54 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             }
             out[3 * j] = X; out[3 * j + 1] = Y; out[3 * j + 2] = Z;
         }
-    } else {
-        triangulate4<MODE != 2>(cx, cy, px, py, valid, tc.kf, tc.T, tc.t_len, out, cam_lut + 4 * g, proj_lut, idx);      // MODE 2: unguarded (A/B, diagnostic build)
+    }
+    uint32_t ill = 0;
+    if constexpr (MODE != SLGC_TRI_EXACT) {
+        ill = triangulate4_flag(cx, cy, px, py, valid, tc.kf, out);      // px / py hold the gathered (cos(beta), sin(beta))
+        if (MODE == 2) ill = 0;                                          // MODE 2: unguarded (A/B, diagnostic build)
     }
     s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
     s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
     s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
+    if constexpr (MODE != SLGC_TRI_EXACT) {
+        // Flat triangles (tri_math.h) are redone in float64 on the reference's float32 intermediates.  Like the fused scan kernel this one compacts
+        // them first -- here over the whole WORKGROUP, which exchanges through LDS anyway: ballots + per-wave counts rank the flagged pixels of the
+        // 1024 into one list, and thread k redoes list entry k (a lane-level loop walked the float64 path once per flagged POSITION of each wave:
+        // scattered wrong codes -- S-uniform -- cost the dense kernel 80 us instead of 45 at 4096x3000).
+        __shared__ unsigned short s_list[1024];
+        __shared__ unsigned s_cnt[4];
+        const int wave = tid >> 6, lane = tid & 63;
+        unsigned long long m[4];
+        unsigned nw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = __builtin_amdgcn_ballot_w64((ill >> j) & 1u);
+            nw += (unsigned)__builtin_popcountll(m[j]);
+        }
+        if (lane == 0) s_cnt[wave] = nw;
+        __syncthreads();
+        const unsigned c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], total = c0 + c1 + c2 + s_cnt[3];
+        if (total) {                                                     // workgroup-uniform
+            unsigned at = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((ill >> j) & 1u) s_list[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], 0u))] = (unsigned short)(4 * tid + j);
+                at += (unsigned)__builtin_popcountll(m[j]);
+            }
+            __syncthreads();
+            float *s_xyz = reinterpret_cast<float *>(s_buf);
+            const float2 *cam_wg = cam_lut + 4 * ((size_t)bid * 256);    // the workgroup's first pixel in the exact per-pixel table
+#pragma unroll 1
+            for (unsigned k = (unsigned)tid; k < total; k += 256u) {
+                const unsigned p = s_list[k];
+                const float2 cr = cam_wg[p], pr = proj_lut[s_idx1[p]];
+                const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
+                s_xyz[3 * p] = r.x;
+                s_xyz[3 * p + 1] = r.y;
+                s_xyz[3 * p + 2] = r.z;
+            }
+        }
+    }
     __syncthreads();
     const size_t first = (size_t)bid * 256;
     const size_t nvec = (ngroups - first < 256 ? ngroups - first : 256) * 3;      // float4s this workgroup owns
