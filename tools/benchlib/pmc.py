@@ -45,7 +45,7 @@ def _run_child(counter, bench_py, child_args, outdir, timeout_s):
     return vals, None
 
 
-def collect(bench_py, workload, scene, pipeline, grid_size, timeout_s=150.0):
+def collect(bench_py, workload, scene, pipeline, grid_size, timeout_s=90.0):
     """-> ({"fetch_size_kb", "write_size_kb", "hbm_bytes_per_launch", "launches", "source"} or None, note)"""
     if os.environ.get("SLGC_BENCH_PMC_CHILD") == "1":
         return None, "this is a counter child"
