@@ -139,3 +139,47 @@ def test_bgr_scan_at_bench_sizes_every_pixel(ctx, workload):
     print(f"\n{workload} from BGR frames: {valid} / {px} decodable, worst rel. XYZ error {worst:.2e}")
     for b in (bgr, maps, xyz):
         b.free()
+
+
+def test_new_entry_points_refuse_bad_arguments(ctx):
+    """Error behaviour of the round-4 entry points: int status + message across the C-ABI (the binding raises ValueError for SLGC_EINVAL, SlgcError
+    otherwise), the context stays usable."""
+    from scanner import _native
+    W, H, N = 64, 16, 44
+    ctx.set_calibration(*bench.calibration(W, H, 64, 48))
+    px = W * H
+    bgr, xyz, maps = ctx.alloc(3 * N * px), ctx.alloc(px * 12), ctx.alloc(px * 4)
+    with pytest.raises((ValueError, _native.SlgcError), match="coeff_bits"):
+        ctx.scan_bgr_dev(bgr.ptr, 1, 3 * N * px, 3 * px, N, H, W, 0, (64, 48), xyz.ptr, coeff_bits=13)
+    with pytest.raises((ValueError, _native.SlgcError), match="plane_stride"):
+        ctx.scan_bgr_dev(bgr.ptr, 1, 3 * N * px, px, N, H, W, 0, (64, 48), xyz.ptr)                     # a grey plane stride for BGR planes
+    with pytest.raises((ValueError, _native.SlgcError), match="null"):
+        ctx.scan_bgr_dev(None, 1, 3 * N * px, 3 * px, N, H, W, 0, (64, 48), xyz.ptr)
+    with pytest.raises((ValueError, _native.SlgcError), match="unsupported N"):
+        ctx.scan_bgr_dev(bgr.ptr, 1, 3 * 13 * px, 3 * px, 13, H, W, 0, (64, 48), xyz.ptr)
+    with pytest.raises((ValueError, _native.SlgcError), match="integer eps"):
+        ctx.scan_bgr_dev(bgr.ptr, 1, 3 * N * px, 3 * px, N, H, W, 0, (64, 48), xyz.ptr, eps=0.5)
+    with pytest.raises((ValueError, _native.SlgcError), match="bad synth"):
+        ctx.synth_uniform_dev(bgr.ptr, px, N, H, 63, seed=1)                                             # W not a multiple of 4
+    with pytest.raises((ValueError, _native.SlgcError), match="bad synth"):
+        ctx.synth_physical_dev(bgr.ptr, px, N, H, W, (64, 48), gains=(10, 999), r2_max=1.0)
+    with pytest.raises((ValueError, _native.SlgcError), match="bad synth"):
+        ctx.synth_bgr_dev(bgr.ptr, px, N, H, W, xyz.ptr, px)                                              # BGR plane stride too small
+    p32 = ctx.alloc_cloud_lists(px, colors=False, points=False, f32=True)
+    with pytest.raises((ValueError, _native.SlgcError), match="d_pts32 is required"):
+        ctx.cloud_dev(bgr.ptr, 1, N * px, px, N, H, W, (64, 48), None, p32)
+    p32.free()
+    lists32 = ctx.alloc_cloud_lists(px, f32=True)
+    with pytest.raises(ValueError, match="float64"):
+        ctx.cloud_lists_dev(maps.at(0), maps.at(px * 2), None, None, W, H, (64, 48), lists32)
+    lists32.free()
+    # an empty band is not an error
+    ctx.scan_bgr_dev(bgr.ptr, 1, 0, 0, N, 0, W, 0, (64, 48), xyz.ptr)
+    ctx.synchronize()
+    # ... and the context still works
+    bench.synth_into(ctx, "s-scene", maps.ptr if False else bgr.ptr, px, N, H, W, (64, 48), 1)
+    ctx.scan_dev(bgr.ptr, 1, N * px, px, N, H, W, 0, (64, 48), xyz.ptr)
+    ctx.synchronize()
+    assert np.isfinite(xyz.download((H, W, 3), np.float32)).any()
+    for b in (bgr, xyz, maps):
+        b.free()
