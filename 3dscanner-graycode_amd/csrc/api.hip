@@ -1229,16 +1229,22 @@ extern "C" int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs
         if ((rc = prof_mark(ctx, 0))) return rc;
         if ((rc = launch_scan_fused(ctx, g, runs, plane_stride, npix, e, d_h, d_v, ctx->lut_cam, ctx->lut_proj, d_xyz, proj_w, proj_h, 1, 0, coeff_bits))) return rc;
         ctx->last_scan_path = SLGC_PATH_FUSED_BGR;
+        ctx->decode_pending = 0;
         return prof_mark(ctx, 1);
     }
     // grey stack in scratch, frames packed back to back, then the ordinary scan
     void *gray;
     const size_t gplane = (npix + 15) & ~(size_t)15;
     if ((rc = slgc_ws(ctx, 11, (size_t)n_runs * N * gplane + 64, &gray))) return rc;
-    for (int r = 0; r < n_runs; ++r)
+    for (int r = 0; r < n_runs; ++r) {
+        if (plane_stride == 3 * npix && gplane == npix) {          // frames back to back on both sides: the whole run in one launch
+            if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)runs.p[r], (uint8_t *)gray + (size_t)r * N * gplane, (size_t)N * npix, coeff_bits))) return rc;
+            continue;
+        }
         for (int f = 0; f < N; ++f)
             if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)runs.p[r] + (size_t)f * plane_stride, (uint8_t *)gray + ((size_t)r * N + f) * gplane, npix, coeff_bits)))
                 return rc;
+    }
     return slgc_scan_dev(ctx, (const uint8_t *)gray, n_runs, (size_t)N * gplane, gplane, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h, d_v, d_xyz, d_count);
 }
 

@@ -414,6 +414,9 @@ struct FrameSpec {
 #ifndef SLGC_PARK_DEPTH
 #define SLGC_PARK_DEPTH 2      // steps of frame loads in flight ahead of the step being classified (specialised kernels)
 #endif
+#ifndef SLGC_MIN_WAVES
+#define SLGC_MIN_WAVES 8       // waves per SIMD the 4-pixels-per-lane kernels are held to (<= 64 VGPRs); variant builds relax it for deeper prefetch (A/B)
+#endif
 constexpr int kWaveLdsBytes = 4096;     // LDS block of one wave: fused tail [indices 1 KB | rays / XYZ 3 KB], aliased by the 12 parked frames (3 KB)
 constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pixels (one byte each), behind the blocks of all waves -- inside the same
                                         // 1280-byte LDS allocation granule of gfx950 as the two 4 KB blocks (8704 -> 8960 B, as 8192 is): no wave less per CU
@@ -428,7 +431,7 @@ constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pi
 // OpenCV's 8-bit luma in registers -- the grey stack of src/3-capture_decode.py:66-70 never exists in HBM.  Raw frames in flight are three
 // registers each: 4 waves per SIMD (<= 128 VGPRs), every wave with three times the bytes in flight.
 template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0, int BGR = 0>
-__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : 8) : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
+__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC_MIN_WAVES) : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NR = BGR ? 3 : NW;      // ... as loaded
