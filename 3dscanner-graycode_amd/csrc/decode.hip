@@ -263,7 +263,20 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     uint64_t batch_stride;    // bytes between the stacks of consecutive scans (maps and XYZ of consecutive scans are npix apart)
     TriF32 kf;                // T / |T| and |T| in float32 for the fast form
     double T[3], t_len;
+#ifdef SLGC_STAMPS            // stamp build (make variant NAME=stamps EXTRA=-DSLGC_STAMPS; tools/time_stamps.py): 5 x s_memrealtime per wave, into memory nothing else reads
+    unsigned long long *stamps;
+#endif
 };
+
+#ifdef SLGC_STAMPS
+#define SLGC_STAMP(i)                                                                                                              \
+    do {                                                                                                                           \
+        if (FUSE != 0 && a.f.stamps && (threadIdx.x & 63) == 0)                                                                    \
+            a.f.stamps[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 5 + (i)] = __builtin_amdgcn_s_memrealtime();     \
+    } while (0)
+#else
+#define SLGC_STAMP(i) do { } while (0)
+#endif
 
 // cv2.cvtColor(BGR2GRAY) on 8-bit pixels inside the frame load (src/3-capture_decode.py:66): Y = (B*BY + G*GY + R*RY + rnd) >> shift.
 // A lane's 4 pixels arrive as 12 bytes B0 G0 R0 B1 G1 R1 B2 G2 R2 B3 G3 R3 in three dwords; pixel 0 IS dword 0 with a zero coefficient for
@@ -450,6 +463,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
             bid -= scan * a.f.batch_bps;
         }
     }
+    SLGC_STAMP(0);                                   // wave started
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t voff = BGR ? 3u * off : off;      // byte offset of the lane's pixels inside a plane
     const uint32_t ps = a.plane_stride;
@@ -563,6 +577,10 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
             }
         }
         uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
+#ifdef SLGC_STAMPS
+        asm volatile("" : "+v"(KA[0]), "+v"(KB[0]), "+v"(C1[0]), "+v"(C2[0]));      // the thresholds exist
+        SLGC_STAMP(1);                                   // threshold frames arrived, thresholds computed
+#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
         // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
@@ -614,6 +632,10 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         }
     }
 
+#ifdef SLGC_STAMPS
+    asm volatile("" : "+v"(mB_h[0]), "+v"(mB_v[0]), "+v"(mV_h[0]), "+v"(mV_v[0]));
+    SLGC_STAMP(2);                                       // every frame consumed
+#endif
     // accumulators hold the L code bits in bits 0 .. L-1 of each half
     const uint32_t full = ((1u << L) - 1u) * 0x00010001u;
     uint32_t oh[NP], ov[NP];
@@ -791,6 +813,11 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
                     dst[it * SPAN + t] = s_buf[it * SPAN + t];
                 }
             }
+#ifdef SLGC_STAMPS
+        SLGC_STAMP(3);                                   // tail done, stores issued
+        __builtin_amdgcn_s_waitcnt(0);                   // ... and acknowledged
+        SLGC_STAMP(4);
+#endif
     }
 }
 
@@ -1125,6 +1152,15 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         b.f.batch_stride = batch_stride;
         blocks *= (unsigned)n_batch;
     }
+#ifdef SLGC_STAMPS
+    {
+        void *st = nullptr;
+        const size_t nw = (size_t)blocks * 2;
+        if (slgc_ws(ctx, 11, nw * 5 * 8 + 64, &st)) return SLGC_ENOMEM;
+        b.f.stamps = (unsigned long long *)st;
+        ctx->stamp_waves = nw;
+    }
+#endif
     const bool wave = b.f.wave_tail != 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;
@@ -1182,6 +1218,19 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
+
+#ifdef SLGC_STAMPS
+// stamp build only: the 5 stamps per wave of the last fused launch (100 MHz ticks of s_memrealtime), wave-major
+extern "C" int slgc_diag_stamps(slgc_ctx *ctx, unsigned long long *host, size_t cap_waves, size_t *n_waves)
+{
+    if (!ctx || !host || !n_waves) return SLGC_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = ctx->stamp_waves < cap_waves ? ctx->stamp_waves : cap_waves;
+    if (n) HIP_TRY(ctx, hipMemcpy(host, ctx->ws[11], n * 5 * 8, hipMemcpyDeviceToHost));
+    *n_waves = ctx->stamp_waves;
+    return SLGC_OK;
+}
+#endif
 
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz)

@@ -80,6 +80,7 @@ struct slgc_ctx {
     void *stage;            // pinned host staging (float64 stacks narrowed to uint8 before the upload)
     size_t stage_bytes;
     int last_input_path;    // slgc_last_input_path
+    size_t stamp_waves;     // stamp build only (SLGC_STAMPS): waves of the last fused launch
     // calibration
     bool have_calib;
     Calib calib;
