@@ -785,15 +785,26 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
                 wave_lds_sync();
                 float *s_xyz = reinterpret_cast<float *>(s_buf);
                 const float2 *cam_wave = a.f.cam_lut + (off - 4u * (uint32_t)t);         // the wave's first pixel in the exact per-pixel table
-#pragma unroll 1
-                for (uint32_t base = 0; base < n; base += 64u) {
-                    if (base + (uint32_t)t < n) {
-                        const uint32_t p = s_list[base + t];
-                        const float2 cr = cam_wave[p], pr = a.f.proj_lut[s_idx1[p]];
-                        const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, a.f.T, a.f.t_len);
-                        s_xyz[3 * p] = r.x;
-                        s_xyz[3 * p + 1] = r.y;
-                        s_xyz[3 * p + 2] = r.z;
+                // up to 4 passes (256 pixels): the exact rays of ALL of a lane's entries are requested before the first pass computes -- one memory
+                // round trip per wave, not one per pass (a wave inside a flat region has all 256 pixels on its list)
+                const uint32_t npass = (n + 63u) >> 6;                                    // wave-uniform
+                uint32_t pq[4];
+                float2 crq[4], prq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((uint32_t)q < npass) {
+                        pq[q] = s_list[min(64u * q + (uint32_t)t, n - 1u)];
+                        crq[q] = cam_wave[pq[q]];
+                        prq[q] = a.f.proj_lut[s_idx1[pq[q]]];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((uint32_t)q < npass && 64u * q + (uint32_t)t < n) {
+                        const Xyzf r = law_of_sines_mirror(Ray2{crq[q].x, crq[q].y}, Ray2{prq[q].x, prq[q].y}, a.f.T, a.f.t_len);
+                        s_xyz[3 * pq[q]] = r.x;
+                        s_xyz[3 * pq[q] + 1] = r.y;
+                        s_xyz[3 * pq[q] + 2] = r.z;
                     }
                 }
             }

@@ -404,14 +404,27 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
             __syncthreads();
             float *s_xyz = reinterpret_cast<float *>(s_buf);
             const float2 *cam_wg = cam_lut + 4 * ((size_t)bid * 256);    // the workgroup's first pixel in the exact per-pixel table
-#pragma unroll 1
-            for (unsigned k = (unsigned)tid; k < total; k += 256u) {
-                const unsigned p = s_list[k];
-                const float2 cr = cam_wg[p], pr = proj_lut[s_idx1[p]];
-                const Xyzf r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, tc.T, tc.t_len);
-                s_xyz[3 * p] = r.x;
-                s_xyz[3 * p + 1] = r.y;
-                s_xyz[3 * p + 2] = r.z;
+            // up to 4 entries per thread (1 024 pixels): the exact rays of all of them are requested before the first one computes (one memory round
+            // trip per workgroup, not one per pass)
+            const unsigned npass = (total + 255u) >> 8;                  // workgroup-uniform
+            unsigned pq[4];
+            float2 crq[4], prq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((unsigned)q < npass) {
+                    pq[q] = s_list[min(256u * q + (unsigned)tid, total - 1u)];
+                    crq[q] = cam_wg[pq[q]];
+                    prq[q] = proj_lut[s_idx1[pq[q]]];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((unsigned)q < npass && 256u * q + (unsigned)tid < total) {
+                    const Xyzf r = law_of_sines_mirror(Ray2{crq[q].x, crq[q].y}, Ray2{prq[q].x, prq[q].y}, tc.T, tc.t_len);
+                    s_xyz[3 * pq[q]] = r.x;
+                    s_xyz[3 * pq[q] + 1] = r.y;
+                    s_xyz[3 * pq[q] + 2] = r.z;
+                }
             }
         }
     }
