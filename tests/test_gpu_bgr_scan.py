@@ -183,3 +183,56 @@ def test_new_entry_points_refuse_bad_arguments(ctx):
     assert np.isfinite(xyz.download((H, W, 3), np.float32)).any()
     for b in (bgr, xyz, maps):
         b.free()
+
+
+def test_bgr_scan_fuzz_vs_chain_and_oracle(ctx):
+    """Seeded random cases (SLGC_FUZZ_SCALE multiplies them): frame counts with and without a specialised kernel, one or two runs, plane padding that keeps or
+    breaks the 4-byte alignment, both coefficient sets, random calibrations, random bytes or the S-scene: whichever path slgc_scan_bgr_dev takes, maps and XYZ are
+    bit-identical with slgc_to_gray_dev + slgc_scan_dev and match the oracle chain."""
+    from scanner import _native
+    rng = np.random.default_rng(909)
+    lib = _native.lib()
+    took = {"fused-bgr": 0, "other": 0}
+    for case in range(30 * int(os.environ.get("SLGC_FUZZ_SCALE", "1"))):
+        N = int(rng.choice([42, 44, 46, 44, 46, 26, 30]))
+        W = int(rng.integers(2, 60)) * 4 if case % 5 else int(rng.integers(9, 200))
+        H = int(rng.integers(1, 40))
+        runs = int(rng.integers(1, 3))
+        pad = int(rng.choice([0, 0, 4, 16, 6]))
+        bits = int(rng.choice([15, 15, 14]))
+        psize = (int(rng.integers(8, 2100)), int(rng.integers(8, 1300)))
+        K = np.array([[float(rng.uniform(0.9, 2.2)) * max(W, H), 0, W / 2 + float(rng.uniform(-3, 3))], [0, float(rng.uniform(0.9, 2.2)) * max(W, H), H / 2 + float(rng.uniform(-3, 3))], [0, 0, 1]])
+        _, cd, pk, pd, R, T = bench.calibration(1920, 1080, *psize)
+        calib = (K, cd * float(rng.uniform(0, 1.3)), pk, pd * float(rng.uniform(0, 1.2)), R, T * float(rng.uniform(0.7, 1.4)))
+        ctx.set_calibration(*calib)
+        px = W * H
+        if case % 3 == 0:
+            gray_h = rng.integers(0, 256, (runs, N, H, W), dtype=np.uint8)
+        else:
+            gray_h = np.stack([onp.synth_scene_int(N, H, W, seed=int(rng.integers(1 << 30)), noise=int(rng.integers(0, 9)))[0] for _ in range(runs)])
+        bgr_h = onp.gray_to_bgr_capture(gray_h.reshape(runs * N, H, W)).reshape(runs, N, px * 3)
+        plane = 3 * px + pad
+        buf = np.zeros((runs, N, plane), np.uint8)
+        buf[:, :, :3 * px] = bgr_h
+        d_bgr = ctx.alloc(max(16, buf.nbytes)).upload(buf)
+        maps, xyz = ctx.alloc(px * 4 + 64).zero(), ctx.alloc(px * 12 + 16).zero()
+        voff = (px * 2 + 31) // 32 * 32
+        ctx.scan_bgr_dev(d_bgr.ptr, runs, N * plane, plane, N, H, W, 0, psize, xyz.ptr, None, maps.at(0), maps.at(voff), coeff_bits=bits)
+        ctx.synchronize()
+        path = ctx.last_scan_path()["path"]
+        took["fused-bgr" if path == "fused-bgr" else "other"] += 1
+        assert (path == "fused-bgr") == (N in (42, 44, 46) and px % 4 == 0 and pad % 4 == 0 and px >= 4), (case, path, N, W, H, pad)
+        got = (maps.download((H, W), np.int16), maps.download((H, W), np.int16, voff), xyz.download((H, W, 3), np.float32))
+        gref = onp.bgr_to_gray(buf[:, :, :3 * px].reshape(runs, N, H, W, 3), coeff_bits=bits)
+        g2 = ctx.alloc(max(16, gref.nbytes)).upload(gref)
+        m2, x2 = ctx.alloc(px * 4 + 64).zero(), ctx.alloc(px * 12 + 16).zero()
+        ctx.scan_dev(g2.ptr, runs, N * px, px, N, H, W, 0, psize, x2.ptr, None, m2.at(0), m2.at(voff))
+        ctx.synchronize()
+        tag = f"case {case}: {W}x{H}x{N} runs={runs} pad={pad} bits={bits} path={path}"
+        assert np.array_equal(got[0], m2.download((H, W), np.int16)) and np.array_equal(got[1], m2.download((H, W), np.int16, voff)), tag
+        assert np.array_equal(got[2].view(np.uint32), x2.download((H, W, 3), np.float32).view(np.uint32)), tag
+        ref_h, ref_v, ref_xyz = oc.scan_dense(gref if runs > 1 else gref[0], psize, *calib)
+        compare_scan(*got, ref_h, ref_v, ref_xyz, tag)
+        for b in (d_bgr, maps, xyz, g2, m2, x2):
+            b.free()
+    assert took["fused-bgr"] > 5 and took["other"] > 5, took
