@@ -1258,7 +1258,7 @@ bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &
 {
     uintptr_t align_or = (uintptr_t)plane_stride | ((uintptr_t)d_h >> 1) | ((uintptr_t)d_v >> 1);
     for (int r = 0; r < g.n_runs; ++r) align_or |= (uintptr_t)runs.p[r];
-    return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && npix % 4 == 0 && (uint64_t)g.N * plane_stride + 3 * (uint64_t)npix < 0xfffffff0ull &&
+    return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && npix % 4 == 0 && (uint64_t)g.N * plane_stride + 3 * (uint64_t)npix + 4096u < 0xfffffff0ull &&      // (+ the lanes of the last, partial workgroup)
            npix < 0x7fffffffull && ctx->tune_fuse_tail && spec_frames(ctx, g) != 0;
 }
 
