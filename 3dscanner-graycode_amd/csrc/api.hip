@@ -1248,6 +1248,44 @@ extern "C" int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs
     return slgc_scan_dev(ctx, (const uint8_t *)gray, n_runs, (size_t)N * gplane, gplane, N, rows, W, row0, proj_w, proj_h, eps, m, mode, d_h, d_v, d_xyz, d_count);
 }
 
+// slgc_decode_dev straight from BGR frames (the maps alone: what slgc_cloud_lists_dev / slgc_triangulate_maps_dev take).  Same shapes, same fall-back as slgc_scan_bgr_dev.
+extern "C" int slgc_decode_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int coeff_bits,
+                                   double eps, double m, int16_t *d_h, int16_t *d_v)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_bgr || !d_h || !d_v) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
+    if (rows < 0 || W < 0 || plane_stride < 3 * (size_t)rows * W) return slgc_fail(ctx, SLGC_EINVAL, "plane_stride smaller than a BGR band");
+    DecodeGeom g;
+    RunPtrs runs{};
+    int e;
+    if (slgc_make_geom(N, n_runs, &g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d", N, n_runs);
+    if (!decode_fast_eligible(eps, &e)) return slgc_fail(ctx, SLGC_EINVAL, "device-resident decode needs an integer eps in [0,255] (got %g)", eps);
+    for (int r = 0; r < n_runs; ++r) runs.p[r] = d_bgr + (size_t)r * run_stride;
+    const size_t npix = (size_t)rows * W;
+    ctx->last_scan_path = SLGC_PATH_NONE;
+    ctx->decode_pending = 1;
+    if (scan_bgr_eligible(ctx, g, runs, plane_stride, npix, d_h, d_v, (const float *)nullptr)) {
+        if ((rc = prof_mark(ctx, 0))) return rc;
+        if ((rc = launch_decode_bgr(ctx, g, runs, plane_stride, npix, e, d_h, d_v, coeff_bits))) return rc;
+        return prof_mark(ctx, 1);
+    }
+    void *gray;
+    const size_t gplane = (npix + 15) & ~(size_t)15;
+    if ((rc = slgc_ws(ctx, 11, (size_t)n_runs * N * gplane + 64, &gray))) return rc;
+    for (int r = 0; r < n_runs; ++r) {
+        if (plane_stride == 3 * npix && gplane == npix) {
+            if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)runs.p[r], (uint8_t *)gray + (size_t)r * N * gplane, (size_t)N * npix, coeff_bits))) return rc;
+            continue;
+        }
+        for (int f = 0; f < N; ++f)
+            if ((rc = launch_bgr_to_gray(ctx, (const uint8_t *)runs.p[r] + (size_t)f * plane_stride, (uint8_t *)gray + ((size_t)r * N + f) * gplane, npix, coeff_bits)))
+                return rc;
+    }
+    return slgc_decode_dev(ctx, (const uint8_t *)gray, n_runs, (size_t)N * gplane, gplane, N, rows, W, eps, m, d_h, d_v, 0);
+}
+
 // Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry, their stacks scan_stride bytes apart, in ONE
 // launch of the fused kernel when every scan is a whole number of its 512-pixel workgroups -- a 1920x1080 scan alone is one round of
 // resident waves (all of them in the same phase of the kernel at the same time); sixteen of them overlap like a large image does.

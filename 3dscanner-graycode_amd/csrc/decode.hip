@@ -1252,6 +1252,40 @@ bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_
            npix < 0x7fffffffull;
 }
 
+// The decode kernel alone on BGR planes (slgc_decode_bgr_dev): the caller has checked scan_bgr_eligible (d_xyz = an aligned dummy).
+int launch_decode_bgr(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h, int16_t *d_v, int bgr_bits)
+{
+    PkArgs b{};
+    for (int r = 0; r < g.n_runs; ++r) b.run[r] = (const uint8_t *)runs.p[r];
+    b.plane_stride = (uint32_t)plane_stride;
+    b.npix = (uint32_t)npix4;
+    b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + 3 * npix4);
+    b.h = d_h; b.v = d_v; b.g = g; b.e = e;
+    const uint32_t ry = bgr_bits == 14 ? 4899 : 9798, gy = bgr_bits == 14 ? 9617 : 19235, by = bgr_bits == 14 ? 1868 : 3735;
+    b.lum.a_hi = (by >> 8) | ((gy >> 8) << 8) | ((ry >> 8) << 16);
+    b.lum.a_lo = (by & 255u) | ((gy & 255u) << 8) | ((ry & 255u) << 16);
+    b.lum.z_hi = b.lum.a_hi << 8;
+    b.lum.z_lo = b.lum.a_lo << 8;
+    b.lum.rnd = 1u << (bgr_bits - 1);
+    b.lum.shift = (uint32_t)bgr_bits;
+    const uint32_t groups = b.npix / 4;
+    if (groups == 0) return SLGC_OK;
+    const unsigned blocks = (groups + 127) / 128;
+    const int ns = spec_frames(ctx, g);
+    ctx->last_ns = ns;
+    ctx->last_ragged = 0;
+#define SLGC_BGR(NSV)                                                                                              \
+    if (ns == NSV) {                                                                                               \
+        if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 0, NSV, 1>), dim3(blocks), dim3(128), b);    \
+        else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 0, NSV, 1>), dim3(blocks), dim3(128), b);                \
+    }
+    SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42)
+#undef SLGC_BGR
+    if (ns == 0) return slgc_fail(ctx, SLGC_EINVAL, "internal: BGR decode launched without a specialised frame count");
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
 // The BGR form of the fused scan (slgc_scan_bgr_dev): planes of 3 bytes per pixel, 4-byte aligned, 32-bit offsets, one of the specialised frame counts.
 bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                        const float *d_xyz)

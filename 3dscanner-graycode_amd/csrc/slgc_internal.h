@@ -154,6 +154,7 @@ int launch_selftest_classify(slgc_ctx *ctx, unsigned long long *d_bad, int skew)
 int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h,
                       int16_t *d_v, const void *cam_lut, const void *proj_lut, float *d_xyz, int proj_w, int proj_h, int n_batch = 1, size_t batch_stride = 0,
                       int bgr_bits = 0);
+int launch_decode_bgr(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix4, int e, int16_t *d_h, int16_t *d_v, int bgr_bits);
 bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                        const float *d_xyz);
 inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj_tile ? (proj_w + 15) / 16 : (proj_w + 7) / 8; }

@@ -74,6 +74,7 @@ SIGNATURES = {
     "slgc_decode_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _d, _d, _vp, _vp, _i]),
     "slgc_scan_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "slgc_scan_bgr_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp]),
+    "slgc_decode_bgr_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _d, _d, _vp, _vp]),
     "slgc_selftest_thresholds": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64)]),
     "slgc_selftest_classify": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "slgc_triangulate_maps_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -605,6 +606,11 @@ class Context:
         """scan_dev straight from BGR frames [n_runs][N][rows][W][3] (plane_stride / run_stride in bytes): cv2.cvtColor's luma inside the frame loads."""
         self._ck(lib().slgc_scan_bgr_dev(self._h, d_bgr, int(n_runs), int(run_stride), int(plane_stride), int(N), int(rows), int(W), int(row0),
                                          int(proj_size[0]), int(proj_size[1]), int(coeff_bits), float(eps), float(m), int(mode), d_h, d_v, d_xyz, d_count))
+
+    def decode_bgr_dev(self, d_bgr: int, n_runs, run_stride, plane_stride, N, rows, W, d_h: int, d_v: int, coeff_bits=15, eps=1, m=10):
+        """decode_dev straight from BGR frames [n_runs][N][rows][W][3] (strides in bytes) -> int16 maps."""
+        self._ck(lib().slgc_decode_bgr_dev(self._h, d_bgr, int(n_runs), int(run_stride), int(plane_stride), int(N), int(rows), int(W), int(coeff_bits),
+                                           float(eps), float(m), d_h, d_v))
 
     def selftest_thresholds(self, eps: int = 1, black_lo: int = 0, black_hi: int = 256) -> int:
         """Exhaustive check of the decode kernels' integer-threshold folding over the uint8 domain; returns the mismatch count."""

@@ -245,6 +245,10 @@ int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_
 int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int row0,
                       int proj_w, int proj_h, int coeff_bits, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz,
                       unsigned long long *d_count);
+/* slgc_decode_dev straight from BGR frames (src/3-capture_decode.py:66-70 + :75-100): the int16 maps alone, for callers that go on with slgc_cloud_lists_dev /
+ * slgc_triangulate_maps_dev.  Arguments, shapes and fall-back as slgc_scan_bgr_dev; maps bit-identical with slgc_to_gray_dev + slgc_decode_dev. */
+int slgc_decode_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int coeff_bits,
+                        double eps, double m, int16_t *d_h, int16_t *d_v);
 /* Throughput mode (BASELINE configs[4]): n_scans independent single-run scans of one geometry in one launch -- stacks scan_stride bytes
  * apart, d_h / d_v [n_scans][rows * W] int16 and d_xyz [n_scans][rows * W][3] float32 back to back.  Same results as n_scans calls of
  * slgc_scan_dev (which is what shapes that are not a whole number of 512-pixel workgroups, and the other modes, fall back to).
