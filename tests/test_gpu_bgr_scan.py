@@ -117,7 +117,8 @@ def test_bgr_scan_equals_to_gray_then_scan_and_the_oracle(ctx, W, H, N, runs, pa
     ctx.decode_bgr_dev(bgr.ptr, runs, N * plane, plane, N, H, W, m3.at(0), m3.at(px * 2), coeff_bits=bits)
     ctx.synchronize()
     assert np.array_equal(m3.download((H, W), np.int16), ref_h) and np.array_equal(m3.download((H, W), np.int16, px * 2), ref_v)
-    assert ctx.last_scan_path()["ns_frames"] == (N if fused else (N if N in (42, 44, 46) and (W * H) % 4 == 0 else ctx.last_scan_path()["ns_frames"]))
+    if fused:
+        assert ctx.last_scan_path()["ns_frames"] == N                      # the specialised decode kernel, reading BGR
     for b in (bgr, gray, maps, xyz, g2, m2, x2, m3):
         b.free()
 
