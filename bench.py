@@ -4,6 +4,8 @@
 One "step" = one scan: the 4096x3000 camera, 44-frame uint8 stack (BASELINE.json configs[2]; resident in HBM
 before the timed region, generated on the device) goes through ONE fused kernel (decode with the triangulation tail) and
 leaves int16 projector maps + a dense float32 XYZ map in HBM.  No torch anywhere: HIP through the ctypes C-ABI.
+The capture of the timed region is the physically consistent scene on the covering rig (tools/benchlib/common.py: 96.5 % of the pixels decode);
+this file is the entry point only -- the run itself lives in tools/benchlib/ (run.py, legs.py, sharded_legs.py, cpu.py, pmc.py).
 
   python bench.py [--gpus 1] --steps K --warmup W            single GPU
   python bench.py --gpus N ...                               N > 1: this process starts N fresh rank processes itself (one per
@@ -16,10 +18,15 @@ leaves int16 projector maps + a dense float32 XYZ map in HBM.  No torch anywhere
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline          the dominant kernel of the timed region: algorithmic bytes (N+12 B/pixel fused, N+4 decode) /
-                    launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s
-  cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on BASELINE configs[0] at full size,
-                    1 thread, plus the plain-C oracle on 1 and on all host cores (N = 1 only)
-  split_pipeline / xyz_only / decode_kernel_alone / throughput_mode / reference_product    N = 1 extras, same run
+                    launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s;
+                    traffic = HBM bytes per launch from the run's OWN counters (two rocprofv3 --pmc children started before this
+                    process touches the GPU: --pmc auto), else the committed constant of profiles/traffic.json (and it says which)
+  cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on BASELINE configs[0] and [1] at full
+                    size, 1 thread, plus the plain-C oracle on 1 thread and over a sweep of host threads (N = 1 only)
+  scenes            the same kernels on SURVEY.md 8(d)'s S-scene and S-uniform and on a dim / noisy physical capture: fractions,
+                    valid and flat-triangle counts (other_scene = the S-scene entry under its old key)
+  two_runs / ingest / small_images / split_pipeline / xyz_only / decode_kernel_alone / throughput_mode / reference_product /
+  sustained / physical_scene_accuracy    N = 1 extras, same run
 """
 import argparse
 import json
