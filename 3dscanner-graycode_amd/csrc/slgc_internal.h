@@ -238,7 +238,10 @@ inline int xcd_env(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 struct CamNodes;
+constexpr size_t kCamNodesMinTable = (size_t)12 << 20;      // bytes of per-pixel camera rays above which the scan kernels read the every-4th-column node table
 // The node table of the band ensure_luts() last built (tri_math.h), or an empty one (kernels then read the per-pixel table).
+// kCamNodesMinTable: round 4 re-measured the choice at 1920x1080 (a 16.6 MB per-pixel table) after the fast form: node table 24.0 vs 24.5 us on the physical
+// capture, 25.1 vs 26.1 on the S-scene, 27.6 vs 28.5 on S-uniform (two boxes); at 1280x720 (7.4 MB) it still loses 2 %: the limit went from 64 MB to 12 MB.
 // tune_cam_nodes 1 (default) = when it pays: a per-pixel table of more than 64 MB streams from HBM on every scan, a smaller one stays in
 // the 256 MB Infinity Cache between scans and the node table only adds arithmetic (measured: 4096x3000 -1.3 % fused / -4.5 % two-kernel
 // step, 1920x1080 and 1280x720 +2 %); 2 = whenever it is accurate enough (tests); 0 = never.  The size that decides is the WHOLE image's
@@ -246,7 +249,7 @@ struct CamNodes;
 #define SLGC_CAM_NODES_FOR(ctx, W, allow)                                                                                                   \
     (((allow) && (ctx)->lut_nodes && (ctx)->lut_cam_W == (W) &&                                                                            \
       ((ctx)->tune_cam_nodes == 2 ||                                                                                                       \
-       ((ctx)->tune_cam_nodes == 1 && (size_t)((ctx)->lut_image_rows > 0 ? (ctx)->lut_image_rows : (ctx)->lut_cam_rows) * (size_t)(W) * 8u > (64u << 20)))) \
+       ((ctx)->tune_cam_nodes == 1 && (size_t)((ctx)->lut_image_rows > 0 ? (ctx)->lut_image_rows : (ctx)->lut_cam_rows) * (size_t)(W) * 8u > kCamNodesMinTable))) \
          ? CamNodes{(const float2 *)(ctx)->lut_nodes, (uint32_t)((W) / 4), (uint32_t)((W) / 4 + 3), 1.0f / (float)((W) / 4)}              \
          : CamNodes{nullptr, 1u, 1u, 1.0f})
 inline uint32_t xcd_chunk_for(const slgc_ctx *ctx, unsigned blocks)

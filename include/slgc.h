@@ -71,7 +71,7 @@ int slgc_synchronize(slgc_ctx *ctx);
  * the default: 1 = one band of rows per XCD takes the kernel's traffic from 823 to 773 MB and its time from 127 to 137 us at
  * 4096x3000x44; n >= 2 = n consecutive tiles per XCD inside groups of 8 n: 782 MB and +2 % at n = 512).  The one knob that is NOT bit-neutral: "cam_nodes"
  * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
- * to stay in the Infinity Cache between scans (> 64 MB; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
+ * to pay as a per-pixel stream (> 12 MB: 1920x1080 and up; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
  * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
  * "lists_order" = workgroup -> tile order of the x-major list build, 0 .. 64, default 4: 0 row-major; 1 column-major (a column's run continues in the tile
  * below, so the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000); 2 column-major inside each XCD (no better); n >= 3 (the
@@ -283,7 +283,7 @@ int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj
  * interpolated ray stays within 2 float32 ulp (of a number in [1, 2)) of the exact one and every component of at least 1e-3 within 4e-6
  * of itself (flat triangles, lanes whose rays cross zero, and the exact mode always read the per-pixel table).
  * *in_use = 1 if the kernels will read the node table for the tables built last (0: W % 4 != 0, too rough a lens, an image of at
- * most 64 MB of rays under slgc_tune "cam_nodes" 1, or "cam_nodes" 0); *max_err = the measured error, in units where 2.4e-7 is the acceptance limit (-1 if no node table was built).
+ * most 12 MB of rays under slgc_tune "cam_nodes" 1, or "cam_nodes" 0); *max_err = the measured error, in units where 2.4e-7 is the acceptance limit (-1 if no node table was built).
  * With slgc_tune "image_rows" both the size and the measured error are the WHOLE image's, whatever band the tables cover.
  * Building a node table reads its error back: that one call synchronises the context's stream (once per calibration / geometry). */
 int slgc_ray_table_info(slgc_ctx *ctx, int *in_use, double *max_err);

@@ -99,7 +99,7 @@ def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
         return (maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32))
 
     # (1) the timed region of bench.py: fused kernel, algebraic (guarded) form, no count -- with the camera rays from the per-pixel
-    # table (cam_nodes 0), interpolated from the every-4th-column table (2) and as bench.py runs it (1: node table above 64 MB of rays)
+    # table (cam_nodes 0), interpolated from the every-4th-column table (2) and as bench.py runs it (1: node table above 12 MB of rays)
     worst_fused = worst_split = 0.0
     for nodes in (0, 2, 1):
         ctx.tune("cam_nodes", nodes)
@@ -111,7 +111,7 @@ def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
         _, w = compare_scan(*run(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT), ref_h, ref_v, ref_xyz, f"{workload} split cam_nodes={nodes}")
         worst_split = max(worst_split, w)
         in_use, node_err = ctx.ray_table_info()
-        assert in_use == (nodes == 2 or (nodes == 1 and W * H * 8 > 64 << 20)) and 0.0 <= node_err <= 2.4e-7
+        assert in_use == (nodes == 2 or (nodes == 1 and W * H * 8 > 12 << 20)) and 0.0 <= node_err <= 2.4e-7
     # (3) the exact (acos / sin) dense kernel on the same maps
     _, worst_exact = compare_scan(*run(_native.TRI_EXACT), ref_h, ref_v, ref_xyz, workload + " exact")
     assert worst_exact < 1e-6
@@ -318,7 +318,7 @@ def test_executed_path_is_observable(ctx, workload):
         ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz_ptr or xyz.ptr, count, maps.at(0), maps.at(px * 2), mode=mode)
         return ctx.last_scan_path()
 
-    big = W * H * 8 > 64 << 20
+    big = W * H * 8 > 12 << 20
     clean = {"decode": False, "triangulation": False}
     assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": N, "node_table": big, "guard": True, "fallback_kernels": clean}
     assert scan(_native.TRI_ALGEBRAIC | _native.TRI_SPLIT) == {"path": "split", "ns_frames": N, "node_table": big, "guard": True, "fallback_kernels": clean}
@@ -410,7 +410,7 @@ def test_cloud_dev_lists_without_dense_xyz(ctx, workload):
     lists = ctx.alloc_cloud_lists(px, colors=True)
     ctx.cloud_dev(stack.ptr, 1, N * px, px, N, H, W, (pw, ph), white.ptr, lists, d_h=maps.at(0), d_v=maps.at(voff))
     path = ctx.last_scan_path()
-    assert path["path"] == "cloud" and path["node_table"] == (W * H * 8 > 64 << 20 and W % 4 == 0)
+    assert path["path"] == "cloud" and path["node_table"] == (W * H * 8 > 12 << 20 and W % 4 == 0)
     assert ctx.last_list_kernel() == ("whole-lines" if W * H >= 4 << 20 else "tile-runs")           # the library's own choice: whole lines where they pay
     cam, proj, pts, col = lists.download()
     h = maps.download((H, W), np.int16).astype(np.int64)

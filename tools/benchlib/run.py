@@ -405,7 +405,7 @@ def run_rank(args, rank, local_rank, world):
                        "luts_hoisted_note": "per-calibration ray tables (both cv2.undistortPoints calls on integer pixel coordinates) built once "
                                             "before the timed region, not per scan",
                        "camera_rays": (lambda use, err: {"node_table_in_use": use, "node_table_error_vs_limit_2.4e-7": err,
-                                                         "note": "per-pixel table 8 B/pixel, or (bands above 64 MB of rays) the every-4th-column "
+                                                         "note": "per-pixel table 8 B/pixel, or (images above 12 MB of rays) the every-4th-column "
                                                                  "table 2 B/pixel + a cubic through 4 nodes per 4-pixel group; flat triangles and "
                                                                  "zero-crossing rays always read the exact per-pixel table"})(*ctx.ray_table_info()),
                        "guard_flagged_pixels": flagged,
