@@ -16,17 +16,20 @@ this file is the entry point only -- the run itself lives in tools/benchlib/ (ru
       the whole cloud on every rank; after the timed region every rank hashes what it holds and the hashes are compared across
       ranks and with a single-GPU scan of the same stack (the run verifies itself: "verify" in the JSON).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+Rank 0 prints ONE compact JSON line LAST on stdout (< 4 KB, fixed key set: tools/benchlib/line.py) -- the bench contract's keys with
   roofline          the dominant kernel of the timed region: algorithmic bytes (N+12 B/pixel fused, N+4 decode) /
-                    launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s;
-                    traffic = HBM bytes per launch from the run's OWN counters (two rocprofv3 --pmc children started before this
-                    process touches the GPU: --pmc auto), else the committed constant of profiles/traffic.json (and it says which)
-  cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on BASELINE configs[0] and [1] at full
-                    size, 1 thread, plus the plain-C oracle on 1 thread and over a sweep of host threads (N = 1 only)
-  scenes            the same kernels on SURVEY.md 8(d)'s S-scene and S-uniform and on a dim / noisy physical capture: fractions,
-                    valid and flat-triangle counts (other_scene = the S-scene entry under its old key)
-  two_runs / ingest / small_images / split_pipeline / xyz_only / decode_kernel_alone / throughput_mode / reference_product /
-  sustained / physical_scene_accuracy    N = 1 extras, same run
+                    launch duration from HIP events bound to the kernel's own dispatch inside the timed region, vs 8 TB/s; frac from the
+                    MEDIAN launch, frac_mean and the count of launches above 2 x median beside it; traffic = HBM bytes per launch from
+                    the run's OWN counters (two rocprofv3 --pmc children started before this process touches the GPU: --pmc auto),
+                    else the committed constant of profiles/traffic.json (traffic_source says which)
+  cpu_baseline      the reference-cost NumPy/Python port (oracle/oracle_np.py, kind "port") on a bounded sample of BASELINE configs[0],
+                    1 thread, plus the plain-C oracle on 1 thread and on the best thread count (N = 1 only; timed before this process
+                    touches the GPU, beside the counter children)
+  s_scene_frac / decode_kernel_frac / throughput_mode_value    the fused kernel on SURVEY.md 8(d)'s S-scene, the decode kernel alone on it
+                    (the north star's >= 60 % target), configs[4] through the batched launch
+and writes the FULL report -- every leg, every roofline object, notes, where the run's seconds went -- to gpurun_out/bench_extras.json
+(--extras-file).  --extras full adds the other scenes, two runs, split pipeline, XYZ only, ingest, small images, reference product,
+sustained and the full-size CPU baselines to that file; the printed line keeps its shape.
 """
 import argparse
 import json
@@ -99,7 +102,12 @@ def main():
                          "else 4; a pair costs ~1.5 %% of a step)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (contexts) per GPU in the throughput-mode measurement")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the configs[4] (16 independent scans) extra measurement")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline timed region (no split / alone / throughput / reference-product / CPU legs)")
+    ap.add_argument("--extras", default="lite", choices=["none", "lite", "full"],
+                    help="lite (default): the timed region + what the printed line needs -- the decode kernel alone, the S-scene leg, the movement-only "
+                         "yardstick, throughput mode, a bounded CPU baseline; full: every leg (all scenes, two runs, split pipeline, XYZ only, ingest, small "
+                         "images, reference product, sustained, full-size CPU baselines) into the side file; none: the timed region only")
+    ap.add_argument("--no-extras", action="store_true", help="the same as --extras none")
+    ap.add_argument("--extras-file", default=None, help="where the full report goes (default gpurun_out/bench_extras.json under the repo root)")
     ap.add_argument("--exchange", default="maps", choices=["maps", "records", "xyz"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default); all-gather maps + "
                          "float32 XYZ bands produced by the fused kernel on each band (xyz); or all-gatherv compacted 16-byte XYZ+key records")
@@ -121,8 +129,10 @@ def main():
                          "8(d)'s calibration (9-28 %% lit); s-scene / s-uniform = SURVEY.md 8(d)'s synthetic inputs on SURVEY.md 8(d)'s calibration")
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic from this run's own counters: before touching the GPU, start two rocprofv3 --pmc children (FETCH_SIZE, WRITE_SIZE) of "
-                         "a 5-step headline run and fold their bytes per launch into the line (auto: single GPU, default extras, rocprofv3 on PATH; "
-                         "otherwise / on failure the committed constant of profiles/traffic.json is used, and the line says which)")
+                         "a 3-step headline run -- they run while this process times the CPU baseline -- and fold their bytes per launch into the line "
+                         "(auto: single GPU, extras lite / full, rocprofv3 on PATH; otherwise / on failure the committed constant of profiles/traffic.json "
+                         "is used, and the line says which)")
+    ap.add_argument("--pmc-timeout", type=float, default=40.0, help="seconds one counter child may take")
     ap.add_argument("--no-small-images", action="store_true", help="skip the BASELINE configs[1] / configs[0] fused-kernel legs of the default run")
     ap.add_argument("--image-rows", type=int, default=0,
                     help="single-GPU band workloads: height of the whole image the band belongs to (slgc_tune image_rows; 0 = the band is the image)")
@@ -139,14 +149,39 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
-    args.pmc_live, args.pmc_note = None, "not requested"
-    if args.pmc != "off" and world == 1 and args.gpus == 1 and not args.force_sharded and (args.pmc == "on" or not args.no_extras):
+    if args.no_extras:
+        args.extras = "none"
+    args.pmc_live, args.pmc_note, args.cpu_baseline_result, args.pre_gpu_seconds = None, "not requested", None, {}
+    single = world == 1 and args.gpus == 1 and not args.force_sharded
+    # Before this process touches the GPU: the counter children (GPU, one after the other, in a thread) and the CPU baseline (host cores, here)
+    # side by side -- neither is inside any timed region, and the two do not share a resource.
+    pmc_thread = None
+    if args.pmc != "off" and single and (args.pmc == "on" or args.extras != "none"):
+        import threading
         from benchlib import pmc
         cw, ch, _, _, _ = WORKLOADS[args.workload]
-        live, note = pmc.collect(os.path.abspath(__file__), args.workload, args.scene, args.pipeline, grid_size=-(-(cw * ch // 4) // 128) * 128)
-        args.pmc_note = note or "collected"
-        if live:
-            args.pmc_live = {f"{args.pipeline}/{args.scene}": live}
+
+        def counters():
+            t0 = time.perf_counter()
+            live, note = pmc.collect(os.path.abspath(__file__), args.workload, args.scene, args.pipeline, grid_size=-(-(cw * ch // 4) // 128) * 128,
+                                     timeout_s=args.pmc_timeout)
+            args.pmc_note = note or "collected"
+            if live:
+                args.pmc_live = {f"{args.pipeline}/{args.scene}": live}
+            args.pre_gpu_seconds["counter children"] = round(time.perf_counter() - t0, 3)
+
+        pmc_thread = threading.Thread(target=counters, daemon=True)
+        pmc_thread.start()
+    if single and args.extras != "none" and not args.no_cpu_baseline and os.environ.get("SLGC_BENCH_PMC_CHILD") != "1":
+        from benchlib.cpu import cpu_baseline
+        t0 = time.perf_counter()
+        try:
+            args.cpu_baseline_result = cpu_baseline(level=args.extras)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: CPU baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
+        args.pre_gpu_seconds["cpu baseline"] = round(time.perf_counter() - t0, 3)
+    if pmc_thread is not None:
+        pmc_thread.join()
     try:
         run_rank(args, rank, local_rank, world)
     except Exception as e:  # noqa: BLE001

@@ -82,11 +82,60 @@ def test_scene_registry_and_command_line():
         assert cfg["rig"] in ("survey", "covering") and cfg["kind"] in ("physical", "s-scene", "uniform") and cfg["label"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0
-    for flag in ("--scene", "--pmc", "--no-small-images", "--gpus", "--steps", "--warmup"):
+    for flag in ("--scene", "--pmc", "--no-small-images", "--gpus", "--steps", "--warmup", "--extras", "--extras-file"):
         assert flag in out.stdout
     # the driver's defaults: one GPU, the configs[2] workload, the covering-rig capture, counters collected by the run
     import argparse  # noqa: F401
     ns = subprocess.run([sys.executable, "-c", "import sys; sys.argv=['bench.py']; import bench, argparse; "
-                         "import re; src=open(bench.__file__).read(); print('default=\"physical\"' in src, 'default=\"auto\"' in src, 'default=\"c3_4096x3000x44\"' in src)"],
+                         "import re; src=open(bench.__file__).read(); print('default=\"physical\"' in src, 'default=\"auto\"' in src, 'default=\"c3_4096x3000x44\"' in src, 'default=\"lite\"' in src)"],
                         capture_output=True, text=True, cwd=ROOT, timeout=60)
-    assert ns.stdout.split() == ["True", "True", "True"], ns.stdout + ns.stderr
+    assert ns.stdout.split() == ["True", "True", "True", "True"], ns.stdout + ns.stderr
+
+
+def test_printed_line_is_compact_and_carries_the_contract_keys():
+    """The driver parses the LAST stdout line: it must stay small whatever the run measured (round 4's 22 KB line was not parsed).  Built here from a
+    committed full report of an earlier round (every leg present, long notes) and from a multi-rank report."""
+    import json
+
+    from benchlib import line as L
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_steps20.json")))
+    assert len(json.dumps(full)) > 20000
+    s = L.dump_line(full, "gpurun_out/bench_extras.json")
+    assert len(s) < L.LINE_LIMIT and "\n" not in s
+    j = json.loads(s)
+    assert set(j) == set(L.TOP_KEYS)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert j[k] == full[k], k
+    assert set(j["config"]) == set(L.CONFIG_KEYS) and "configs[2]" in j["config"]["workload"] and j["config"]["executed_path"] == "fused"
+    assert set(j["roofline"]) == set(L.ROOFLINE_KEYS)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch"):
+        assert j["roofline"][k] == full["roofline"][k], k
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["peak"] == 8000.0 and j["roofline"]["traffic"] > 0
+    assert set(j["cpu_baseline"]) == set(L.CPU_KEYS) and len(j["cpu_baseline"]["sample"]) <= 120 and j["cpu_baseline"]["kind"] == "port"
+    assert j["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and j["cpu_baseline"]["cores"] == 1
+    assert j["s_scene_frac"] == full["scenes"]["s-scene"]["frac"] and j["decode_kernel_frac"] == full["decode_kernel_alone"]["roofline"]["frac"]
+    assert j["throughput_mode_value"] == full["throughput_mode"]["batched"]["value"]
+    assert j["sharded"] is None and j["verify_ok"] is None and j["extras_file"] == "gpurun_out/bench_extras.json"
+    # a multi-rank report: the sharded summary and the verification verdict ride along, long strings are cut
+    multi = dict(full, n_gpus=8, sharded={"rccl_nranks": 8, "exchange": "maps", "wire": "hv24", "overlap": True, "with_exchange_value": 1.0, "compute_only_value": 2.0,
+                                          "exchange_bytes_per_rank": {"sent": 1, "received": 7}, "compute_only_note": "x" * 5000},
+                 verify={"ok": True, "note": "y" * 5000}, error="z" * 5000)
+    multi["config"] = dict(full["config"], workload="w" * 3000, pipeline="p" * 3000)
+    s = L.dump_line(multi, None)
+    j = json.loads(s)
+    assert len(s) < L.LINE_LIMIT and j["sharded"]["rccl_nranks"] == 8 and j["verify_ok"] is True and set(j["sharded"]) == set(L.SHARDED_KEYS)
+    assert len(j["config"]["workload"]) <= 120 and len(j["error"]) <= 200
+    # a report without any extras (--extras none): the keys are there, empty
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                                 "config", "roofline")}
+    j = json.loads(L.dump_line(bare, None))
+    assert set(j) == set(L.TOP_KEYS) and j["cpu_baseline"] is None and j["s_scene_frac"] is None and j["roofline"]["frac"] == full["roofline"]["frac"]
+
+
+def test_launch_statistics_are_robust_to_one_slow_launch():
+    """frac comes from the median launch; the mean and the count of launches above 2 x median are beside it (one 10 ms launch among
+    twenty of 0.1 ms turned a leg's fraction from 0.72 into 0.12)."""
+    from benchlib.common import launch_stats
+    st = launch_stats([0.1] * 19 + [10.0])
+    assert st["median_launch_ms"] == 0.1 and st["max_launch_ms"] == 10.0 and st["outliers"] == 1
+    assert launch_stats([0.1, 0.11, 0.12])["outliers"] == 0 and launch_stats([]) == {}

@@ -43,6 +43,29 @@ def keep_stall_evidence(tag, attempt, stdout, stderr):
     warnings.warn(f"RCCL-on-one-GPU run {tag} attempt {attempt} timed out and was repeated; evidence in {os.path.relpath(where, ROOT)}")
 
 
+def load_report(lines, side_file):
+    """bench.py prints ONE compact line (the driver's contract: < 4 KB, fixed keys) and writes the full report to the side file: the tests read
+    the full report, after checking the line against it."""
+    if not lines:
+        return None
+    line = json.loads(lines[-1])
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    if not os.path.exists(side_file):
+        return line                                         # error lines (no report was assembled)
+    try:
+        with open(side_file) as f:
+            full = json.load(f)
+    finally:
+        os.unlink(side_file)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):
+        assert line[k] == full[k], (k, line[k], full[k])
+    if full.get("verify") is not None:
+        assert line["verify_ok"] == bool(full["verify"]["ok"])
+    if full.get("sharded"):
+        assert line["sharded"]["rccl_nranks"] == full["sharded"]["rccl_nranks"]
+    return full
+
+
 def run_bench(*args, timeout=600, ranks_as_hosts=False, attempts=1, tag="run"):
     """attempts > 1 (only the several-ranks-on-ONE-GPU test mode passes it): a run that TIMES OUT is repeated ONCE MORE AT MOST per extra attempt
     -- after its evidence has been kept (keep_stall_evidence) and reported; a run that finishes with a wrong result or an error is never
@@ -52,10 +75,15 @@ def run_bench(*args, timeout=600, ranks_as_hosts=False, attempts=1, tag="run"):
     if ranks_as_hosts:
         env["SLGC_RANKS_AS_HOSTS"] = "1"
         env.setdefault("SLGC_BENCH_FAULTHANDLER_S", str(max(10, timeout - 40)))      # every rank dumps its Python stacks shortly before the watchdog fires
+    import tempfile
     for attempt in range(attempts):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout + 60, env=env)
+        side = tempfile.NamedTemporaryFile(prefix="slgc_bench_", suffix=".json", delete=False)
+        side.close()
+        os.unlink(side.name)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args, "--extras-file", side.name], capture_output=True, text=True,
+                           timeout=timeout + 60, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        j = json.loads(lines[-1]) if lines else None
+        j = load_report(lines, side.name)
         timed_out = j is None or "timed out" in str(j.get("error", ""))
         if not (timed_out and r.returncode != 0) or attempt + 1 == attempts:
             return r, j
@@ -175,7 +203,8 @@ def test_driver_launcher_two_ranks_on_one_gpu():
     pytest.importorskip("torch")
     env = dict(os.environ, SLGC_RANKS_AS_HOSTS="1", SLGC_BENCH_TIMEOUT_S="150", SLGC_BENCH_ALT_TIMEOUT_S="90", SLGC_BENCH_FAULTHANDLER_S="140")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29611",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "c2_1920x1080x44", "--no-cpu-baseline"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--workload", "c2_1920x1080x44", "--no-cpu-baseline",
+           "--extras-file", os.path.join(ROOT, "gpurun_out", "bench_extras_driver_launcher_test.json")]
     for attempt in range(2):                                                # a run that times out is repeated once, loudly (run_bench's docstring); a wrong result never
         env["MASTER_PORT"] = cmd[cmd.index("--master-port") + 1] = str(29611 + attempt)
         try:
@@ -194,7 +223,7 @@ def test_driver_launcher_two_ranks_on_one_gpu():
         break
     _skip_if_transport_unavailable(r, json.loads(lines[-1]) if lines else None)
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
-    j = json.loads(lines[0])
+    j = load_report(lines, os.path.join(ROOT, "gpurun_out", "bench_extras_driver_launcher_test.json"))
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "strong" and j["sharded"]["rccl_nranks"] == 2 and j["verify"]["ok"]
     alt = j["sharded_alternatives"]
     assert j["sharded"]["wire"] == "hv24"                                   # the default wire with more than one rank: 3 B/pixel

@@ -108,8 +108,9 @@ def launch_stats(samples_ms):
     if s.size == 0:
         return {}
     q = lambda f: float(s[min(s.size - 1, int(round(f * (s.size - 1))))])     # noqa: E731
-    return {"min_launch_ms": round(float(s[0]), 5), "median_launch_ms": round(q(0.5), 5), "p95_launch_ms": round(q(0.95), 5),
-            "max_launch_ms": round(float(s[-1]), 5)}
+    med = float(np.median(s))
+    return {"min_launch_ms": round(float(s[0]), 5), "median_launch_ms": round(med, 5), "p95_launch_ms": round(q(0.95), 5),
+            "max_launch_ms": round(float(s[-1]), 5), "outliers": int((s > 2.0 * med).sum()), "outliers_rule": "launches above 2 x median"}
 
 
 def digest64(*arrays):

@@ -9,11 +9,13 @@ from .common import ROOT, WORKLOADS, calibration
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (N = 1)
-def _port_scan(onp, name):
-    """One decode + triangulate of a BASELINE configuration through the reference-cost port; -> (seconds, seconds get_codes, seconds loops, points)"""
+def _port_scan(onp, name, rows=None):
+    """One decode + triangulate of a BASELINE configuration (rows = only its first `rows` image rows: a bounded sample, the cost is per pixel)
+    through the reference-cost port; -> (seconds, seconds get_codes, seconds loops, points)"""
     cw, ch, pw, ph, n = WORKLOADS[name]
     K, cd, pk, pd, R, T = calibration(cw, ch, pw, ph)
-    st, _, _ = onp.synth_scene_int(n, ch, cw, seed=1)
+    st, _, _ = onp.synth_scene_int(n, ch, cw, seed=1, rows=rows)
+    ch = st.shape[1]
     white = np.repeat(st[1][:, :, None], 3, axis=2)
     t0 = time.perf_counter()
     hc, vc = onp.get_codes_loops(st.astype(np.float64))                # float64 stack like the reference driver (src/3:68-70)
@@ -25,15 +27,22 @@ def _port_scan(onp, name):
     return time.perf_counter() - t0, t_codes, t_pix, pts.shape[1]
 
 
-def cpu_baseline(with_c2=True):
-    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames) and configs[1]
-    (1920x1080, 44 frames) at FULL size: get_codes with the reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the
-    per-pixel Python loops of src/3-capture_decode.py:99-100 and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference."""
+def cpu_baseline(level="full"):
+    """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames): get_codes with the
+    reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the per-pixel Python loops of src/3-capture_decode.py:99-100
+    and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference.
+    level "lite" (the default run): a bounded sample -- the first 360 rows of configs[0] (half of the image; every step of the port costs per
+    pixel), the C oracle on a 1024x512 crop, threads swept over {8, 32, all}.  level "full": configs[0] AND configs[1] at full size, the C oracle
+    on 2048x1024, the whole thread sweep."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as oc
     import oracle_np as onp
+    lite = level != "full"
+    with_c2 = not lite
     cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
-    dt, t_codes, t_pix, npts = _port_scan(onp, "c1_1280x720x42")
+    if lite:
+        ch = 360
+    dt, t_codes, t_pix, npts = _port_scan(onp, "c1_1280x720x42", rows=ch if lite else None)
     mpix = cw * ch / 1e6
     c2 = None
     if with_c2:
@@ -42,34 +51,37 @@ def cpu_baseline(with_c2=True):
               "sample": f"BASELINE configs[1] at full size: 1920x1080 camera and projector, 44 frames, S-scene, decode + triangulate, {d2:.1f} s "
                         f"({c2_codes:.1f} s get_codes, {c2_pix:.1f} s gray_to_decimal loops), {c2_pts} points; same port, 1 thread"}
     # strong baseline: the plain-C oracle on the headline workload's own size class (a 2048x1024 crop of the 44-frame scene)
-    st2, _, _ = onp.synth_scene_int(44, 1024, 2048, seed=1)
+    c_w, c_h = (1024, 512) if lite else (2048, 1024)
+    st2, _, _ = onp.synth_scene_int(44, c_h, c_w, seed=1)
     cal3 = calibration(4096, 3000, 1920, 1200)
     t1 = time.perf_counter()
     oc.scan_dense(st2, (1920, 1200), *cal3)
     dt_c = time.perf_counter() - t1
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     dt_mt, used, sweep = None, 1, {}
-    for nthr in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):     # a container's CPU quota can be far below its visible cores
+    for nthr in sorted({min(cores, c) for c in ((8, 32, cores) if lite else (8, 16, 32, 64, 128, cores))}):     # a container's CPU quota can be far below its visible cores
         oc.set_threads(nthr)
         oc.scan_dense(st2, (1920, 1200), *cal3)                        # thread pool start-up
         t2 = time.perf_counter()
         oc.scan_dense(st2, (1920, 1200), *cal3)
         d = time.perf_counter() - t2
-        sweep[str(nthr)] = round(2048 * 1024 / 1e6 / d, 2)
+        sweep[str(nthr)] = round(c_w * c_h / 1e6 / d, 2)
         if dt_mt is None or d < dt_mt:
             dt_mt, used = d, nthr
     oc.set_threads(1)
-    mpix2 = 2048 * 1024 / 1e6
-    out = {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-           "sample": f"BASELINE configs[0] at full size: {cw}x{ch} camera, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
-                     f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {npts} points; "
-                     "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
+    mpix2 = c_w * c_h / 1e6
+    size = f"first {ch} rows of configs[0] ({cw}x{ch}x{n})" if lite else f"configs[0] full size ({cw}x{ch}x{n})"
+    out = {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port", "level": level,
+           "sample": f"{size}, decode+triangulate, {dt:.1f} s, {npts} points; NumPy/Python port, reference's cost shape, 1 thread",
+           "sample_detail": f"BASELINE configs[0]: {cw}x{ch} camera rows, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
+                            f"triangulate, {dt:.1f} s ({t_codes:.1f} s get_codes, {t_pix:.1f} s gray_to_decimal loops), {npts} points; "
+                            "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
            "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
                                   "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
-           "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": "plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, 2048x1024x44 crop of the headline scene",
+           "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": f"plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, {c_w}x{c_h}x44 crop of the headline scene",
            "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
            "c_oracle_threads_sweep_mpix_s": sweep,
-           "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP); the figure is the BEST of the sweep over 8/16/32/64/128/all "
+           "c_oracle_all_cores_note": "the same C oracle, per-pixel loops on host threads (OpenMP); the figure is the BEST of the sweep over 8/(16)/32/(64/128)/all "
                                       "visible cores (every point of the sweep is listed): the box shows the host's cores but the job's CPU quota and the "
                                       "2 MB crop's memory traffic stop the scaling well below them, so more threads than the best point are slower, not faster"}
     if c2:

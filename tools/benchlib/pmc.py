@@ -53,8 +53,8 @@ def collect(bench_py, workload, scene, pipeline, grid_size, timeout_s=90.0):
         return None, "this process already runs under a profiler"
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
-    child_args = ["--gpus", "1", "--steps", "5", "--warmup", "2", "--preheat", "0", "--no-extras", "--pmc", "off", "--workload", workload,
-                  "--scene", scene, "--pipeline", pipeline]
+    child_args = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--preheat", "0", "--no-extras", "--pmc", "off", "--workload", workload,
+                  "--scene", scene, "--pipeline", pipeline, "--extras-file", os.devnull]
     got = {}
     top = tempfile.mkdtemp(prefix="slgc_pmc_", dir="/tmp")
     try:

@@ -9,6 +9,7 @@ import numpy as np
 from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, SCENES, STAGE, WORKLOADS, calibration, csrc_fingerprint, digest64, launch_stats,
                      synth_into, workload_label)
 from .cpu import cpu_baseline
+from .line import dump_line
 from .legs import ingest_leg, physical_accuracy, reference_product, small_image_legs, sustained_leg, throughput_batched, throughput_mode
 from .sharded_legs import sharded_report, verify_sharded
 
@@ -99,7 +100,36 @@ def run_rank(args, rank, local_rank, world):
             out_.append(s)
         return out_
 
-    stacks = make_stacks(args.scene)
+    t_run0 = time.perf_counter()
+    leg_s = {}
+
+    class leg:                                  # wall seconds of every leg of the run (side file: where the run's time goes)
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            STAGE[0] = self.name
+            self.t0 = time.perf_counter()
+
+        def __exit__(self, *exc):
+            leg_s[self.name] = round(leg_s.get(self.name, 0.0) + time.perf_counter() - self.t0, 3)
+            STAGE[0] = "extras"
+
+    single = G == 1 and not use_comm
+    extras = single and args.extras != "none" and args.mode == "algebraic" and args.tri == "lut"       # "lite" legs: what the printed line needs
+    extras_full = extras and args.extras == "full"                                                     # everything else (side file only)
+    # EVERY input stack of every leg is allocated and filled here, before the first timed window: a hipMalloc / hipFree of a 0.5 GB stack
+    # between two legs left one launch of 10 ms in the next leg's samples (round 4: first touch of fresh page tables inside the event pairs)
+    with leg("synthetic captures"):
+        stacks = make_stacks(args.scene)
+        scene_stacks = {args.scene: stacks}
+        if extras:
+            for name in (("s-scene", "s-uniform", "noisy-physical", "physical") if extras_full else ("s-scene",)):
+                if name in scene_stacks or (SCENES[name]["kind"] == "uniform" and (cam_w % 4 or plane % 4)):
+                    continue
+                scene_stacks[name] = make_stacks(name)
+        pairs = make_stacks(args.scene, n_runs=2) if extras_full else None
+        use_rig(SCENES[args.scene]["rig"])
     maps = ctx.alloc(max(16, band_px * 4))
     xyz = ctx.alloc(max(16, band_px * 12))
     count = ctx.alloc(16).zero()
@@ -179,8 +209,6 @@ def run_rank(args, rank, local_rank, world):
     STAGE[0] = "extras"
     executed = ctx.last_scan_path()                          # what the library actually launched in the timed region (not what this script asked for)
     last_stack = (args.steps - 1) % len(stacks)              # what the output buffers hold now
-    single = G == 1 and not use_comm
-    extras = single and not args.no_extras and args.mode == "algebraic" and args.tri == "lut"
 
     def scene_stats(src):
         """valid / guard-flagged pixels of one scan of src[0] (untimed)"""
@@ -192,7 +220,7 @@ def run_rank(args, rank, local_rank, world):
 
     def time_decode(src):
         """the decode kernel by itself, back to back over the rotated stacks (no other kernel's write-back in its way) -> (ms, launches, samples), path"""
-        for i in range(3):
+        for i in range(max(3, len(src))):
             ctx.decode_dev(src[i % len(src)].ptr, 1, N * plane, plane, N, rows, cam_w, maps.at(0), maps.at(band_px * 2), variant=args.variant)
         ctx.synchronize()
         ctx.prof_begin(args.steps + 8)
@@ -203,66 +231,71 @@ def run_rank(args, rank, local_rank, world):
     # ---- the same kernels on every synthetic capture of common.SCENES (SURVEY.md 8(d) names S-uniform as the worst case and the S-scene as the
     # realistic one; the physical ones are what a scanner sees): fused scan + decode kernel timed, valid / guard-flagged pixels counted
     scene_legs = {}
-    s_scene_stacks = stacks if args.scene == "s-scene" else None
+    s_scene_stacks = scene_stacks.get("s-scene")
+    W_leg = max(2, args.warmup // 2, len(stacks))            # the warm-up of a leg touches every one of its rotated stacks
     if extras:
-        for name in ("s-scene", "s-uniform", "noisy-physical", "physical"):
-            if name == args.scene or (SCENES[name]["kind"] == "uniform" and (cam_w % 4 or plane % 4)):
+        for name, st in scene_stacks.items():
+            if name == args.scene:
                 continue
-            STAGE[0] = f"scene leg {name}"
-            st = make_stacks(name)
-            o_el, o_kms, o_kn, _, o_samples = timed(args.steps, max(2, args.warmup // 2), preheat=False, scene=name, mode=mode_fused, src=st)
-            o_exec = ctx.last_scan_path()
-            o_valid, o_flag = scene_stats(st)
-            o_dec, o_dec_exec = time_decode(st)
-            acc = None
-            if SCENES[name]["kind"] == "physical":
-                acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), name, maps, xyz, band_px, mode_fused)
-            scene_legs[name] = (o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc, o_dec, o_dec_exec)
-            if name == "s-scene":
-                s_scene_stacks = st
-            else:
-                for b in st:
-                    b.free()
-        STAGE[0] = "extras"
-    head_acc = None
-    if extras and SCENES[args.scene]["kind"] == "physical":
-        use_rig(SCENES[args.scene]["rig"])
-        head_acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), args.scene, maps, xyz, band_px, mode_fused)
+            with leg(f"scene leg {name}"):
+                o_el, o_kms, o_kn, _, o_samples = timed(args.steps, W_leg, preheat=False, scene=name, mode=mode_fused, src=st)
+                o_exec = ctx.last_scan_path()
+                o_valid, o_flag = scene_stats(st)
+                o_dec, o_dec_exec = time_decode(st)
+                scene_legs[name] = [o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, None, o_dec, o_dec_exec]
     head_dec = None
     if extras:
-        head_dec = time_decode(stacks)
+        with leg("decode kernel alone"):
+            use_rig(SCENES[args.scene]["rig"])
+            head_dec = time_decode(stacks)
+    # (accuracy against the generator's truth allocates: after every timed window of the scene legs)
+    head_acc = None
+    if extras_full:
+        with leg("accuracy vs true surface"):
+            for name in scene_legs:
+                if SCENES[name]["kind"] == "physical":
+                    use_rig(SCENES[name]["rig"])
+                    scene_legs[name][7] = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), name, maps, xyz, band_px, mode_fused)
+            if SCENES[args.scene]["kind"] == "physical":
+                use_rig(SCENES[args.scene]["rig"])
+                head_acc = physical_accuracy(ctx, N, cam_h, cam_w, row0, rows, plane, (proj_w, proj_h), args.scene, maps, xyz, band_px, mode_fused)
 
     # ---- two captures per scan, max-merged per code bit inside the kernel (the reference always merges MAX_NB_RUNS = 2: src/3-capture_decode.py:48,95-96)
     two_runs = None
-    if extras:
-        pairs = make_stacks(args.scene, n_runs=2)
-        two_runs = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, src=pairs, n_runs=2) + (ctx.last_scan_path(),)
-        for b in pairs:
-            b.free()
+    if extras_full:
+        with leg("two runs"):
+            two_runs = timed(args.steps, W_leg, preheat=False, mode=mode_fused, src=pairs, n_runs=2) + (ctx.last_scan_path(),)
 
     sustained = None
     use_rig(SCENES[args.scene]["rig"])
-    if single and not args.no_extras and args.sustained > 0:
-        sustained = sustained_leg(ctx, step, drain, args.sustained, cam_w * rows / 1e6)
+    if single and args.extras == "full" and args.sustained > 0:
+        with leg("sustained"):
+            sustained = sustained_leg(ctx, step, drain, args.sustained, cam_w * rows / 1e6)
 
     other = None
-    if extras:
-        om = mode_fused if args.pipeline == "split" else mode_split
-        other = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=om)
-        other_executed = ctx.last_scan_path()
+    if extras_full:
+        with leg("other pipeline"):
+            om = mode_fused if args.pipeline == "split" else mode_split
+            other = timed(args.steps, W_leg, preheat=False, mode=om)
+            other_executed = ctx.last_scan_path()
 
     xyz_only = None
-    if extras:
+    if extras_full:
         # the same scan for a caller that wants the cloud only (no map buffers passed): the fused kernel then moves exactly SURVEY 8(d)'s N + 12 B/pixel
-        xyz_only = timed(args.steps, max(2, args.warmup // 2), preheat=False, mode=mode_fused, no_maps=True)
-        xyz_only_executed = ctx.last_scan_path()
+        with leg("xyz only"):
+            xyz_only = timed(args.steps, W_leg, preheat=False, mode=mode_fused, no_maps=True)
+            xyz_only_executed = ctx.last_scan_path()
 
     dec_alone = None
-    if extras:
-        dec_alone, dec_alone_exec = time_decode(s_scene_stacks)
+    if extras and s_scene_stacks is not None:
+        if args.scene == "s-scene":
+            dec_alone, dec_alone_exec = head_dec
+        else:
+            dec_alone, dec_alone_exec = scene_legs["s-scene"][8], scene_legs["s-scene"][9]     # (timed in the S-scene leg above)
 
     movement = None
     if extras and N in (42, 44, 46) and band_px % 256 == 0 and plane % 4 == 0:
+        t_mv0 = time.perf_counter()
         # the yardstick: a kernel that ONLY moves the bytes of this scan (slgc_move_only_dev) -- N planes in; maps + 12 B/px, 12 B/px alone, or the
         # maps alone out -- launched back to back over the same rotated stacks, timed with HIP events around the batch
         def move(K, **out_ptrs):
@@ -279,30 +312,32 @@ def run_rank(args, rank, local_rank, world):
         movement = {"fused_with_maps_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2), d_xyz=xyz.ptr),
                     "fused_xyz_only_ms": move(K_mv, d_xyz=xyz.ptr),
                     "decode_ms": move(K_mv, d_h=maps.at(0), d_v=maps.at(band_px * 2))}
+        leg_s["movement-only yardstick"] = round(time.perf_counter() - t_mv0, 3)
 
     ref_product = None
-    if extras and row0 == 0:
-        use_rig(SCENES["s-scene"]["rig"])
-        ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps, mode_fused)
-        ref_product["scene"] = "s-scene"
+    if extras_full and row0 == 0 and s_scene_stacks is not None:
+        with leg("reference product"):
+            use_rig(SCENES["s-scene"]["rig"])
+            ref_product = reference_product(ctx, _native, s_scene_stacks, N, plane, rows, cam_w, row0, (proj_w, proj_h), maps, xyz, band_px, args.steps,
+                                            mode_fused)
+            ref_product["scene"] = "s-scene"
 
     thr = thr_batched = None
-    if not args.no_throughput_mode and not args.no_extras and args.mode == "algebraic" and args.tri == "lut":
-        thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
-        thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
+    if not args.no_throughput_mode and args.extras != "none" and args.mode == "algebraic" and args.tri == "lut":
+        with leg("throughput mode"):
+            thr = throughput_mode(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, args.streams, collective=use_comm, scene=args.scene)
+            thr_batched = throughput_batched(ctx, _native, G, max(5, args.steps // 4), mode_fused, device, collective=use_comm, scene=args.scene)
 
     ingest = None
-    if extras and row0 == 0 and N in (42, 44, 46) and band_px % 4 == 0:
-        STAGE[0] = "ingest"
-        use_rig(SCENES[args.scene]["rig"])
-        ingest = ingest_leg(ctx, args.scene, N, rows, cam_w, (proj_w, proj_h), max(5, args.steps // 2), mode_fused, maps, xyz)
-        STAGE[0] = "extras"
+    if extras_full and row0 == 0 and N in (42, 44, 46) and band_px % 4 == 0:
+        with leg("ingest"):
+            use_rig(SCENES[args.scene]["rig"])
+            ingest = ingest_leg(ctx, args.scene, N, rows, cam_w, (proj_w, proj_h), max(5, args.steps // 2), mode_fused, maps, xyz)
 
     small = None
-    if extras and args.workload == "c3_4096x3000x44" and not args.no_small_images:
-        STAGE[0] = "small images"
-        small = small_image_legs(_native, device, args.steps, mode_fused)
-        STAGE[0] = "extras"
+    if extras_full and args.workload == "c3_4096x3000x44" and not args.no_small_images:
+        with leg("small images"):
+            small = small_image_legs(_native, device, args.steps, mode_fused)
 
     # ---- what one scan holds: valid pixels, pixels on the guarded triangulation path (untimed)
     use_rig(SCENES[args.scene]["rig"])
@@ -352,13 +387,19 @@ def run_rank(args, rank, local_rank, world):
             frac_incl_maps counts them too."""
             per_px = (n_runs * N + 4) if pipeline == "split" else (n_runs * N + 12)
             avg_ms = kms / max(1, kn)
-            ach = per_px * band_px / (avg_ms * 1e-3) / 1e9
+            st = launch_stats(samples)
+            med_ms = st.get("median_launch_ms") or avg_ms
+            # frac / achieved come from the MEDIAN launch of the timed region (one hiccup of the box -- round 4 saw a 10 ms launch among twenty of
+            # 0.1 ms -- must not decide the number); the mean is beside it (frac_mean, avg_launch_ms) with the count of launches above 2 x median
+            ach = per_px * band_px / (med_ms * 1e-3) / 1e9
+            ach_mean = per_px * band_px / (avg_ms * 1e-3) / 1e9
             r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                 "frac_mean": round(ach_mean / HBM_PEAK_GBS, 4), "achieved_mean": round(ach_mean, 1), "frac_from": "median launch",
                  "traffic": None, "kernel": kernel_name(ex or executed, pipeline),
-                 "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, **launch_stats(samples),
+                 "avg_launch_ms": round(avg_ms, 5), "launches_timed": kn, **st,
                  "algorithmic_bytes_per_px": per_px, "algorithmic_bytes_per_launch": per_px * band_px}
             if pipeline != "split":
-                r["frac_incl_maps"] = round((n_runs * N + 16) * band_px / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                r["frac_incl_maps"] = round((n_runs * N + 16) * band_px / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 r["frac_incl_maps_note"] = "N + 16 B/pixel: the 4 B/pixel int16 maps the fused kernel also writes counted as algorithmic"
             sc = scene or args.scene
             live = (getattr(args, "pmc_live", None) or {}).get(f"{pipeline}/{sc}") if n_runs == 1 else None
@@ -394,6 +435,7 @@ def run_rank(args, rank, local_rank, world):
                                     else {"fused": "fused (one kernel)", "batch-fused": "fused (one kernel, batched)", "split": "split (decode kernel + triangulation kernel)",
                                           "split-ragged": "split (decode kernel + triangulation kernel, with byte-wide / per-pixel fallback kernels)"}.get(executed["path"], executed["path"])),
                        "executed": {**executed, "source": "slgc_last_scan_path after the timed region", "requested_pipeline": args.pipeline},
+                       "extras": args.extras,
                        "scene": SCENES[args.scene]["label"], "scene_name": args.scene, "rig": SCENES[args.scene]["rig"],
                        "rig_note": "survey = SURVEY.md 8(d)'s calibration; covering = the same camera and stereo pose with a projector whose addressable "
                                    "2^L x 2^L raster covers the camera's field of view (benchlib/common.py: calibration)",
@@ -467,21 +509,24 @@ def run_rank(args, rank, local_rank, world):
         if extras:
             # one table over every synthetic capture: fused scan + decode kernel, valid / guard-flagged pixels
             table = {args.scene: {"scene": SCENES[args.scene]["label"], "rig": SCENES[args.scene]["rig"], "headline": True, "value": round(value, 1), "unit": "Mpixels/s",
-                                  "ms_per_step": round(ms_per_step, 4), "frac": out["roofline"]["frac"], "avg_launch_ms": out["roofline"]["avg_launch_ms"],
+                                  "ms_per_step": round(ms_per_step, 4), "frac": out["roofline"]["frac"], "frac_mean": out["roofline"]["frac_mean"],
+                                  "avg_launch_ms": out["roofline"]["avg_launch_ms"], "median_launch_ms": out["roofline"].get("median_launch_ms"),
+                                  "outliers": out["roofline"].get("outliers"),
                                   "valid_pixels_per_scan": valid, "guard_flagged_pixels": flagged, "executed": executed,
                                   "decode_kernel": (lambda d: {"frac": d["frac"], "avg_launch_ms": d["avg_launch_ms"]})(kernel_roofline("split", *head_dec[0], ex=head_dec[1]))}}
             for name, (o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, acc, o_dec, o_dec_exec) in scene_legs.items():
                 fr = kernel_roofline("fused" if o_exec["path"] == "fused" else "split", o_kms, o_kn, o_samples, o_exec, scene=name)
                 dr = kernel_roofline("split", *o_dec, ex=o_dec_exec, scene=name)
                 table[name] = {"scene": SCENES[name]["label"], "rig": SCENES[name]["rig"], "value": round(mpix_per_step * args.steps / o_el, 1), "unit": "Mpixels/s",
-                               "ms_per_step": round(o_el / args.steps * 1e3, 4), "frac": fr["frac"], "avg_launch_ms": fr["avg_launch_ms"],
+                               "ms_per_step": round(o_el / args.steps * 1e3, 4), "frac": fr["frac"], "frac_mean": fr["frac_mean"], "avg_launch_ms": fr["avg_launch_ms"],
+                               "median_launch_ms": fr.get("median_launch_ms"), "outliers": fr.get("outliers"),
                                "fused_time_over_s_scene": None, "valid_pixels_per_scan": o_valid, "guard_flagged_pixels": o_flag, "executed": o_exec,
                                "roofline": fr, "decode_kernel": {"frac": dr["frac"], "avg_launch_ms": dr["avg_launch_ms"], "roofline": dr}}
                 if acc is not None:
                     table[name]["accuracy_vs_true_surface"] = acc
-            ref_ms = table.get("s-scene", {}).get("avg_launch_ms")
+            ref_ms = table.get("s-scene", {}).get("median_launch_ms")
             for name, row in table.items():
-                row["fused_time_over_s_scene"] = round(row["avg_launch_ms"] / ref_ms, 3) if ref_ms else None
+                row["fused_time_over_s_scene"] = round(row["median_launch_ms"] / ref_ms, 3) if ref_ms and row.get("median_launch_ms") else None
             out["scenes"] = table
             if "s-scene" in scene_legs:                      # (kept under its old key as well)
                 row = table["s-scene"]
@@ -510,8 +555,14 @@ def run_rank(args, rank, local_rank, world):
                 out["throughput_mode"]["batched"] = {"value": round(b_scans * b_mpix * t_steps / b_el, 1), "unit": "Mpixels/s",
                                                      "scans_per_s": round(b_scans * t_steps / b_el, 1),
                                                      "note": "the same scans through slgc_scan_batch_dev: each GPU's share in one launch per step"}
-        if single and not args.no_cpu_baseline and not args.no_extras:
-            out["cpu_baseline"] = cpu_baseline()
+        if single and not args.no_cpu_baseline and args.extras != "none":
+            # (bench.py runs the CPU leg BEFORE this process touches the GPU, beside the counter children: args.cpu_baseline_result)
+            with leg("cpu baseline (in line)"):
+                out["cpu_baseline"] = getattr(args, "cpu_baseline_result", None) or cpu_baseline(level=args.extras)
+        if extras and head_dec is not None:
+            out["decode_kernel_headline"] = {"roofline": kernel_roofline("split", *head_dec[0], ex=head_dec[1]), "scene": args.scene,
+                                             "note": "decode kernel launched back to back on the headline scene's rotated stacks, same run"}
+        out["leg_seconds"] = dict(leg_s, **(getattr(args, "pre_gpu_seconds", None) or {}), rank_total=round(time.perf_counter() - t_run0, 3))
 
     import threading
     emit_lock, emitted = threading.Lock(), []
@@ -524,10 +575,20 @@ def run_rank(args, rank, local_rank, world):
             if rank == 0:
                 import ctypes
                 ctypes.CDLL(None).fflush(None)
-                line = dict(out)
+                report = dict(out)
                 if extra:
-                    line.update(extra)
-                print(json.dumps(line), flush=True)
+                    report.update(extra)
+                # the full report goes to a side file; the LAST stdout line is the compact object the driver parses (benchlib/line.py)
+                path = getattr(args, "extras_file", None) or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    with open(path, "w") as f:
+                        json.dump(report, f, indent=1)
+                    shown = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+                except OSError as e:
+                    shown = None
+                    print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+                print(dump_line(report, shown), flush=True)
 
     # Extras of the multi-rank run, AFTER everything above is measured and assembled: a watchdog prints the line as it stands and ends
     # the process if they do not come back (a hang in a collective that has never run on more than one GPU must not cost the run).
@@ -540,7 +601,7 @@ def run_rank(args, rank, local_rank, world):
     watchdog.start()
     alternatives = None
     STAGE[0] = "sharded alternatives"
-    if use_comm and args.exchange == "maps" and not args.no_extras and pipelined:
+    if use_comm and args.exchange == "maps" and args.extras != "none" and pipelined:
         # The first run on real xGMI is rare: time the other exchange forms too (same stacks, same pipelining, each verified against the maps
         # the main strategy left) -- extras after the counted region, a failure here is reported and changes nothing above.
         sharded_scanner.submit(stacks[last_stack].ptr, plane)
