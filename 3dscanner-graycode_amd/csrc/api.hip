@@ -1061,6 +1061,7 @@ extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
     ctx->last_scan_path = SLGC_PATH_NONE;          // a decode alone is not a scan; slgc_triangulate_maps_dev after it completes the two-kernel path
     ctx->last_ragged = 0;
+    ctx->last_tri_ragged = 0;                      // slgc_last_scan_ragged after a decode alone reports the decode's bit only
     ctx->decode_pending = 1;
     return decode_fast_timed(ctx, g, runs, plane_stride, rows, W, e, d_h, d_v, variant);
 }
@@ -1105,7 +1106,8 @@ extern "C" int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, cons
     if (!d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 3) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count))) return rc;
-    ctx->last_scan_path = (ctx->last_tri_ragged || (ctx->decode_pending && ctx->last_ragged)) ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
+    if (!ctx->decode_pending) ctx->last_ragged = 0;      // a triangulation on its own reports its own bit only (no decode of this context is part of it)
+    ctx->last_scan_path = (ctx->last_tri_ragged || ctx->last_ragged) ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;
     ctx->decode_pending = 0;
     return SLGC_OK;
 }
@@ -1151,6 +1153,7 @@ extern "C" int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, i
     if (!d_wire || !d_h || !d_v || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (mode < 0 || mode > 1) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
     if ((rc = launch_triangulate_maps(ctx, d_h, d_v, rows, W, row0, proj_w, proj_h, mode, d_xyz, d_count, d_wire))) return rc;
+    ctx->last_ragged = 0;
     ctx->last_scan_path = ctx->last_tri_ragged ? SLGC_PATH_SPLIT_RAGGED : SLGC_PATH_SPLIT;      // the maps came over the wire: no decode of this context is part of it
     ctx->decode_pending = 0;
     return SLGC_OK;
@@ -1265,6 +1268,8 @@ extern "C" int slgc_decode_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_ru
     for (int r = 0; r < n_runs; ++r) runs.p[r] = d_bgr + (size_t)r * run_stride;
     const size_t npix = (size_t)rows * W;
     ctx->last_scan_path = SLGC_PATH_NONE;
+    ctx->last_ragged = 0;
+    ctx->last_tri_ragged = 0;
     ctx->decode_pending = 1;
     if (scan_bgr_eligible(ctx, g, runs, plane_stride, npix, d_h, d_v, (const float *)nullptr)) {
         if ((rc = prof_mark(ctx, 0))) return rc;

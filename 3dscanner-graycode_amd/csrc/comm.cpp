@@ -264,7 +264,7 @@ extern "C" int slgc_scan_sharded_dev(slgc_ctx *ctx, const uint8_t *d_band_stack,
         // 3-byte wire format (slgc_tune "wire" = 1): pack the band into its slot of a packed full-size buffer, ONE in-place all-gather of
         // 3 B/pixel, and the triangulation kernel unpacks while it loads (it also writes the int16 maps, which stay a product)
         void *wire;
-        if ((rc = slgc_ws(ctx, 11, (size_t)H * W * 3 + 64, &wire))) return rc;
+        if ((rc = slgc_ws(ctx, 13, (size_t)H * W * 3 + 64, &wire))) return rc;
         for (int r = 0; r < ctx->nranks; ++r) {
             counts[r] = counts[r] / 2 * 3;
             displs[r] = displs[r] / 2 * 3;

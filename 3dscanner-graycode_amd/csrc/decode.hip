@@ -1167,7 +1167,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     {
         void *st = nullptr;
         const size_t nw = (size_t)blocks * 2;
-        if (slgc_ws(ctx, 11, nw * 5 * 8 + 64, &st)) return SLGC_ENOMEM;
+        if (slgc_ws(ctx, 12, nw * 5 * 8 + 64, &st)) return SLGC_ENOMEM;      // (a slot of its own: 11 holds the grey stack of the BGR fall-back)
         b.f.stamps = (unsigned long long *)st;
         ctx->stamp_waves = nw;
     }
@@ -1287,13 +1287,15 @@ int launch_decode_bgr(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
 }
 
 // The BGR form of the fused scan (slgc_scan_bgr_dev): planes of 3 bytes per pixel, 4-byte aligned, 32-bit offsets, one of the specialised frame counts.
+// d_xyz == nullptr: the decode-only BGR kernel (no fused tail: the fuse_tail knob does not apply).  The BGR kernels always compact flat
+// triangles over the wave (FUSE = 3): the guard_list A/B knob is not honoured there.
 bool scan_bgr_eligible(const slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                        const float *d_xyz)
 {
     uintptr_t align_or = (uintptr_t)plane_stride | ((uintptr_t)d_h >> 1) | ((uintptr_t)d_v >> 1);
     for (int r = 0; r < g.n_runs; ++r) align_or |= (uintptr_t)runs.p[r];
     return align_or % 4 == 0 && (uintptr_t)d_xyz % 16 == 0 && npix >= 4 && npix % 4 == 0 && (uint64_t)g.N * plane_stride + 3 * (uint64_t)npix + 4096u < 0xfffffff0ull &&      // (+ the lanes of the last, partial workgroup)
-           npix < 0x7fffffffull && ctx->tune_fuse_tail && spec_frames(ctx, g) != 0;
+           npix < 0x7fffffffull && (ctx->tune_fuse_tail || !d_xyz) && spec_frames(ctx, g) != 0;
 }
 
 // variant: 0 = library default; otherwise ABL*10000000 + NT*1000000 + ALG*100000 + PX*1000 + BLOCK, e.g. 104128 = packed-16 kernel,

@@ -8,11 +8,11 @@
 #include <cstdio>
 #include <cstring>
 
-#include "slgc.h"
+#include "slgc_bench.h"      // slgc.h (the reference-facing ABI) + the measurement / diagnostic exports
 
 #define SLGC_MAX_RUNS 8
 #define SLGC_MAX_EVENTS 16
-#define SLGC_WS_SLOTS 12
+#define SLGC_WS_SLOTS 14
 
 // Frame bookkeeping of one decode call; the index arithmetic follows the reference exactly
 // (decode_codes.py:109-111 float pattern_len + uint8 truncation; :149 int pattern_len).
@@ -242,10 +242,12 @@ constexpr size_t kCamNodesMinTable = (size_t)12 << 20;      // bytes of per-pixe
 // The node table of the band ensure_luts() last built (tri_math.h), or an empty one (kernels then read the per-pixel table).
 // kCamNodesMinTable: round 4 re-measured the choice at 1920x1080 (a 16.6 MB per-pixel table) after the fast form: node table 24.0 vs 24.5 us on the physical
 // capture, 25.1 vs 26.1 on the S-scene, 27.6 vs 28.5 on S-uniform (two boxes); at 1280x720 (7.4 MB) it still loses 2 %: the limit went from 64 MB to 12 MB.
-// tune_cam_nodes 1 (default) = when it pays: a per-pixel table of more than 64 MB streams from HBM on every scan, a smaller one stays in
-// the 256 MB Infinity Cache between scans and the node table only adds arithmetic (measured: 4096x3000 -1.3 % fused / -4.5 % two-kernel
-// step, 1920x1080 and 1280x720 +2 %); 2 = whenever it is accurate enough (tests); 0 = never.  The size that decides is the WHOLE image's
-// (tune_image_rows when the context scans a band of a taller image): the choice must not depend on how many GPUs share the image.
+// tune_cam_nodes 1 (default) = when it pays: above 12 MB of per-pixel rays (1920x1080 and larger; measured at 4096x3000: -1.3 % fused / -4.5 %
+// two-kernel step) the node table wins, below it (1280x720, 7.4 MB: the table stays cache-resident between scans and the nodes only add
+// arithmetic) it loses 2 %; 2 = whenever it is accurate enough (tests); 0 = never.  The node-table rays are not bit-identical with the per-pixel
+// table's (within 1 ulp; XYZ within the 1e-4 bar): moving the limit from 64 MB to 12 MB in round 4 changed the low bits of XYZ at 1920x1080 --
+// cam_nodes = 0 gives the per-pixel table's bits at every size.  The size that decides is the WHOLE image's (tune_image_rows
+// when the context scans a band of a taller image): the choice must not depend on how many GPUs share the image.
 #define SLGC_CAM_NODES_FOR(ctx, W, allow)                                                                                                   \
     (((allow) && (ctx)->lut_nodes && (ctx)->lut_cam_W == (W) &&                                                                            \
       ((ctx)->tune_cam_nodes == 2 ||                                                                                                       \

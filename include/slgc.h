@@ -19,6 +19,9 @@
  *    SLGC_F64 (the reference's own float64 stack; narrowed to uint8 on the host when every sample is a grey level,
  *    see slgc_last_input_path).  14 <= N <= 65 (code length L=int((N-2)/4) <= 15).
  *  - there is NO CPU fallback: without a HIP device slgc_create fails with SLGC_ENODEV.
+ *  - this header is the reference-facing ABI only.  Measurement and diagnostic exports of the same library (synthetic captures, device
+ *    self-tests, the movement-only yardstick, event / per-launch timing, the A/B knobs of slgc_tune) are declared in slgc_bench.h; nothing a
+ *    binding of the reference's functions needs is in there.
  */
 #ifndef SLGC_H
 #define SLGC_H
@@ -62,34 +65,14 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
-/* Tuning knobs for same-process A/B timing; no setting but the last one named here changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
- * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
- * "park" 1 = at 42 / 44 / 46 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
- * 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte wire format / 0 = int16 (default;
- * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default -1: 1 from 4 Mpixels per launch up, 3 below);
- * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1), "fuse_xcd" the same for the fused scan kernel (0 = off,
- * the default: 1 = one band of rows per XCD takes the kernel's traffic from 823 to 773 MB and its time from 127 to 137 us at
- * 4096x3000x44; n >= 2 = n consecutive tiles per XCD inside groups of 8 n: 782 MB and +2 % at n = 512).  The one knob that is NOT bit-neutral: "cam_nodes"
- * 1 = the scan kernels' fast form interpolates the camera rays from the every-4th-column table when the per-pixel table is too large
- * to pay as a per-pixel stream (> 12 MB: 1920x1080 and up; default, see slgc_ray_table_info: rays within 2 float32 ulp of the exact
- * ones, XYZ inside the 1e-4 tolerance, maps untouched) / 2 = whenever that table is accurate enough / 0 = reads the per-pixel table.
- * "lists_order" = workgroup -> tile order of the x-major list build, 0 .. 64, default 4: 0 row-major; 1 column-major (a column's run continues in the tile
- * below, so the seams are written close together in time; 217.6 -> 205.6 us at 4096x3000); 2 column-major inside each XCD (no better); n >= 3 (the
- * whole-lines scatter k_xmajor_lines only) column-major in runs of n consecutive tiles per XCD, so that a tile and the tile below it -- whose rows it also
- * reads -- share an L2 (n = 4: 218.8 -> 210.5 us).  The two scatter kernels read the value differently: the tile-run scatter k_xmajor_scatter treats
- * every value other than 0 and 2 as plain column-major (1).
- * "guard_list" 1 (default) = the fused scan kernel compacts its flat triangles over the wave and redoes 64 of them per float64 pass / 0 = redoes them lane by
- * lane (bit-identical XYZ; scattered wrong codes make the lane-by-lane form walk the float64 path in nearly every wave).
- * "lists_lines" 1 (default) = slgc_cloud_dev's list build writes whole aligned 128-byte lines (k_xmajor_lines; see slgc_last_list_kernel) for images of at
- * least 2048 tiles of 64 x 32 pixels (below that the tile-run kernel is the faster one) / 2 = wherever the shape allows / 0 = tile runs (A/B).
- * "image_rows" H > 0 = this context scans row bands of an image of H rows (the multi-GPU plan): the "cam_nodes" decision -- table size
- * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
- * scan its bands (0, the default: the band is the image).
- * Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD,
- * SLGC_FUSE_XCD, SLGC_CAM_NODES, SLGC_LISTS_LINES, SLGC_LISTS_ORDER, SLGC_GUARD_LIST), read when the context is created.  Other environment
- * switches (read once per process, A/B only): SLGC_FD_SEGS (segment count of the frame-difference kernel), SLGC_PAR_DOWNLOAD, SLGC_F64_PACK. */
+/* Settings of a context by name.  Three of them belong to the product: "image_rows" H > 0 = this context scans row bands of an image of H
+ * rows (the multi-GPU plan sets it): the camera ray-table choice is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether
+ * one GPU scans the image or N GPUs scan its bands (0, the default: the band is the image); "wire" 1 = slgc_scan_sharded_dev exchanges the
+ * maps in the 3-byte wire format / 0 = int16 (default); "cam_nodes" 1 (default) = above 12 MB of per-pixel camera rays (1920x1080 and up) the
+ * scan kernels interpolate the rays from an every-4th-column table (rays within 2 float32 ulp, XYZ inside the 1e-4 tolerance, maps
+ * untouched) / 0 = always the per-pixel table: the one setting that changes result bits.  Everything else slgc_tune accepts is an A/B
+ * timing knob documented in slgc_bench.h.  Unknown names: SLGC_EINVAL. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
-
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
  * integers in [0,255] (what src/3-capture_decode.py:66-70 builds), narrowed to uint8 on host threads into pinned staging and
  * uploaded as 1 byte per sample; 2 = float64 shipped as it is (a fraction / negative / NaN was found) and decoded by the float64
@@ -123,9 +106,6 @@ int slgc_last_scan_ragged(slgc_ctx *ctx);
 enum { SLGC_LISTS_NONE = 0, SLGC_LISTS_TILE_RUNS = 1, SLGC_LISTS_WHOLE_LINES = 2 };
 int slgc_last_list_kernel(slgc_ctx *ctx);
 int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen);
-/* PCI address of the context's device, "0000:c1:00.0" (how bench.py finds the device's clock / busy nodes under /sys/bus/pci/devices). */
-int slgc_device_pci_bus_id(slgc_ctx *ctx, char *buf, int buflen);
-
 /* ------------------------------------------------------------------ decode, host buffers */
 
 /* get_direct_indirect(images) -- scanner/grayCode/decode_codes.py:90-122.  L_d, L_g: float64 [H][W]. */
@@ -256,19 +236,6 @@ int slgc_decode_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t 
 int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n_scans, size_t scan_stride, size_t plane_stride, int N, int rows, int W,
                         int row0, int proj_w, int proj_h, double eps, double m, int mode, int16_t *d_h, int16_t *d_v, float *d_xyz);
 
-/* Diagnostic.  The device-resident decode kernels fold the per-pixel fp64 quantities of decode_codes.py:113-120 into integer
- * thresholds; this checks, for every (black, white, L_max, L_min) with black in [black_lo, black_hi) and the other three over
- * 0..255, that the folded tests agree with the literal fp64 comparisons of :172-182 for every grey level 0..255.
- * *mismatches receives the number of disagreements (0 expected).  black_lo = 0, black_hi = 256 is the whole uint8 domain.
- * Negative control: eps | 0x100 evaluates the literal side with eps + 1 (the count must then be non-zero). */
-int slgc_selftest_thresholds(slgc_ctx *ctx, int eps, int black_lo, int black_hi, unsigned long long *mismatches);
-
-/* Diagnostic.  The packed 16-bit evaluation of the rule table (two pixels per register, decode_codes.py:162-182 "last match
- * wins") against the scalar rules for every threshold triple (tnd, tg in 0..256, cA in 1..256 or "not direct") and every
- * (normal, inverse) grey-level pair: 1.1e12 classifications; *mismatches = 0 expected.  negative_control != 0 shifts one
- * threshold of the scalar side by one (the count must then be non-zero). */
-int slgc_selftest_classify(slgc_ctx *ctx, int negative_control, unsigned long long *mismatches);
-
 /* Triangulate dense int16 maps (as written by slgc_decode_dev) into dense XYZ; same outputs as slgc_scan_dev. */
 int slgc_triangulate_maps_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0,
                               int proj_w, int proj_h, int mode, float *d_xyz, unsigned long long *d_count);
@@ -287,11 +254,6 @@ int slgc_build_ray_tables_dev(slgc_ctx *ctx, int rows, int W, int row0, int proj
  * With slgc_tune "image_rows" both the size and the measured error are the WHOLE image's, whatever band the tables cover.
  * Building a node table reads its error back: that one call synchronises the context's stream (once per calibration / geometry). */
 int slgc_ray_table_info(slgc_ctx *ctx, int *in_use, double *max_err);
-
-/* Diagnostic: d_counts[0] += decodable pixels of the band, d_counts[1] += those among them that the dense triangulation redoes
- * on the reference's float32 intermediates because the triangle is flat (tri_is_flat, csrc/tri_math.h) -- the guarded slow path. */
-int slgc_guard_count_dev(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, int rows, int W, int row0, int proj_w, int proj_h,
-                         unsigned long long *d_counts);
 
 /* The reference-shaped product without leaving HBM: from the int16 maps and the dense XYZ of a (full-image) scan, the x-major
  * correspondence lists of get_cam_proj_pts (triangulate.py:52-71: columns outer, rows inner, clamp to the projector, colour =
@@ -342,56 +304,6 @@ int slgc_unpack_hv24_dev(slgc_ctx *ctx, const uint8_t *d_wire, size_t npix, int1
  * writes the int16 maps d_h / d_v as well (the separate unpack pass disappears).  mode: SLGC_TRI_EXACT or SLGC_TRI_ALGEBRAIC. */
 int slgc_triangulate_wire_dev(slgc_ctx *ctx, const uint8_t *d_wire, int rows, int W, int row0, int proj_w, int proj_h, int mode,
                               int16_t *d_h, int16_t *d_v, float *d_xyz, unsigned long long *d_count);
-
-/* Synthetic capture written straight into HBM (SURVEY.md section 8(d) "S-scene", counter-based noise). */
-int slgc_synth_scene_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows,
-                         uint32_t seed, int noise, int shadow);
-
-/* Measurement yardstick, not a product: moves the bytes of one single-run scan of N = 42 / 44 / 46 frames and does nothing else -- N planes
- * read 4 bytes per lane and plane like the scan kernels read them, the two int16 maps (d_h / d_v, both or neither) and 12 bytes per pixel
- * at d_xyz (may be NULL) written in the scan kernels' store shapes; what lands there is meaningless.  bench.py times it beside the kernel it
- * grades: on MI355X the scan kernels take what this takes (tools/ubench/stream_rates.hip is the longer study).  npix % 256 == 0. */
-int slgc_move_only_dev(slgc_ctx *ctx, const uint8_t *d_stack, size_t plane_stride, int N, size_t npix, int16_t *d_h, int16_t *d_v, float *d_xyz);
-
-/* Physically consistent synthetic capture (needs slgc_set_calibration): every camera pixel's ray is cast into a fixed scene (a tilted plane
- * with a sphere in front, 0.4 - 0.65 m away), the hit point goes through the stereo pose and the projector's forward lens model to the
- * projector pixel that lights it, and the frames encode THAT pixel -- one surface seen by camera and projector, which is what
- * src/4-triangulate.py:50-64 assumes of its inputs.  Pixels the projector does not reach stay at ambient level in every frame.
- * Optional outputs (device, may be NULL): d_h_true / d_v_true int16 [rows][W] = the encoded projector pixel (-1 = unlit);
- * d_truth_xyz float32 [rows][W][3] = the true surface point in the frame Triangulate.triangulate reports (NaN = unlit).
- * d_stack may be NULL (codes / truth only).  Bit-identical NumPy twin: oracle/oracle_np.py synth_physical. */
-int slgc_synth_physical_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
-                            int proj_h, uint32_t seed, int noise, int16_t *d_h_true, int16_t *d_v_true, float *d_truth_xyz);
-
-/* The same generator with its knobs: gain_lo / gain_hi = the two surface gains of its 16-pixel checker (frames = 15 + gain * bit + noise;
- * slgc_synth_physical_dev uses 140 / 180), r2_max = the squared radius in normalised projector coordinates up to which the projector's lens
- * model is taken to be monotonic (0.16 for the reference's `proj` calibration, which folds over at ~0.22; a mild lens can take 1.5).
- * Twin: oracle_np.synth_physical(..., gains=, r2_max=). */
-int slgc_synth_physical_ex_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, int proj_w,
-                               int proj_h, uint32_t seed, int noise, int gain_lo, int gain_hi, double r2_max, int16_t *d_h_true,
-                               int16_t *d_v_true, float *d_truth_xyz);
-
-/* SURVEY.md section 8(d) "S-uniform": every byte of every frame uniform in 0..255 (counter hash keyed by frame, dword of the whole image and
- * seed: a band holds the bytes of the same rows of the whole image).  W, plane_stride, d_stack multiples of 4.  Twin: oracle_np.synth_uniform. */
-int slgc_synth_uniform_dev(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int H, int W, int row0, int rows, uint32_t seed);
-
-/* A synthetic BGR capture of a grey stack (what the camera hands src/3-capture_decode.py:66): B = clip(g + ((7 x + 3 y) mod 11) - 5), G = g,
- * R = clip(g - (((5 x + 11 y) mod 9) - 4)) with y counted in the whole image.  d_bgr: [N][rows][W][3], bgr_plane_stride bytes between frames.
- * Twin: oracle_np.gray_to_bgr_capture. */
-int slgc_synth_bgr_dev(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_plane_stride, int N, int H, int W, int row0, int rows, uint8_t *d_bgr,
-                       size_t bgr_plane_stride);
-
-/* HIP-event timing on the context's stream: id in [0,16). */
-int slgc_event_record(slgc_ctx *ctx, int id);
-int slgc_event_elapsed_ms(slgc_ctx *ctx, int id_start, int id_stop, float *ms);
-
-/* Per-launch timing of the decode kernel: between _begin and _end every stride-th decode launch made through slgc_decode_dev /
- * slgc_scan_dev is bracketed by a HIP event pair on the context's stream (up to max_launches pairs); _end synchronises and
- * returns the summed kernel time and the number of launches sampled. */
-int slgc_prof_begin(slgc_ctx *ctx, int max_launches, int stride);
-int slgc_prof_end(slgc_ctx *ctx, double *total_ms, int *launches);
-/* After _end: the individual kernel durations (ms) of the sampled launches, in launch order; *n = number sampled (may exceed cap). */
-int slgc_prof_samples(slgc_ctx *ctx, float *ms, int cap, int *n);
 
 /* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI) */
 #define SLGC_UNIQUE_ID_BYTES 128

@@ -12,19 +12,26 @@ import pytest
 from conftest import PKG, ROOT
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "slgc.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(slgc_[a-z0-9_]+)\s*\(", text)))
+def header_functions(name=None):
+    """name = "slgc.h" (the reference-facing ABI) or "slgc_bench.h" (measurement / diagnostic exports); None = both."""
+    out = set()
+    for h in ([name] if name else ["slgc.h", "slgc_bench.h"]):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(slgc_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol():
     from scanner import _native
     lib = _native.lib()
     declared = header_functions()
-    assert len(declared) >= 35
+    abi, bench = header_functions("slgc.h"), header_functions("slgc_bench.h")
+    assert len(abi) >= 35 and not set(abi) & set(bench), set(abi) & set(bench)
+    # the reference-facing header stays free of measurement / diagnostic exports
+    assert not [n for n in abi if re.search(r"synth|selftest|move_only|prof_|event_|guard_count", n)], abi
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in slgc.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert sorted(_native.SIGNATURES) == declared, "ctypes signature table out of sync with slgc.h"
     out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (slgc_[a-z0-9_]+)", out)))
@@ -116,7 +123,7 @@ def test_header_is_plain_c_and_links(tmp_path):
     libslgc.so and call the entry points that need no GPU."""
     from scanner import _native
     src = tmp_path / "host.c"
-    src.write_text('#include <stdio.h>\n#include "slgc.h"\nint main(void){ int r0, rn;\n'
+    src.write_text('#include <stdio.h>\n#include "slgc.h"\n#include "slgc_bench.h"\nint main(void){ int r0, rn;\n'
                    ' if (slgc_shard_band(3000, 8, 7, &r0, &rn)) return 2;\n'
                    ' printf("%d %s %d %d\\n", slgc_version(), slgc_backend(), r0, rn); return 0; }\n')
     exe = tmp_path / "host"
