@@ -123,10 +123,10 @@ def test_bgr_scan_equals_to_gray_then_scan_and_the_oracle(ctx, W, H, N, runs, pa
         b.free()
 
 
-@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44"])
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "c3_4096x3000x46", "c2_1920x1080x46"])
 def test_bgr_scan_at_bench_sizes_every_pixel(ctx, workload):
     W, H, pw, ph, N = bench.WORKLOADS[workload]
-    scene = "physical"
+    scene = "physical" if N != 46 else "s-scene"          # 46 frames: the S-scene's 11-bit codes run past the projector's edge (clamp)
     calib = bench.calibration(W, H, pw, ph, rig=bench.SCENES[scene]["rig"])
     ctx.set_calibration(*calib)
     px = W * H
@@ -142,7 +142,7 @@ def test_bgr_scan_at_bench_sizes_every_pixel(ctx, workload):
     ref_h, ref_v, ref_xyz = oc.scan_dense(gref, (pw, ph), *calib)
     valid, worst = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32), ref_h, ref_v, ref_xyz,
                                 f"{workload} bgr scan")
-    assert valid > 0.8 * px
+    assert valid > (0.8 if scene == "physical" else 0.5) * px
     print(f"\n{workload} from BGR frames: {valid} / {px} decodable, worst rel. XYZ error {worst:.2e}")
     for b in (bgr, maps, xyz):
         b.free()

@@ -77,7 +77,7 @@ def compare_scan(got_h, got_v, got_xyz, ref_h, ref_v, ref_xyz, what):
     return int(ok.sum()), worst
 
 
-@pytest.mark.parametrize("workload,expect_valid", [("c3_4096x3000x44", 9_924_736), ("c2_1920x1080x44", None)])
+@pytest.mark.parametrize("workload,expect_valid", [("c3_4096x3000x44", 9_924_736), ("c2_1920x1080x44", None), ("c3_4096x3000x46", None), ("c2_1920x1080x46", None)])
 def test_bench_configuration_every_pixel(ctx, workload, expect_valid):
     from scanner import _native
     W, H, pw, ph, N = bench.WORKLOADS[workload]
@@ -167,10 +167,11 @@ def test_node_table_on_the_reference_lenses(ctx, cam):
         b.free()
 
 
-def test_bench_configuration_two_runs_every_pixel(ctx):
-    """src/3-capture_decode.py:95-96 (MAX_NB_RUNS = 2) at 4096x3000x44: two captures max-merged per code bit inside the fused kernel."""
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c3_4096x3000x46"])
+def test_bench_configuration_two_runs_every_pixel(ctx, workload):
+    """src/3-capture_decode.py:95-96 (MAX_NB_RUNS = 2) at 4096x3000x44 / x46: two captures max-merged per code bit inside the fused kernel."""
     from scanner import _native
-    W, H, pw, ph, N = bench.WORKLOADS["c3_4096x3000x44"]
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
     calib = bench.calibration(W, H, pw, ph)
     ctx.set_calibration(*calib)
     px = W * H
@@ -336,6 +337,15 @@ def test_executed_path_is_observable(ctx, workload):
     ctx.decode_dev(stack.ptr + 1, 1, N * px, px, N, H - 1, W, maps.at(0), maps.at(px * 2))
     ctx.triangulate_maps_dev(maps.at(0), maps.at(px * 2), H - 1, W, 0, (pw, ph), xyz.ptr)       # directly after a decode: completes that two-kernel scan
     assert ctx.last_scan_path()["path"] == "split-ragged"
+    # ... and a SECOND triangulation after it, with no fused scan in between, is on its own again: the decode's bit is gone
+    ctx.triangulate_maps_dev(maps.at(0), maps.at(px * 2), H - 1, W, 0, (pw, ph), xyz.ptr)
+    again = ctx.last_scan_path()
+    assert again["path"] == "split" and again["fallback_kernels"] == clean, again
+    # a triangulation through the per-pixel fallback, then a decode alone: the decode reports only its own (clean) bit
+    ctx.triangulate_maps_dev(maps.at(0), maps.at(px * 2), H - 1, W, 0, (pw, ph), xyz.ptr + 4)
+    assert ctx.last_scan_path()["fallback_kernels"] == {"decode": False, "triangulation": True}
+    ctx.decode_dev(stack.ptr, 1, N * px, px, N, H, W, maps.at(0), maps.at(px * 2))
+    assert ctx.last_scan_path()["fallback_kernels"] == clean
     ctx.tune("park", 0)
     assert scan(_native.TRI_ALGEBRAIC) == {"path": "fused", "ns_frames": 0, "node_table": big, "guard": True, "fallback_kernels": clean}
     ctx.tune("park", 1)

@@ -79,7 +79,10 @@ def test_covering_rig_generator_equals_numpy_twin(ctx, scene):
         b.free()
 
 
-@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "c1_1280x720x42"])
+# N = 46 (L = 11 code bits) is the only frame count the reference's own generator emits for the projectors of BASELINE.json
+# (generate_codes.py:22-25,53: 4 * ceil(log2(max(w, h))) + 2): codes reach 2047, so the projector clamp of triangulate.py:60-61 fires on every
+# pixel decoded right of / below the projector's edge, and the 46-frame kernels are separate compiled specialisations.
+@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "c1_1280x720x42", "c3_4096x3000x46", "c2_1920x1080x46"])
 @pytest.mark.parametrize("scene", ["physical", "noisy-physical", "s-uniform", "s-scene"])
 def test_bench_scene_every_pixel(ctx, workload, scene):
     from scanner import _native
@@ -115,7 +118,12 @@ def test_bench_scene_every_pixel(ctx, workload, scene):
     frac = valid / px
     print(f"\n{workload} {scene}: {valid} / {px} decodable ({frac:.3f}), {n_flat} on the guarded path ({100.0 * n_flat / max(valid, 1):.3f} % of them), "
           f"worst rel. XYZ error {worst:.2e}")
-    if scene == "physical":
+    if N == 46:
+        clamped = int((((ref_h >= pw) | (ref_v >= ph)) & (ref_h != -1) & (ref_v != -1)).sum())
+        print(f"  N = 46: {clamped} decodable pixels beyond the projector's edge (clamped, triangulate.py:60-61)")
+        if scene == "s-uniform" or (scene == "s-scene" and W > 1920):      # (the S-scene's codes stay inside a 1920x1080 projector at 1920x1080)
+            assert clamped > 0.02 * valid
+    if scene == "physical" and N != 46:
         assert frac >= 0.8 and n_flat <= 0.001 * n_ok       # the headline capture: most pixels decode, one consistent surface, (almost) no flat triangle
     if scene == "s-uniform":
         assert 0.1 < frac < 0.35 and n_flat > 0
