@@ -313,6 +313,7 @@ extern "C" int slgc_destroy(slgc_ctx *ctx)
 {
     if (!ctx) return SLGC_EINVAL;
     (void)hipSetDevice(ctx->device);
+    slgc_direct_destroy(ctx);
     slgc_comm_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < SLGC_WS_SLOTS; ++i)

@@ -1,0 +1,490 @@
+// direct.hip -- the exchange step of the row-sharded scan written for this machine: every rank pushes its band straight into every
+// peer's full-size buffer over xGMI, all G-1 links busy at once ("direct all-gather").
+//
+// The reference is single-process; this exists only because the build shards ONE scan by image rows over the GPUs of a node
+// (BASELINE.json configs[3]).  RCCL's all-gather is a ring (per-link bound, G-1 steps) and its ragged form is a group of broadcasts;
+// MI355X's xGMI is a full point-to-point mesh (7 links per GPU), so an all-gather of row bands is G-1 independent band copies per rank
+// that can all be in flight together.  How it is built:
+//   * one POSIX shared-memory segment per job (name = the job's key): IPC handles of the registered buffers, the flag words, a host barrier.
+//     Every rank page-locks the segment (hipHostRegister): host memory is fine-grained, so flag words written by one GPU (or the host) are
+//     seen by another GPU's system-scope loads -- device memory shared over IPC is coarse-grained and gives no such promise inside a kernel;
+//   * slgc_direct_register (collective): each rank exports the hipIpcMemHandle of a full-size buffer, opens every peer's;
+//   * slgc_direct_allgatherv_begin on up to 3 registered buffers with one band layout (h + v maps, or + XYZ), on the exchange stream:
+//       gate kernel   waits until every peer has RELEASED the buffers (their previous contents were consumed there: slgc_direct_release),
+//       push kernel   copies the rank's band from its own buffer into the same place of every peer's buffer (16-byte lanes, one workgroup
+//                     per (peer, chunk): every link carries its band at the same time), __threadfence_system() behind the last store,
+//       flag kernel   writes the exchange's sequence number into arrived[peer][rank][buffer] of every peer;
+//   * slgc_direct_wait(slot), on the compute stream: a one-wave kernel polls arrived[rank][*][buffer] until every peer's band of that
+//     sequence number is in.  The kernels that read the bands start AFTER it ends: the acquire at their start is what makes remotely
+//     written coarse-grained memory visible (no kernel reads a byte a peer wrote while it runs).
+// Polling kernels are one wave, sleep between polls and give up after kDirectTimeoutS seconds (error word in the segment, reported by the
+// next host call): a lost peer costs a failed scan, never a hung GPU.
+// hipIpcOpenMemHandle also works between processes that share ONE GPU, so tests/test_gpu_rccl_multi.py runs this path bit for bit on the
+// one-GPU test box; the links themselves are only exercised on a real node.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <new>
+
+#include "slgc_internal.h"
+
+namespace {
+
+constexpr int kMaxRanks = 16;
+constexpr int kMaxBufs = 16;
+constexpr uint32_t kMagic = 0x534c4744u;       // "SLGD"
+constexpr double kDirectTimeoutS = 20.0;       // GPU-side polls (s_memrealtime runs at 100 MHz)
+constexpr double kHostTimeoutS = 120.0;        // host barrier
+
+struct Segment {                               // lives in the shared-memory segment, identical view in every rank
+    std::atomic<uint32_t> magic;               // set by rank 0 when the segment is initialised
+    uint32_t nranks;
+    std::atomic<uint32_t> attached;            // ranks that have mapped the segment
+    std::atomic<uint32_t> bar_count, bar_sense;
+    std::atomic<uint32_t> error;               // a GPU-side poll timed out (rank + 1 of the first one that did)
+    uint32_t pad0[10];
+    int64_t word[kMaxRanks];                   // host all-gather / all-reduce scratch
+    double dword[kMaxRanks];
+    hipIpcMemHandle_t handle[kMaxRanks][kMaxBufs];
+    uint64_t bytes[kMaxRanks][kMaxBufs];
+    // flag words, written by GPUs with system-scope stores: arrived[dst][src][buf] = sequence number of the last band of src that is complete
+    // in dst's buffer; released[rank][buf] = sequence number up to which rank has consumed (and is about to overwrite) its buffer
+    uint32_t arrived[kMaxRanks][kMaxRanks][kMaxBufs];
+    uint32_t released[kMaxRanks][kMaxBufs];
+};
+
+struct Direct {
+    int rank = 0, nranks = 0;
+    char name[96] = {0};
+    Segment *seg = nullptr;                    // host mapping
+    Segment *dseg = nullptr;                   // the same memory as the device sees it
+    bool registered_host = false;
+    uint32_t local_sense = 0;
+    int nbuf = 0;
+    void *base[kMaxBufs] = {nullptr};          // this rank's buffers
+    size_t bytes[kMaxBufs] = {0};
+    void *peer[kMaxBufs][kMaxRanks] = {{nullptr}};   // every rank's buffer b as mapped here (own entry = base)
+    uint32_t seq[kMaxBufs] = {0};              // exchanges started on buffer b (same on every rank: the calls are collective)
+    uint32_t want[4][kMaxBufs] = {{0}};        // slot -> sequence number to wait for per buffer (0 = buffer not part of the slot)
+    hipStream_t stream = nullptr;              // exchange stream
+    hipEvent_t ev_compute = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+Direct *state(slgc_ctx *ctx) { return (Direct *)ctx->direct; }
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int need_direct(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    if (!ctx->direct) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange not initialised (call slgc_direct_init)");
+    const uint32_t e = state(ctx)->seg->error.load(std::memory_order_acquire);
+    if (e) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: a GPU-side wait on rank %u timed out after %.0f s (a peer is gone or stalled)", e - 1, kDirectTimeoutS);
+    return SLGC_OK;
+}
+
+// Host barrier over the segment (sense reversing).  Only around set-up / tear-down and the small host collectives: never per scan.
+int host_barrier(slgc_ctx *ctx, Direct *d)
+{
+    Segment *s = d->seg;
+    const uint32_t sense = d->local_sense ^= 1u;
+    if (s->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)d->nranks) {
+        s->bar_count.store(0, std::memory_order_relaxed);
+        s->bar_sense.store(sense, std::memory_order_release);
+        return SLGC_OK;
+    }
+    const double t0 = now_s();
+    while (s->bar_sense.load(std::memory_order_acquire) != sense) {
+        if (now_s() - t0 > kHostTimeoutS) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: host barrier timed out after %.0f s", kHostTimeoutS);
+        usleep(50);
+    }
+    return SLGC_OK;
+}
+
+__device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+struct FlagList {
+    uint32_t *p[kMaxRanks * 3];                // flag words (device view of the segment)
+    uint32_t v[kMaxRanks * 3];                 // value to wait for (>=) / to store
+    int n;
+    uint32_t *error;
+    uint32_t who;                              // rank + 1
+    unsigned long long timeout_ticks;
+};
+
+// One wave: lane i polls flag i until it has reached its value (sequence numbers only grow; the comparison is wrap-safe).
+__global__ void __launch_bounds__(64) k_flags_wait(const FlagList f)
+{
+    const int i = threadIdx.x;
+    if (i >= f.n) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(sys_load(f.p[i]) - f.v[i]) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > f.timeout_ticks) {
+            sys_store(f.error, f.who);           // (a plain store: atomics on host memory would need PCIe atomics)
+            return;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_flags_set(const FlagList f)
+{
+    const int i = threadIdx.x;
+    if (i >= f.n) return;
+    __threadfence_system();
+    sys_store(f.p[i], f.v[i]);
+}
+
+struct PushArgs {
+    const uint8_t *src[3];                     // the band in this rank's buffers
+    uint8_t *dst[3][kMaxRanks];                // the same place in every peer's buffer (own rank: nullptr)
+    uint64_t bytes[3];                         // band bytes per buffer
+    int nbuf, npeers;
+    int peer_rank[kMaxRanks];
+    uint32_t chunks;                           // workgroups per (buffer, peer)
+};
+
+// grid = nbuf * npeers * chunks workgroups of 256 lanes; each moves a contiguous slice of one band to one peer, 16 bytes per lane and step.
+// Loads are ordinary (the band was just written by this GPU: L2 / Infinity Cache hits), stores go straight out over the link.
+__global__ void __launch_bounds__(256) k_push_bands(const PushArgs a)
+{
+    uint32_t id = blockIdx.x;
+    const uint32_t chunk = id % a.chunks;
+    id /= a.chunks;
+    const int pi = (int)(id % (uint32_t)a.npeers), b = (int)(id / (uint32_t)a.npeers);
+    const uint8_t *src = a.src[b];
+    uint8_t *dst = a.dst[b][a.peer_rank[pi]];
+    const uint64_t n = a.bytes[b];
+    // slices in whole 16-byte units; the bytes before the first aligned unit and after the last one go with chunk 0 (bands of the sharded
+    // scan are multiples of the row length, so src and dst share their alignment)
+    const uint64_t head = (16u - ((uintptr_t)src & 15u)) & 15u;
+    const uint64_t h = head < n ? head : n;
+    const uint64_t units = (n - h) / 16u, tail = (n - h) % 16u;
+    if (chunk == 0 && threadIdx.x < 32) {
+        for (uint64_t i = threadIdx.x; i < h; i += 32) dst[i] = src[i];
+        for (uint64_t i = threadIdx.x; i < tail; i += 32) dst[h + units * 16u + i] = src[h + units * 16u + i];
+    }
+    const uint64_t per = (units + a.chunks - 1) / a.chunks;
+    const uint64_t u0 = (uint64_t)chunk * per, u1 = u0 + per < units ? u0 + per : units;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src + h);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst + h);
+    if (((uintptr_t)(dst + h) & 15u) == 0) {
+        for (uint64_t u = u0 + threadIdx.x; u < u1; u += 256) d4[u] = s4[u];
+    } else {                                    // differently aligned destination (not produced by the sharded scan): bytes
+        for (uint64_t u = u0 + threadIdx.x; u < u1; u += 256)
+            for (int k = 0; k < 16; ++k) dst[h + u * 16u + k] = src[h + u * 16u + k];
+    }
+    __threadfence_system();                     // this lane's stores are complete at the peer before the kernel can end
+}
+
+int find_buf(Direct *d, const void *base)
+{
+    for (int b = 0; b < d->nbuf; ++b)
+        if (d->base[b] == base) return b;
+    return -1;
+}
+
+int after_compute(slgc_ctx *ctx, Direct *d)
+{
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(d->ev_compute, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(d->stream, d->ev_compute, 0));
+    return SLGC_OK;
+}
+
+void fill_common(FlagList &f, Direct *d)
+{
+    f.error = reinterpret_cast<uint32_t *>(&d->dseg->error);
+    f.who = (uint32_t)d->rank + 1u;
+    f.timeout_ticks = (unsigned long long)(kDirectTimeoutS * 1e8);
+}
+
+}  // namespace
+
+extern "C" int slgc_direct_init(slgc_ctx *ctx, int rank, int nranks, const char *key)
+{
+    if (!ctx || !key || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return slgc_fail(ctx, SLGC_EINVAL, "bad rank / nranks (at most %d) / key", kMaxRanks);
+    if (ctx->direct) return slgc_fail(ctx, SLGC_ESTATE, "direct exchange already initialised");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Direct *d = new (std::nothrow) Direct();
+    if (!d) return SLGC_ENOMEM;
+    d->rank = rank;
+    d->nranks = nranks;
+    snprintf(d->name, sizeof d->name, "/slgc_direct_%.64s", key);
+    for (char *c = d->name + 1; *c; ++c)
+        if (*c == '/') *c = '_';
+    const size_t seg_bytes = (sizeof(Segment) + 4095u) & ~(size_t)4095u;
+    int fd = -1;
+    const double t0 = now_s();
+    if (rank == 0) {
+        shm_unlink(d->name);                                       // a stale segment of a crashed job with the same key
+        fd = shm_open(d->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)seg_bytes) != 0) {
+            close(fd);
+            fd = -1;
+        }
+    } else {
+        while (fd < 0 && now_s() - t0 < kHostTimeoutS) {
+            fd = shm_open(d->name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < seg_bytes)) {      // rank 0 has not sized it yet
+                close(fd);
+                fd = -1;
+            }
+            if (fd < 0) usleep(200);
+        }
+    }
+    if (fd < 0) {
+        slgc_fail(ctx, SLGC_ECOMM, "direct exchange: shm_open(%s) failed on rank %d", d->name, rank);
+        delete d;
+        return SLGC_ECOMM;
+    }
+    void *m = mmap(nullptr, seg_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        delete d;
+        return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: mmap of the shared segment failed");
+    }
+    d->seg = (Segment *)m;
+    if (rank == 0) {
+        memset(m, 0, seg_bytes);
+        d->seg->nranks = (uint32_t)nranks;
+        d->seg->magic.store(kMagic, std::memory_order_release);
+    } else {
+        while (d->seg->magic.load(std::memory_order_acquire) != kMagic) {
+            if (now_s() - t0 > kHostTimeoutS) {
+                munmap(m, seg_bytes);
+                delete d;
+                return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: rank 0 never initialised the shared segment");
+            }
+            usleep(100);
+        }
+        if (d->seg->nranks != (uint32_t)nranks) {
+            munmap(m, seg_bytes);
+            delete d;
+            return slgc_fail(ctx, SLGC_EINVAL, "direct exchange: ranks disagree on nranks");
+        }
+    }
+    ctx->direct = d;
+    hipError_t e = hipHostRegister(m, seg_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e == hipSuccess) {
+        d->registered_host = true;
+        e = hipHostGetDevicePointer((void **)&d->dseg, m, 0);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_compute, hipEventDisableTiming);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&d->ev_done[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        slgc_fail(ctx, SLGC_EHIP, "direct exchange set-up: %s", hipGetErrorString(e));
+        slgc_direct_destroy(ctx);
+        return SLGC_EHIP;
+    }
+    d->seg->attached.fetch_add(1, std::memory_order_acq_rel);
+    int rc = host_barrier(ctx, d);
+    if (rc == SLGC_OK && rank == 0) shm_unlink(d->name);           // every rank holds its mapping: the name can go (nothing is left behind if the job dies)
+    return rc;
+}
+
+extern "C" int slgc_direct_destroy(slgc_ctx *ctx)
+{
+    if (!ctx) return SLGC_EINVAL;
+    Direct *d = state(ctx);
+    if (!d) return SLGC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    for (int b = 0; b < d->nbuf; ++b)
+        for (int r = 0; r < d->nranks; ++r)
+            if (r != d->rank && d->peer[b][r]) (void)hipIpcCloseMemHandle(d->peer[b][r]);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->ev_compute) (void)hipEventDestroy(d->ev_compute);
+    for (int i = 0; i < 4; ++i)
+        if (d->ev_done[i]) (void)hipEventDestroy(d->ev_done[i]);
+    if (d->seg) {
+        if (d->registered_host) (void)hipHostUnregister(d->seg);
+        munmap(d->seg, (sizeof(Segment) + 4095u) & ~(size_t)4095u);
+    }
+    delete d;
+    ctx->direct = nullptr;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_direct_register(slgc_ctx *ctx, void *d_base, size_t bytes)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    if (!d_base || !bytes) return slgc_fail(ctx, SLGC_EINVAL, "null buffer");
+    if (d->nbuf >= kMaxBufs) return slgc_fail(ctx, SLGC_EINVAL, "at most %d buffers can be registered", kMaxBufs);
+    if (find_buf(d, d_base) >= 0) return slgc_fail(ctx, SLGC_EINVAL, "buffer already registered");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int b = d->nbuf;
+    hipIpcMemHandle_t mine;
+    HIP_TRY(ctx, hipIpcGetMemHandle(&mine, d_base));              // d_base must be the start of a slgc_dev_alloc allocation
+    d->seg->handle[d->rank][b] = mine;
+    d->seg->bytes[d->rank][b] = bytes;
+    if ((rc = host_barrier(ctx, d))) return rc;                     // every rank's handle of buffer b is in the segment
+    int bad = 0;
+    for (int r = 0; r < d->nranks; ++r) {
+        if (r == d->rank) {
+            d->peer[b][r] = d_base;
+            continue;
+        }
+        if (d->seg->bytes[r][b] != bytes) {
+            bad = 1;
+            continue;
+        }
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, d->seg->handle[r][b], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            slgc_fail(ctx, SLGC_EHIP, "hipIpcOpenMemHandle (rank %d's buffer %d): %s", r, b, hipGetErrorString(e));
+            bad = 2;
+            continue;
+        }
+        d->peer[b][r] = p;
+    }
+    d->base[b] = d_base;
+    d->bytes[b] = bytes;
+    d->nbuf = b + 1;
+    const int rc2 = host_barrier(ctx, d);                           // nobody re-uses the handle slots before everyone has opened them
+    if (bad == 1) return slgc_fail(ctx, SLGC_EINVAL, "direct exchange: ranks registered buffers of different sizes");
+    if (bad == 2) return SLGC_EHIP;
+    return rc2;
+}
+
+extern "C" int slgc_direct_allgatherv_begin(slgc_ctx *ctx, int nbuf, void *const *d_bases, const int64_t *const *counts, const int64_t *const *displs, int slot)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    if (nbuf < 1 || nbuf > 3 || !d_bases || !counts || !displs || slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "1..3 buffers, slot 0..3");
+    int ids[3];
+    PushArgs pa{};
+    FlagList gate{}, done{};
+    fill_common(gate, d);
+    fill_common(done, d);
+    for (int i = 0; i < nbuf; ++i) {                                  // (everything is checked before any sequence number moves)
+        ids[i] = find_buf(d, d_bases[i]);
+        if (ids[i] < 0) return slgc_fail(ctx, SLGC_EINVAL, "buffer %d is not registered (slgc_direct_register)", i);
+        if (!counts[i] || !displs[i]) return slgc_fail(ctx, SLGC_EINVAL, "null layout");
+        const int64_t c = counts[i][d->rank], o = displs[i][d->rank];
+        if (c < 0 || o < 0 || (uint64_t)(o + c) > d->bytes[ids[i]]) return slgc_fail(ctx, SLGC_EINVAL, "band outside the registered buffer");
+        for (int j = 0; j < i; ++j)
+            if (ids[j] == ids[i]) return slgc_fail(ctx, SLGC_EINVAL, "the same buffer twice in one exchange");
+    }
+    for (int i = 0; i < kMaxBufs; ++i) d->want[slot][i] = 0;
+    for (int i = 0; i < nbuf; ++i) {
+        const int64_t c = counts[i][d->rank], o = displs[i][d->rank];
+        const uint32_t seq = ++d->seq[ids[i]];
+        d->want[slot][ids[i]] = seq;
+        pa.src[i] = (const uint8_t *)d->base[ids[i]] + o;
+        pa.bytes[i] = (uint64_t)c;
+        for (int r = 0; r < d->nranks; ++r) {
+            if (r == d->rank) continue;
+            pa.dst[i][r] = (uint8_t *)d->peer[ids[i]][r] + o;
+            gate.p[gate.n] = &d->dseg->released[r][ids[i]];        // the peer has let go of what exchange seq - 1 left in its buffer
+            gate.v[gate.n++] = seq - 1u;
+            done.p[done.n] = &d->dseg->arrived[r][d->rank][ids[i]];
+            done.v[done.n++] = seq;
+        }
+    }
+    pa.nbuf = nbuf;
+    for (int r = 0; r < d->nranks; ++r)
+        if (r != d->rank) pa.peer_rank[pa.npeers++] = r;
+    if ((rc = after_compute(ctx, d))) return rc;
+    if (pa.npeers > 0) {
+        uint64_t most = 0;
+        for (int i = 0; i < nbuf; ++i) most = pa.bytes[i] > most ? pa.bytes[i] : most;
+        // enough workgroups per link to keep it busy (64 KB slices, at most 64 per band and peer), never an empty grid
+        uint32_t chunks = (uint32_t)((most + 65535u) / 65536u);
+        pa.chunks = chunks < 1 ? 1 : chunks > 64 ? 64 : chunks;
+        hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, d->stream, gate);
+        hipLaunchKernelGGL(k_push_bands, dim3((unsigned)(nbuf * pa.npeers) * pa.chunks), dim3(256), 0, d->stream, pa);
+        hipLaunchKernelGGL(k_flags_set, dim3(1), dim3(64), 0, d->stream, done);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(d->ev_done[slot], d->stream));
+    return SLGC_OK;
+}
+
+extern "C" int slgc_direct_wait(slgc_ctx *ctx, int slot)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    if (slot < 0 || slot > 3) return slgc_fail(ctx, SLGC_EINVAL, "slot outside 0..3");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, d->ev_done[slot], 0));     // this rank's own pushes are out (its band may be overwritten from here on)
+    FlagList f{};
+    fill_common(f, d);
+    for (int b = 0; b < d->nbuf; ++b) {
+        if (!d->want[slot][b]) continue;
+        for (int r = 0; r < d->nranks; ++r) {
+            if (r == d->rank) continue;
+            f.p[f.n] = &d->dseg->arrived[d->rank][r][b];
+            f.v[f.n++] = d->want[slot][b];
+        }
+    }
+    if (f.n > 0) {
+        hipLaunchKernelGGL(k_flags_wait, dim3(1), dim3(64), 0, ctx->stream, f);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return SLGC_OK;
+}
+
+// On the compute stream: "everything enqueued so far has finished with what the last exchange left in these buffers" -- peers may push the
+// next bands into them.  The sharded scanner calls it right before it re-uses a buffer set itself.
+extern "C" int slgc_direct_release(slgc_ctx *ctx, int nbuf, void *const *d_bases)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    if (nbuf < 1 || nbuf > 3 || !d_bases) return slgc_fail(ctx, SLGC_EINVAL, "1..3 buffers");
+    FlagList f{};
+    fill_common(f, d);
+    for (int i = 0; i < nbuf; ++i) {
+        const int b = find_buf(d, d_bases[i]);
+        if (b < 0) return slgc_fail(ctx, SLGC_EINVAL, "buffer %d is not registered", i);
+        f.p[f.n] = &d->dseg->released[d->rank][b];
+        f.v[f.n++] = d->seq[b];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_flags_set, dim3(1), dim3(64), 0, ctx->stream, f);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+// Small host collectives over the segment (set-up, verification, timing): both streams are drained first.
+extern "C" int slgc_direct_barrier(slgc_ctx *ctx)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+    if ((rc = need_direct(ctx))) return rc;                          // a GPU-side timeout shows here
+    return host_barrier(ctx, d);
+}
+
+extern "C" int slgc_direct_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all)
+{
+    int rc = need_direct(ctx);
+    if (rc) return rc;
+    Direct *d = state(ctx);
+    if (!all) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    d->seg->word[d->rank] = mine;
+    if ((rc = host_barrier(ctx, d))) return rc;
+    for (int r = 0; r < d->nranks; ++r) all[r] = d->seg->word[r];
+    return host_barrier(ctx, d);
+}

@@ -126,6 +126,7 @@ struct slgc_ctx {
     hipStream_t comm_stream;          // every collective runs here, ordered against ctx->stream with events
     hipEvent_t ev_compute;            // "compute stream reached this point" (recorded before a collective is enqueued)
     hipEvent_t ev_comm_done[4];       // completion of the collective started in slot s (slgc_comm_allgatherv_begin / _wait)
+    void *direct;                     // direct.hip: state of the all-links band exchange (slgc_direct_*), nullptr until slgc_direct_init
 };
 
 int slgc_fail(slgc_ctx *ctx, int status, const char *fmt, ...);

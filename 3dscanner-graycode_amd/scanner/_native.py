@@ -109,6 +109,14 @@ SIGNATURES = {
     "slgc_comm_allgatherv_begin": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_allgatherv_pair_begin": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_wait": (_i, [_vp, _i]),
+    "slgc_direct_init": (_i, [_vp, _i, _i, C.c_char_p]),
+    "slgc_direct_destroy": (_i, [_vp]),
+    "slgc_direct_register": (_i, [_vp, _vp, _sz]),
+    "slgc_direct_allgatherv_begin": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.POINTER(_i64)), C.POINTER(C.POINTER(_i64)), _i]),
+    "slgc_direct_wait": (_i, [_vp, _i]),
+    "slgc_direct_release": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "slgc_direct_barrier": (_i, [_vp]),
+    "slgc_direct_allgather_i64": (_i, [_vp, _i64, C.POINTER(_i64)]),
     "slgc_shard_band": (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "slgc_scan_batch_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
     "slgc_scan_sharded_dev": (_i, [_vp, _vp, _i, _sz, _sz, _i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp]),
@@ -788,6 +796,42 @@ class Context:
 
     def comm_wait(self, slot: int):
         self._ck(lib().slgc_comm_wait(self._h, int(slot)))
+
+    # ---- direct exchange (every rank pushes its band into every peer's buffer over xGMI: csrc/direct.hip)
+    def direct_init(self, rank: int, nranks: int, key: str):
+        self._ck(lib().slgc_direct_init(self._h, int(rank), int(nranks), str(key).encode()))
+        self.direct_rank, self.direct_nranks = rank, nranks
+
+    def direct_destroy(self):
+        self._ck(lib().slgc_direct_destroy(self._h))
+
+    def direct_register(self, d_base: int, nbytes: int):
+        self._ck(lib().slgc_direct_register(self._h, d_base, int(nbytes)))
+
+    def direct_allgatherv_begin(self, d_bases, layouts, slot: int):
+        """d_bases: 1..3 registered buffers (base device pointers); layouts: [(counts, displs)] per buffer, bytes per rank."""
+        n, k = self.direct_nranks, len(d_bases)
+        bases = (C.c_void_p * k)(*[int(b) for b in d_bases])
+        cs = [(C.c_int64 * n)(*[int(x) for x in c]) for c, _ in layouts]
+        ds = [(C.c_int64 * n)(*[int(x) for x in d]) for _, d in layouts]
+        cp = (C.POINTER(C.c_int64) * k)(*[C.cast(a, C.POINTER(C.c_int64)) for a in cs])
+        dp = (C.POINTER(C.c_int64) * k)(*[C.cast(a, C.POINTER(C.c_int64)) for a in ds])
+        self._ck(lib().slgc_direct_allgatherv_begin(self._h, k, bases, cp, dp, int(slot)))
+
+    def direct_wait(self, slot: int):
+        self._ck(lib().slgc_direct_wait(self._h, int(slot)))
+
+    def direct_release(self, d_bases):
+        k = len(d_bases)
+        self._ck(lib().slgc_direct_release(self._h, k, (C.c_void_p * k)(*[int(b) for b in d_bases])))
+
+    def direct_barrier(self):
+        self._ck(lib().slgc_direct_barrier(self._h))
+
+    def direct_allgather_i64(self, mine: int):
+        out = (C.c_int64 * self.direct_nranks)()
+        self._ck(lib().slgc_direct_allgather_i64(self._h, int(mine), out))
+        return [int(x) for x in out]
 
     def scan_sharded_dev(self, d_band_stack: int, n_runs, run_stride, plane_stride, N, H, W, proj_size, d_h_full: int, d_v_full: int,
                          d_xyz_full: int, eps=1, m=10, mode=TRI_ALGEBRAIC):

@@ -156,6 +156,66 @@ class RcclExchange:
     def barrier(self):
         self.ctx.comm_barrier()
 
+    def register(self, buffers):
+        """(RCCL needs no registration; the direct exchange does)"""
+
+    def release(self, buffers):
+        """(RCCL overwrites a rank's buffers from that rank's own communication stream, ordered after its compute stream: nothing to release)"""
+
+
+class DirectExchange:
+    """The same exchange protocol with every band pushed straight into every peer's buffer over xGMI, all links at once (csrc/direct.hip;
+    hipIpcMemHandle mappings, flags in one shared-memory segment, no RCCL).  Buffers that take part are the scanner's full-size buffers,
+    registered collectively (same order on every rank); every exchange is in place: the rank's band sits at displs[rank] of the buffer.
+
+    EXPERIMENTAL until a node has timed it against RcclExchange: RCCL stays the default of :class:`ShardedScanner` users (bench.py times this
+    one as a ``sharded_alternatives`` entry and verifies it bit for bit)."""
+
+    def __init__(self, ctx, rank: int, nranks: int, key: str):
+        self.ctx, self.rank, self.nranks = ctx, rank, nranks
+        ctx.direct_init(rank, nranks, key)
+        self._base = {}                                                # registered base pointer -> size
+
+    def register(self, buffers):
+        for b in buffers:
+            if b.ptr not in self._base:
+                self.ctx.direct_register(b.ptr, b.nbytes)
+                self._base[b.ptr] = b.nbytes
+
+    def _in_place(self, d_send, d_recv, displs):
+        recv = RcclExchange._ptr(d_recv)
+        if recv not in self._base:
+            raise ValueError("DirectExchange: the receive buffer is not registered")
+        if RcclExchange._ptr(d_send) != recv + displs[self.rank]:
+            raise ValueError("DirectExchange exchanges in place: the band must sit at displs[rank] of the receive buffer")
+        return recv
+
+    def allgather_i64(self, value: int):
+        return self.ctx.direct_allgather_i64(value)
+
+    def allgatherv_begin(self, d_send, d_recv, byte_counts, byte_displs, slot: int):
+        self.ctx.direct_allgatherv_begin([self._in_place(d_send, d_recv, byte_displs)], [(byte_counts, byte_displs)], slot)
+
+    def allgatherv_pair_begin(self, d_send_a, d_recv_a, d_send_b, d_recv_b, byte_counts, byte_displs, slot: int):
+        self.ctx.direct_allgatherv_begin([self._in_place(d_send_a, d_recv_a, byte_displs), self._in_place(d_send_b, d_recv_b, byte_displs)],
+                                         [(byte_counts, byte_displs)] * 2, slot)
+
+    def allgatherv(self, d_send, d_recv, byte_counts, byte_displs):
+        self.allgatherv_begin(d_send, d_recv, byte_counts, byte_displs, 3)
+        self.wait(3)
+
+    def wait(self, slot: int):
+        self.ctx.direct_wait(slot)
+
+    def release(self, buffers):
+        """Compute stream: everything enqueued so far is done with what the last exchange left in these buffers; peers may overwrite them."""
+        bases = [b.ptr for b in buffers if b.ptr in self._base]
+        for i in range(0, len(bases), 3):
+            self.ctx.direct_release(bases[i:i + 3])
+
+    def barrier(self):
+        self.ctx.direct_barrier()
+
 
 def map_band_layout(plan: ShardPlan):
     """Byte counts / displacements of the int16 map bands inside one full [H][W] int16 map."""
@@ -232,17 +292,32 @@ class ShardedScanner:
             self._submitted = 0
             self._pending = None
             self._pair = False
+            # what travels: the packed wire buffers, or the maps themselves (registered with an exchange that maps peers' buffers)
+            self._exchanged = [[self._wire[s]] if wire == "hv24" else list(self._sets[s]) for s in range(2)]
         elif exchange_kind == "xyz":
             self.wire = "int16"
             self._sets = [(ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 2)), ctx.alloc(max(16, full_px * 12))) for _ in range(2)]
             self.h_full, self.v_full, self.xyz_full = self._sets[0]
             self._submitted = 0
             self._pending = None
+            self._exchanged = [list(self._sets[s]) for s in range(2)]
         else:
             self.maps = ctx.alloc(max(16, band_px * 4))
             self.xyz = ctx.alloc(max(16, band_px * 12))
             self.records = ctx.alloc(max(16, band_px * RECORD_BYTES))
             self.all_records = ctx.alloc(max(16, full_px * RECORD_BYTES))
+            self._exchanged = [[], []]
+        if hasattr(exchange, "register"):                          # collective, same order on every rank
+            for s in range(2):
+                exchange.register(self._exchanged[s])
+        self._used = [False, False]                                # set s has held an exchange's result (its re-use must be announced)
+
+    def _reuse(self, s: int):
+        """This rank is about to overwrite buffer set s: with an exchange whose peers write into this rank's buffers (DirectExchange) they
+        must not do so before everything enqueued so far -- the kernels that read the set's previous contents -- has run."""
+        if self._used[s] and hasattr(self.exchange, "release"):
+            self.exchange.release(self._exchanged[s])
+        self._used[s] = True
 
     class _WholeImage:
         def __init__(self, scanner):
@@ -272,6 +347,7 @@ class ShardedScanner:
         c, W, H = self.ctx, self.plan.W, self.plan.H
         self.flush()
         self.h_full, self.v_full = self._sets[0]
+        self._reuse(0)
         off = self.row0 * W * 2
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      self.h_full.at(off), self.v_full.at(off), eps=eps)
@@ -304,6 +380,7 @@ class ShardedScanner:
         c, W = self.ctx, self.plan.W
         s = self._submitted % 2
         h_full, v_full, xyz_full = self._sets[s]
+        self._reuse(s)
         px0 = self.row0 * W
         if self.rows:
             c.scan_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W, self.row0, self.proj_size,
@@ -359,6 +436,7 @@ class ShardedScanner:
         c, W = self.ctx, self.plan.W
         s = self._submitted % 2
         h_full, v_full = self._sets[s]
+        self._reuse(s)
         off = self.row0 * W * 2
         c.decode_dev(d_band_stack, n_runs, run_stride or self.N * plane_stride, plane_stride, self.N, self.rows, W,
                      h_full.at(off), v_full.at(off), eps=eps)

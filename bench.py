@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--exchange", default="maps", choices=["maps", "records", "xyz"],
                     help="multi-GPU reassembly: all-gather the int16 map bands and triangulate everywhere (default); all-gather maps + "
                          "float32 XYZ bands produced by the fused kernel on each band (xyz); or all-gatherv compacted 16-byte XYZ+key records")
+    ap.add_argument("--exchange-impl", default="rccl", choices=["rccl", "direct"],
+                    help="how the bands travel: rccl (default) = ncclAllGather / grouped ncclBroadcast; direct = every rank pushes its band straight into "
+                         "every peer's buffer over IPC mappings, all xGMI links at once (csrc/direct.hip; EXPERIMENTAL until timed on a node -- the one not "
+                         "chosen is timed after the counted region: sharded_alternatives)")
     ap.add_argument("--wire", default="auto", choices=["auto", "int16", "hv24"],
                     help="sharded 'maps' exchange: the int16 maps as they are (4 B/pixel) or packed to 3 B/pixel (codes of <= 11 bits); auto (default) = "
                          "packed when there is more than one rank and the codes fit -- a sharded scan is bound by its exchange (SURVEY.md 8(e)), a quarter "

@@ -327,6 +327,29 @@ int slgc_comm_allgatherv_pair_begin(slgc_ctx *ctx, const void *d_send_a, void *d
                                     const int64_t *counts, const int64_t *displs, int slot);
 int slgc_comm_wait(slgc_ctx *ctx, int slot);
 
+/* ------------------------------------------------------------------ multi-GPU, direct exchange (all xGMI links at once)
+ * The same exchange step without a ring: every rank pushes its band straight into every peer's full-size buffer (hipIpcMemHandle mappings),
+ * G-1 band copies per rank in flight together -- xGMI on MI355X is a point-to-point mesh, a ring all-gather is bound by one link.  No RCCL
+ * involved: set-up and flags go through one POSIX shared-memory segment named after `key` (the same string on every rank of the job, e.g.
+ * the launcher's port + pid; at most 16 ranks, one node).  The reference has no counterpart (single process).
+ *   slgc_direct_register       collective, same order on every rank: d_base = start of a slgc_dev_alloc buffer of `bytes` bytes (same size everywhere)
+ *   slgc_direct_allgatherv_begin  nbuf = 1..3 registered buffers that each hold this rank's band at displs[i][rank] (counts[i][r] / displs[i][r]:
+ *                              band layout of buffer i, int64 [nranks], bytes): enqueued on the exchange stream after the compute stream's work so
+ *                              far; afterwards every peer holds the band at the same place of ITS buffer.  slot 0..3 names the exchange for _wait.
+ *   slgc_direct_wait           compute stream waits until every peer's band of that exchange has arrived here
+ *   slgc_direct_release        compute stream: work enqueued so far is done with what the last exchange left in these buffers; peers may overwrite.
+ *                              Call it before re-using a buffer set (the first exchange on a buffer needs none).
+ *   slgc_direct_barrier / _allgather_i64   small host-side collectives over the segment (both streams drained first)
+ * A peer that never shows up costs a failed call (SLGC_ECOMM after a 20 s GPU-side / 120 s host-side timeout), never a hung GPU. */
+int slgc_direct_init(slgc_ctx *ctx, int rank, int nranks, const char *key);
+int slgc_direct_destroy(slgc_ctx *ctx);
+int slgc_direct_register(slgc_ctx *ctx, void *d_base, size_t bytes);
+int slgc_direct_allgatherv_begin(slgc_ctx *ctx, int nbuf, void *const *d_bases, const int64_t *const *counts, const int64_t *const *displs, int slot);
+int slgc_direct_wait(slgc_ctx *ctx, int slot);
+int slgc_direct_release(slgc_ctx *ctx, int nbuf, void *const *d_bases);
+int slgc_direct_barrier(slgc_ctx *ctx);
+int slgc_direct_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all);
+
 /* Row-band plan of the sharded scan: contiguous bands, the first H % nranks ranks get one extra
  * row.  Pure arithmetic, no context needed. */
 int slgc_shard_band(int H, int nranks, int rank, int *row0, int *rows);

@@ -161,6 +161,13 @@ CASES = [
     (2, "t_516x1031x44", ["--exchange", "xyz"]),                           # fused kernel per band, three in-place band exchanges
     (4, "t_516x1031x44", ["--exchange", "records"]),                       # count all-gather + all-gatherv of 16-byte records
     (5, "t_512x1024x44", ["--exchange", "xyz", "--no-overlap"]),           # more ranks than divide the rows evenly, one scan at a time
+    # the direct exchange (csrc/direct.hip): bands pushed into the peers' buffers through hipIpcMemHandle mappings, flags in a shared segment.
+    # IPC mappings work between processes on one GPU, so everything but the links themselves runs here: registration, gate / push / flag
+    # kernels, the release protocol under the pipelined submit / flush, ragged bands, three buffers per exchange
+    (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "int16", "--exchange-impl", "direct"]),
+    (3, "t_516x1031x44", ["--exchange", "maps", "--wire", "hv24", "--exchange-impl", "direct"]),
+    (2, "t_516x1031x44", ["--exchange", "xyz", "--exchange-impl", "direct"]),
+    (5, "t_512x1024x44", ["--exchange", "xyz", "--no-overlap", "--exchange-impl", "direct"]),
 ]
 
 
@@ -181,7 +188,9 @@ def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
 
 @pytest.mark.rccl_one_gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
-@pytest.mark.parametrize("nranks,extra", [(2, ["--exchange", "maps"]), (8, ["--exchange", "maps"]), (7, ["--exchange", "xyz"])], ids=["2-maps", "8-maps", "7-xyz-ragged"])
+@pytest.mark.parametrize("nranks,extra", [(2, ["--exchange", "maps"]), (8, ["--exchange", "maps"]), (7, ["--exchange", "xyz"]),
+                                          (8, ["--exchange", "maps", "--exchange-impl", "direct"]), (7, ["--exchange", "xyz", "--exchange-impl", "direct"])],
+                         ids=["2-maps", "8-maps", "7-xyz-ragged", "8-maps-direct", "7-xyz-ragged-direct"])
 def test_rccl_configs3_full_size_on_one_gpu_over_loopback(nranks, extra):
     """BASELINE.json configs[3] -- 4096x3000x44 row-sharded over 2 / 8 / (ragged) 7 ranks -- through the real RCCL exchange (loopback socket
     transport, all ranks on the one GPU), pipelined, self-verified bit for bit on every rank."""
@@ -228,4 +237,5 @@ def test_driver_launcher_two_ranks_on_one_gpu():
     alt = j["sharded_alternatives"]
     assert j["sharded"]["wire"] == "hv24"                                   # the default wire with more than one rank: 3 B/pixel
     assert alt["maps_int16"]["maps_equal_main_strategy_on_every_rank"] and alt["xyz"]["maps_equal_main_strategy_on_every_rank"], alt
+    assert alt["maps_hv24_direct"]["exchange_impl"] == "direct" and alt["maps_hv24_direct"]["maps_equal_main_strategy_on_every_rank"], alt
     assert j["throughput_mode"]["value"] > 0 and j["throughput_mode"]["scaling"] == "weak"

@@ -13,7 +13,7 @@ CONFIG_KEYS = ("workload", "pipeline", "scene_name", "rig", "executed_path", "va
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_mean", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_launch_ms",
                  "median_launch_ms", "max_launch_ms", "launches_timed", "outliers", "algorithmic_bytes_per_launch")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "c_oracle_value", "c_oracle_all_cores_value", "c_oracle_all_cores")
-SHARDED_KEYS = ("rccl_nranks", "exchange", "wire", "overlap", "with_exchange_value", "compute_only_value")
+SHARDED_KEYS = ("rccl_nranks", "exchange", "exchange_impl", "wire", "overlap", "with_exchange_value", "compute_only_value")
 
 
 def _cut(s, n):

@@ -135,8 +135,14 @@ def run_rank(args, rank, local_rank, world):
     count = ctx.alloc(16).zero()
     sharded_scanner = None
     if use_comm:                            # (sets slgc_tune "image_rows": the ray-table choice below is the whole image's)
-        sharded_scanner = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode,
-                                                 exchange_kind=args.exchange, wire=args.wire)
+        direct_key = "bench_" + (os.environ.get("SLGC_UID_KEY") or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+        if args.exchange_impl == "direct":
+            STAGE[0] = "direct exchange set-up (shared segment, IPC handles)"
+            exch = sharded.DirectExchange(ctx, rank, G, direct_key)
+        else:
+            exch = sharded.RcclExchange(ctx)
+        sharded_scanner = sharded.ShardedScanner(ctx, exch, plan, (proj_w, proj_h), N, mode=mode, exchange_kind=args.exchange, wire=args.wire)
+        STAGE[0] = "setup"
     elif args.image_rows > 0:               # band workloads (b2 / b4 / b8): time the band kernels as a rank of the sharded scan would run them
         ctx.tune("image_rows", args.image_rows)
     # per-calibration work, hoisted out of the scans and timed on its own: both undistortPoints calls evaluated into the two ray tables
@@ -610,11 +616,18 @@ def run_rank(args, rank, local_rank, world):
         main_digest = digest64(h_main, v_main)
         alternatives = {}
         other_wire = "int16" if sharded_scanner.wire == "hv24" else "hv24"           # whichever wire the main strategy did not use
-        for label, kind, wire in (("maps_" + other_wire, "maps", other_wire), ("xyz", "xyz", "int16")):
+        other_impl = "rccl" if args.exchange_impl == "direct" else "direct"                # ... and the exchange implementation it did not use
+        for label, kind, wire, impl in (("maps_" + other_wire, "maps", other_wire, args.exchange_impl), ("xyz", "xyz", "int16", args.exchange_impl),
+                                        (f"maps_{sharded_scanner.wire}_{other_impl}", "maps", sharded_scanner.wire, other_impl)):
             if wire == "hv24" and int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS:
                 continue
             try:
-                alt = sharded.ShardedScanner(ctx, sharded.RcclExchange(ctx), plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
+                STAGE[0] = f"sharded alternatives: {label}"
+                if impl == "direct":
+                    alt_exch = exch if args.exchange_impl == "direct" else sharded.DirectExchange(ctx, rank, G, direct_key + "_alt")
+                else:
+                    alt_exch = sharded.RcclExchange(ctx)
+                alt = sharded.ShardedScanner(ctx, alt_exch, plan, (proj_w, proj_h), N, mode=mode, exchange_kind=kind, wire=wire)
                 K = max(5, args.steps // 2)
                 for i in range(3):
                     alt.submit(stacks[i % len(stacks)].ptr, plane)
@@ -632,8 +645,8 @@ def run_rank(args, rank, local_rank, world):
                 alt.flush()
                 ha, va, _ = alt.fetch_dense()
                 same = ctx.comm_allgather_i64(1 if digest64(ha, va) == main_digest else 0)
-                alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K,
-                                       "bytes_per_pixel_on_the_links": {"maps_hv24": 3, "maps_int16": 4, "xyz": 16}[label],
+                alternatives[label] = {"value": round(cam_w * cam_h / 1e6 * K / el_alt, 1), "unit": "Mpixels/s", "steps": K, "exchange_impl": impl,
+                                       "bytes_per_pixel_on_the_links": 16 if kind == "xyz" else 3 if wire == "hv24" else 4,
                                        "maps_equal_main_strategy_on_every_rank": bool(all(same))}
                 del alt
             except Exception as e:  # noqa: BLE001

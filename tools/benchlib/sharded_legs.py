@@ -22,7 +22,7 @@ def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, c
         t_compute = ctx.comm_allreduce_max(t_compute)
     px = cam_w * cam_h
     per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
-    info = {"rccl_nranks": G, "exchange": args.exchange, "wire": scanner.wire if args.exchange == "maps" else None,
+    info = {"rccl_nranks": G, "exchange": args.exchange, "exchange_impl": args.exchange_impl, "wire": scanner.wire if args.exchange == "maps" else None,
             "overlap": not args.no_overlap and args.exchange != "records",
             "exchange_bytes_per_rank": {"sent": int(rows * cam_w * per_px), "received": int((px - rows * cam_w) * per_px)},
             "with_exchange_value": round(px / 1e6 * args.steps / elapsed, 1), "unit": "Mpixels/s"}
