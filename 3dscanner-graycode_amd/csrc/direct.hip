@@ -12,7 +12,8 @@
 //   * slgc_direct_allgatherv_begin on up to 3 registered buffers with one band layout (h + v maps, or + XYZ), on the exchange stream:
 //       gate kernel   waits until every peer has RELEASED the buffers (their previous contents were consumed there: slgc_direct_release),
 //       push kernel   copies the rank's band from its own buffer into the same place of every peer's buffer (16-byte lanes, one workgroup
-//                     per (peer, chunk): every link carries its band at the same time), __threadfence_system() behind the last store,
+//                     per (peer, chunk): every link carries its band at the same time; system-scope write-through stores, acknowledged
+//                     before the wave ends),
 //       flag kernel   writes the exchange's sequence number into arrived[peer][rank][buffer] of every peer;
 //   * slgc_direct_wait(slot), on the compute stream: a one-wave kernel polls arrived[rank][*][buffer] until every peer's band of that
 //     sequence number is in.  The kernels that read the bands start AFTER it ends: the acquire at their start is what makes remotely
@@ -155,7 +156,13 @@ struct PushArgs {
 };
 
 // grid = nbuf * npeers * chunks workgroups of 256 lanes; each moves a contiguous slice of one band to one peer, 16 bytes per lane and step.
-// Loads are ordinary (the band was just written by this GPU: L2 / Infinity Cache hits), stores go straight out over the link.
+// Loads are ordinary (the band was just written by this GPU: L2 / Infinity Cache hits).  Stores carry sc0 sc1 = system scope, write-through:
+// a peer's memory is mapped non-coherently cacheable (MTYPE_NC) on this GPU, so an ordinary store may sit in this GPU's L2 until some later
+// release -- written through, the bytes are at the peer when the store is acknowledged, and the wave waits for its acknowledgements before
+// it ends.  The flag kernel that follows on the stream then publishes data that is already there (no per-wave L2 write-back fence).
+typedef unsigned dv4u __attribute__((ext_vector_type(4)));
+constexpr int kSysWriteThrough = 17;           // cache-policy bits of the raw buffer intrinsics on gfx942 / gfx950: bit 0 = sc0, bit 4 = sc1
+
 __global__ void __launch_bounds__(256) k_push_bands(const PushArgs a)
 {
     uint32_t id = blockIdx.x;
@@ -164,27 +171,31 @@ __global__ void __launch_bounds__(256) k_push_bands(const PushArgs a)
     const int pi = (int)(id % (uint32_t)a.npeers), b = (int)(id / (uint32_t)a.npeers);
     const uint8_t *src = a.src[b];
     uint8_t *dst = a.dst[b][a.peer_rank[pi]];
-    const uint64_t n = a.bytes[b];
+    const uint64_t n = a.bytes[b];                 // < 2^32 (checked by the launcher)
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, (uint32_t)n, 0x00020000);
     // slices in whole 16-byte units; the bytes before the first aligned unit and after the last one go with chunk 0 (bands of the sharded
     // scan are multiples of the row length, so src and dst share their alignment)
     const uint64_t head = (16u - ((uintptr_t)src & 15u)) & 15u;
     const uint64_t h = head < n ? head : n;
     const uint64_t units = (n - h) / 16u, tail = (n - h) % 16u;
     if (chunk == 0 && threadIdx.x < 32) {
-        for (uint64_t i = threadIdx.x; i < h; i += 32) dst[i] = src[i];
-        for (uint64_t i = threadIdx.x; i < tail; i += 32) dst[h + units * 16u + i] = src[h + units * 16u + i];
+        for (uint64_t i = threadIdx.x; i < h; i += 32) __builtin_amdgcn_raw_buffer_store_b8(src[i], rd, (uint32_t)i, 0, kSysWriteThrough);
+        for (uint64_t i = threadIdx.x; i < tail; i += 32)
+            __builtin_amdgcn_raw_buffer_store_b8(src[h + units * 16u + i], rd, (uint32_t)(h + units * 16u + i), 0, kSysWriteThrough);
     }
     const uint64_t per = (units + a.chunks - 1) / a.chunks;
     const uint64_t u0 = (uint64_t)chunk * per, u1 = u0 + per < units ? u0 + per : units;
     const uint4 *s4 = reinterpret_cast<const uint4 *>(src + h);
-    uint4 *d4 = reinterpret_cast<uint4 *>(dst + h);
     if (((uintptr_t)(dst + h) & 15u) == 0) {
-        for (uint64_t u = u0 + threadIdx.x; u < u1; u += 256) d4[u] = s4[u];
+        for (uint64_t u = u0 + threadIdx.x; u < u1; u += 256) {
+            const uint4 q = s4[u];
+            __builtin_amdgcn_raw_buffer_store_b128(dv4u{q.x, q.y, q.z, q.w}, rd, (uint32_t)(h + u * 16u), 0, kSysWriteThrough);
+        }
     } else {                                    // differently aligned destination (not produced by the sharded scan): bytes
         for (uint64_t u = u0 + threadIdx.x; u < u1; u += 256)
-            for (int k = 0; k < 16; ++k) dst[h + u * 16u + k] = src[h + u * 16u + k];
+            for (uint32_t k = 0; k < 16; ++k) __builtin_amdgcn_raw_buffer_store_b8(src[h + u * 16u + k], rd, (uint32_t)(h + u * 16u + k), 0, kSysWriteThrough);
     }
-    __threadfence_system();                     // this lane's stores are complete at the peer before the kernel can end
+    __builtin_amdgcn_s_waitcnt(0);              // every store of this wave has been acknowledged by the peer's memory before the wave ends
 }
 
 int find_buf(Direct *d, const void *base)
@@ -379,6 +390,7 @@ extern "C" int slgc_direct_allgatherv_begin(slgc_ctx *ctx, int nbuf, void *const
         if (!counts[i] || !displs[i]) return slgc_fail(ctx, SLGC_EINVAL, "null layout");
         const int64_t c = counts[i][d->rank], o = displs[i][d->rank];
         if (c < 0 || o < 0 || (uint64_t)(o + c) > d->bytes[ids[i]]) return slgc_fail(ctx, SLGC_EINVAL, "band outside the registered buffer");
+        if ((uint64_t)c >= 0xfffffff0ull) return slgc_fail(ctx, SLGC_EINVAL, "a band of 4 GB or more");
         for (int j = 0; j < i; ++j)
             if (ids[j] == ids[i]) return slgc_fail(ctx, SLGC_EINVAL, "the same buffer twice in one exchange");
     }
