@@ -29,6 +29,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <new>
 
 #include "slgc_internal.h"
@@ -71,6 +72,7 @@ struct Direct {
     void *peer[kMaxBufs][kMaxRanks] = {{nullptr}};   // every rank's buffer b as mapped here (own entry = base)
     uint32_t seq[kMaxBufs] = {0};              // exchanges started on buffer b (same on every rank: the calls are collective)
     uint32_t want[4][kMaxBufs] = {{0}};        // slot -> sequence number to wait for per buffer (0 = buffer not part of the slot)
+    double timeout_s = kDirectTimeoutS;        // GPU-side polls give up after this (SLGC_DIRECT_TIMEOUT_S, tests)
     hipStream_t stream = nullptr;              // exchange stream
     hipEvent_t ev_compute = nullptr, ev_done[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -89,7 +91,7 @@ int need_direct(slgc_ctx *ctx)
     if (!ctx) return SLGC_EINVAL;
     if (!ctx->direct) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange not initialised (call slgc_direct_init)");
     const uint32_t e = state(ctx)->seg->error.load(std::memory_order_acquire);
-    if (e) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: a GPU-side wait on rank %u timed out after %.0f s (a peer is gone or stalled)", e - 1, kDirectTimeoutS);
+    if (e) return slgc_fail(ctx, SLGC_ECOMM, "direct exchange: a GPU-side wait on rank %u timed out after %.1f s (a peer is gone or stalled)", e - 1, state(ctx)->timeout_s);
     return SLGC_OK;
 }
 
@@ -217,7 +219,7 @@ void fill_common(FlagList &f, Direct *d)
 {
     f.error = reinterpret_cast<uint32_t *>(&d->dseg->error);
     f.who = (uint32_t)d->rank + 1u;
-    f.timeout_ticks = (unsigned long long)(kDirectTimeoutS * 1e8);
+    f.timeout_ticks = (unsigned long long)(d->timeout_s * 1e8);
 }
 
 }  // namespace
@@ -231,6 +233,10 @@ extern "C" int slgc_direct_init(slgc_ctx *ctx, int rank, int nranks, const char 
     if (!d) return SLGC_ENOMEM;
     d->rank = rank;
     d->nranks = nranks;
+    if (const char *t = getenv("SLGC_DIRECT_TIMEOUT_S")) {
+        const double v = atof(t);
+        if (v >= 0.05 && v <= 600.0) d->timeout_s = v;
+    }
     snprintf(d->name, sizeof d->name, "/slgc_direct_%.64s", key);
     for (char *c = d->name + 1; *c; ++c)
         if (*c == '/') *c = '_';
