@@ -167,7 +167,7 @@ struct TriScatter {
     const float2 *cam_lut;     // [H][W] exact camera rays
     CamNodes cn;               // every-4th-column nodes (cn.nodes == nullptr: read cam_lut)
     const float2 *proj_lut;      // projector rays (guarded redo)
-    const float2 *proj_cs;       // (cos(beta), sin(beta)) per projector pixel, same index (fast form)
+    const float *proj_th;        // tan(beta / 2) per projector pixel, same index (fast form)
     int ptiles_x, wide;
     int f32;                   // slgc_cloud32_dev: points and colours leave as float32 (12 instead of 24 bytes each per point) -- NOT the reference's dtypes
     TriF32 kf;
@@ -329,14 +329,14 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
     }
     // SRC == 2: the projector rays of this lane's CPH pixels are requested now, all in flight together (unconditional: an undecodable pixel
     // reads entry 0, unused) -- not one memory round trip per column inside the loop
-    float2 prj[TRI ? CPH : 1];
+    float prj[TRI ? CPH : 1];
     if constexpr (TRI) {
         static_assert(!TRI || (SPLIT == 1 && SPH == 1), "one segment per column and half-wave");
 #pragma unroll
         for (int j = 0; j < CPH; ++j) {
             const unsigned hv = s_hv[r][hw + 16 * j];
             const bool ok = hv != kInvalidHV;
-            prj[j] = ts.proj_cs[ok ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+            prj[j] = ts.proj_th[ok ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
         }
     }
 #pragma unroll
@@ -383,8 +383,8 @@ k_xmajor_scatter(const MapT *__restrict__ h, const MapT *__restrict__ v, int W, 
                         cxr = cr.x;
                         cyr = cr.y;
                     }
-                    const float2 pr = prj[j];
-                    const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
+                    const float pr = prj[j];
+                    const Xyzf r3 = triangulate1<true>(cxr, cyr, pr, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
                     if (!LISTS_ABL(2)) {
                         if (ts.f32) {                                                // (3,M) float32 (slgc_cloud32_dev)
                             float *p32 = reinterpret_cast<float *>(pts);
@@ -574,7 +574,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
     wave_lds_sync();                                               // every list is written and read by one wave only
     // (b) first pass of every column: whichever rows its records are, and their projector rays requested -- all CPH gathers in flight together
     int rowk[CPH];
-    float2 prj[CPH];
+    float prj[CPH];
 #pragma unroll
     for (int j = 0; j < CPH; ++j) {
         const int c = hw + 16 * j, k = (win[j] & 0xff) - 16 + r;
@@ -582,12 +582,12 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
         const int row = s_list[c][min(max(k, 0), TR - 1)];
         const unsigned hv = s_hv[row][c];
         rowk[j] = act ? row : -1;
-        prj[j] = ts.proj_cs[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+        prj[j] = ts.proj_th[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
     }
     // (c) one record per lane and pass
     char *const cam_b = reinterpret_cast<char *>(cam), *const proj_b = reinterpret_cast<char *>(proj), *const col_b = reinterpret_cast<char *>(colors);
     char *const p0_b = reinterpret_cast<char *>(pts), *const p1_b = reinterpret_cast<char *>(pts + M), *const p2_b = reinterpret_cast<char *>(pts + 2 * (size_t)M);
-    auto emit = [&](int c, int kp, int ka, int kb, int row, float2 pr) {
+    auto emit = [&](int c, int kp, int ka, int kb, int row, float pr) {
         const int x = x_tile + c;
         const unsigned B0 = s_b0[c];
         if (row >= 0) {
@@ -614,7 +614,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
                 *reinterpret_cast<float2 *>(cam_b + o8) = make_float2((float)x, (float)(y_tile + row));          // :59 [i, j] = (x, y)
                 *reinterpret_cast<float2 *>(proj_b + o8) = make_float2((float)pu, (float)pv);
             }
-            const Xyzf r3 = triangulate1<true>(cxr, cyr, pr.x, pr.y, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
+            const Xyzf r3 = triangulate1<true>(cxr, cyr, pr, ts.kf, ts.T, ts.t_len, ts.cam_lut + pix, ts.proj_lut + proj_lut_index(pu, pv, ts.ptiles_x, ts.wide));
             if (!LISTS_ABL(2)) {
                 if (ts.f32) {                                                                                   // (3,M) float32 (slgc_cloud32_dev): a group of 16 records = one 64-byte piece
                     const unsigned o4 = o8 >> 1;
@@ -655,7 +655,7 @@ k_xmajor_lines(const int16_t *__restrict__ h, const int16_t *__restrict__ v, int
             const bool act = k >= ka && k < kb;
             const int row = s_list[c][min(max(k, 0), TR - 1)];
             const unsigned hv = s_hv[row][c];
-            const float2 pr = ts.proj_cs[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
+            const float pr = ts.proj_th[act ? proj_lut_index((int)(short)(hv & 0xffffu), (int)(short)(hv >> 16), ts.ptiles_x, ts.wide) : 0u];
             emit(c, kp, ka, kb, act ? row : -1, pr);
         }
     }
@@ -934,7 +934,7 @@ int launch_cloud_tri(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, cons
     ts.cam_lut = (const float2 *)ctx->lut_cam;
     ts.cn = SLGC_CAM_NODES_FOR(ctx, cam_w, (size_t)cam_w * cam_h / 4 < (1u << 24));
     ts.proj_lut = (const float2 *)ctx->lut_proj;
-    ts.proj_cs = (const float2 *)ctx->lut_proj_cs;
+    ts.proj_th = (const float *)ctx->lut_proj_th;
     ts.ptiles_x = proj_tiles_x(ctx, proj_w);
     ts.wide = ctx->tune_proj_tile;
     ts.f32 = f32;

@@ -252,7 +252,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     const float2 *cam_lut;    // [npix] camera rays of this band
     CamNodes cn;              // the same rays at every 4th column (cn.nodes == nullptr: read cam_lut)
     const float2 *proj_lut;   // tiled projector rays (the guarded redo reads them)
-    const float2 *proj_cs;    // same index: (cos(beta), sin(beta)) per projector pixel -- what the fast form gathers
+    const float *proj_th;     // same index: tan(beta / 2) per projector pixel, 4 bytes -- what the fast form gathers
     float *xyz;               // [npix][3]
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads); bit 2: the maps are not stored at all
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         }
         s_idx[t] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
         sync();
-        float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
+        float *s_th = reinterpret_cast<float *>(s_buf);
         const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
         // four independent gathers in flight per lane: the loads are unconditional (an undecodable pixel reads entry 0, its ray is
         // never used), so no branch separates them and none waits for the one before
@@ -736,22 +736,22 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
-                s_ray[it * SPAN + t] = (i != 0xffffffffu) ? a.f.proj_cs[i] : make_float2(0.1f, 0.2f);
+                s_th[it * SPAN + t] = (i != 0xffffffffu) ? a.f.proj_th[i] : 0.5f;
             }
         } else {
-            float2 gr[4];
+            float gr[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
-                gr[it] = (ABL != 6) ? a.f.proj_cs[i != 0xffffffffu ? i : 0u] : make_float2(0.1f, 0.2f);
+                gr[it] = (ABL != 6) ? a.f.proj_th[i != 0xffffffffu ? i : 0u] : 0.5f;
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) s_ray[it * SPAN + t] = gr[it];
+            for (int it = 0; it < 4; ++it) s_th[it * SPAN + t] = gr[it];
         }
         sync();
-        const float4 r01 = s_buf[2 * t], r23 = s_buf[2 * t + 1];
+        const float4 t4 = s_buf[t];
         sync();
-        const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
+        const float pth[4] = {t4.x, t4.y, t4.z, t4.w};
         float out[12];
         const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                                (idx[3] != 0xffffffffu ? 8u : 0u);
@@ -761,8 +761,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
             if (live) cam_rays_exact_where_tiny(fx, fy, a.f.cam_lut + off);
         }
         uint32_t ill = 0;
-        if constexpr (GLIST) ill = triangulate4_flag(fx, fy, px, py, valid, a.f.kf, out);      // px / py hold the gathered (cos(beta), sin(beta))
-        else triangulate4<ABL != 8>(fx, fy, px, py, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
+        if constexpr (GLIST) ill = triangulate4_flag(fx, fy, pth, valid, a.f.kf, out);      // pth holds the gathered tan(beta / 2)
+        else triangulate4<ABL != 8>(fx, fy, pth, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
@@ -1140,7 +1140,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         b.lum.shift = (uint32_t)bgr_bits;
     }
     b.h = d_h; b.v = d_v; b.g = g; b.e = e;
-    b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.proj_cs = (const float2 *)ctx->lut_proj_cs; b.f.xyz = d_xyz;
+    b.f.cam_lut = (const float2 *)cam_lut; b.f.proj_lut = (const float2 *)proj_lut; b.f.proj_th = (const float *)ctx->lut_proj_th; b.f.xyz = d_xyz;
     const int lut_w = ctx->lut_cam_W;
     b.f.cn = SLGC_CAM_NODES_FOR(ctx, lut_w, cam_lut == ctx->lut_cam && npix4 / 4 < (1u << 24));
     b.f.proj_w = proj_w; b.f.proj_h = proj_h; b.f.tiles_x = proj_tiles_x(ctx, proj_w); b.f.wide = ctx->tune_proj_tile;

@@ -87,7 +87,7 @@ struct slgc_ctx {
     unsigned calib_ver;
     // ray tables (triangulate.hip), rebuilt when the calibration or the geometry changes
     void *lut_cam, *lut_proj;
-    void *lut_proj_cs;      // second half of the projector table's allocation: (cos(beta), sin(beta)) per projector pixel (tri_math.h fast form)
+    void *lut_proj_th;      // second part of the projector table's allocation: tan(beta / 2) per projector pixel, float32 (tri_math.h fast form)
     void *lut_nodes;        // camera rays at every 4th column (tri_math.h CamNodes), nullptr when not built / not accurate enough
     float lut_nodes_err;    // error measure of k_check_cam_nodes over the band -- or, with tune_image_rows, over the whole image (-1: not measured)
     int lut_image_rows;     // tune_image_rows the tables were built under

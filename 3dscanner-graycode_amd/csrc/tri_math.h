@@ -56,22 +56,29 @@ __device__ __forceinline__ Xyzf law_of_sines_mirror(Ray2 cam, Ray2 prj, const do
 // triangulate.py:86-95 with everything that depends on ONE ray only moved out of the per-pixel arithmetic.  With e = c / |c| the unit camera
 // ray (c = [cx, cy, 1]), t = T / |T|:
 //   cos(alpha) = -t.e      sin(alpha) = sqrt(1 - cos^2(alpha))      (alpha in (0, pi): the non-negative root, like arccos -> sin)
-//   cos(beta), sin(beta): per PROJECTOR PIXEL, evaluated once per calibration in float64 from the reference's float32 ray and float32 norm
-//                         (triangulate.py:92) and kept as float32 in the projector table the scan kernels gather from (ProjCs below)
+//   beta: per PROJECTOR PIXEL, evaluated once per calibration in float64 from the reference's float32 ray and float32 norm (triangulate.py:92)
+//         and kept as ONE float32 per projector pixel, th = tan(beta / 2), in the table the scan kernels gather from (proj_tan_half below):
+//             cos(beta) = (1 - th^2) / (1 + th^2)        sin(beta) = 2 th / (1 + th^2)            (beta in (0, pi): th in (0, inf))
 //   sin(gamma) = sin(alpha + beta) = sa cb + ca sb =: Dn             Pts = e * |T| sb / Dn                           (:93-95)
-// Per pixel that is one rsq, one sqrt, one rcp and ~20 multiply-adds; the flat-triangle test is three more (below).  (Rounds 1-3 formed
-// the same quantities un-normalised from cross products of T with both rays -- twice the arithmetic, and the projector's half of it
-// repeated for every camera pixel that sees the same projector pixel; at 1280x720 the fused kernel is bound by its vector ALU.)
+// The common factor 1 / (1 + th^2) cancels in sb / Dn: with om = 1 - th^2, op = 1 + th^2, nb = 2 th the kernels form Dn' = sa om + ca nb (= Dn op)
+// and Pts = e * |T| nb / Dn' -- no division by op anywhere, the flat test compares against op and op^2 instead.  Per pixel: one rsq, one sqrt,
+// one rcp and ~25 multiply-adds.  (Rounds 1-3 formed the same quantities un-normalised from cross products of T with both rays -- twice the
+// arithmetic; round 4 kept (cos(beta), sin(beta)) as 8 bytes per projector pixel: a gathered table entry drags a 128-byte line over the fabric,
+// and with 4-byte entries a line -- and the L2 -- holds twice as many projector pixels.  Counter traffic: NOTES.md round 5.)
 // Float32 suffices because no subtraction of nearly equal numbers is left except the one the geometry itself has, in Dn ~ sin(gamma):
 // sa comes from 1 - ca^2 with |ca| <= 0.6 for any camera ray a scanner uses (and a ray nearly parallel to the baseline is flagged flat).
 // On gfx950 float64 vector instructions issue at half rate, v_rcp_f64 / v_rsq_f64 at an eighth (tools/ubench/valu_rates.hip).
-// Error budget.  Each of cos(alpha), sin(alpha), cos(beta), sin(beta) carries an ABSOLUTE error <= ~4 * 2^-24 = 2.4e-7 from the
-// float32 arithmetic / the float32 table (+ 6e-8 from rounding T to float32): eps_f32 <= 3.0e-7; the reference's own float32 steps (NormedL: a
-// sqrt and three divisions -- the projector norm's rounding IS in the table) move ITS cos(alpha) by eps_ref <= 3 * 2^-24 = 1.8e-7, and
+// Error budget.  cos(alpha), sin(alpha) carry an ABSOLUTE error <= ~4 * 2^-24 = 2.4e-7 from the float32 arithmetic (+ 6e-8 from rounding T to
+// float32): eps_f32 <= 3.0e-7.  On the projector side the table's rounding of th (relative 2^-24) IS a perturbation of beta itself,
+// d beta = sin(beta) 2^-24, i.e. |d cos(beta)|, |d sin(beta)| <= 6e-8; th^2, 1 - th^2 and 2 th add at most 2 * 2^-24 relative to op = 1 + th^2
+// (1.2e-7 on the normalised cos(beta)); the division by op never happens.  So the projector side stays inside the same eps_f32 as before.  The
+// reference's own float32 steps (NormedL: a sqrt and three divisions -- the projector norm's rounding IS in the table) move ITS cos(alpha) by
+// eps_ref <= 3 * 2^-24 = 1.8e-7, and
 //   |d len / len| <= eps_ref * [1/sin^2 b + (1/sin a + 1/sin b)/sin g]  +  eps_f32 * [1/sin b + 4/sin g].
 // A pixel is "flat" when a term can pass kGuardAmp = 60 (sin^2 b < 1/60, or min(sin a, sin b) * |sin g| < 2/60 -- which also gives
 // |sin g| >= 1/30 for the pixels that pass):  2 * 60 * 1.8e-7 + 3.0e-7 * (7.8 + 120) = 2.2e-5 + 3.8e-5 = 6.0e-5 < 1e-4 even if every
-// rounding aligns.  Flat pixels are redone by law_of_sines_mirror (float64 on the reference's float32 intermediates).
+// rounding aligns.  Flat pixels are redone by law_of_sines_mirror (float64 on the reference's float32 intermediates).  th = inf or NaN
+// (beta = pi: the ray points back along the baseline) makes Dn' NaN: flagged flat like any other NaN.
 constexpr float kGuardAmp = 60.0f;
 
 struct TriF32 {               // per-launch constants of the fast form: T / |T| and |T|
@@ -83,21 +90,22 @@ __host__ __device__ inline TriF32 make_tri_f32(const double (&T)[3], double t_le
     return TriF32{(float)(T[0] / t_len), (float)(T[1] / t_len), (float)(T[2] / t_len), (float)t_len};
 }
 
-// What the projector table holds per pixel for the fast form: (cos(beta), sin(beta)) of the pixel's ray against the baseline.
-__host__ __device__ inline void proj_cos_sin(float px, float py, const double (&T)[3], double t_len, float &cb, float &sb)
+// What the projector table holds per pixel for the fast form: tan(beta / 2) of the pixel's ray against the baseline.
+__host__ __device__ inline float proj_tan_half(float px, float py, const double (&T)[3], double t_len)
 {
     const float qn = sqrtf((px * px + py * py) + 1.0f);                                                    // norm inside triangulate.py:92 (float32)
     const double c = ((T[0] * (double)px + T[1] * (double)py) + T[2]) / (t_len * (double)qn);             // :92
-    cb = (float)c;
-    sb = (float)sqrt(fmax(0.0, 1.0 - c * c));
+    const double s = sqrt(fmax(0.0, 1.0 - c * c));
+    return (float)(c >= 0.0 ? s / (1.0 + c) : (1.0 - c) / s);                                             // the well-conditioned form on each side
 }
 
 struct TriFastTerms {
     float ex, ey, ez;         // unit camera ray
-    float ca, sa, Dn;         // cos(alpha), sin(alpha), sin(gamma)
+    float ca, sa;             // cos(alpha), sin(alpha)
+    float nb, op, Dn;         // 2 th (= sin(beta) op), 1 + th^2, sin(gamma) op
 };
 
-__device__ __forceinline__ TriFastTerms tri_fast_terms(float cx, float cy, float cb, float sb, const TriF32 &k)
+__device__ __forceinline__ TriFastTerms tri_fast_terms(float cx, float cy, float th, const TriF32 &k)
 {
     TriFastTerms t;
     const float r = __builtin_amdgcn_rsqf(fmaf(cx, cx, fmaf(cy, cy, 1.0f)));      // v_rsq_f32 / v_sqrt_f32 / v_rcp_f32: 1 ulp, inside eps_f32
@@ -106,36 +114,39 @@ __device__ __forceinline__ TriFastTerms tri_fast_terms(float cx, float cy, float
     t.ez = r;
     t.ca = -fmaf(k.t0, t.ex, fmaf(k.t1, t.ey, k.t2 * t.ez));
     t.sa = __builtin_amdgcn_sqrtf(fmaf(-t.ca, t.ca, 1.0f));
-    t.Dn = fmaf(t.sa, cb, t.ca * sb);
+    t.nb = th + th;
+    t.op = fmaf(th, th, 1.0f);
+    t.Dn = fmaf(t.sa, fmaf(-th, th, 1.0f), t.ca * t.nb);
     return t;
 }
 
-// sin^2(beta) < 1/A_g,  or  min(sin a, sin b) * |sin g| < 2/A_g,  or a NaN anywhere
-__device__ __forceinline__ bool tri_flat(const TriFastTerms &t, float sb)
+// sin^2(beta) < 1/A_g,  or  min(sin a, sin b) * |sin g| < 2/A_g,  or a NaN anywhere -- on the un-normalised quantities (sb = nb / op, Dn = Dn' / op)
+__device__ __forceinline__ bool tri_flat(const TriFastTerms &t)
 {
-    return ((sb * sb) * kGuardAmp < 1.0f) | (fminf(t.sa, sb) * fabsf(t.Dn) < 2.0f / kGuardAmp) | !(t.Dn == t.Dn);
+    const float op2 = t.op * t.op;
+    return ((t.nb * t.nb) * kGuardAmp < op2) | (fminf(t.sa * t.op, t.nb) * fabsf(t.Dn) < (2.0f / kGuardAmp) * op2) | !(t.Dn == t.Dn);
 }
 
-__device__ __forceinline__ bool tri_is_flat(float cx, float cy, float cb, float sb, const TriF32 &k)
+__device__ __forceinline__ bool tri_is_flat(float cx, float cy, float th, const TriF32 &k)
 {
-    return tri_flat(tri_fast_terms(cx, cy, cb, sb, k), sb);
+    return tri_flat(tri_fast_terms(cx, cy, th, k));
 }
 
 // valid: bit j set = pixel j decodable; out = x0 y0 z0 x1 ... (NaN where not decodable).  GUARD = false: fast form everywhere (A/B).
-// cb / sb: the pixels' entries of the projector table's (cos, sin) half.  cam4 / proj_rays + idx: where the lane's exact float32 rays are --
+// th: the pixels' entries of the projector table's tan(beta / 2) half.  cam4 / proj_rays + idx: where the lane's exact float32 rays are --
 // the rare path reads them instead of keeping 16 registers alive.
 template <bool GUARD>
-__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&cb)[4], const float (&sb)[4],
+__device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (&cy)[4], const float (&th)[4],
                                                  uint32_t valid, const TriF32 &k, const double (&T)[3], double t_len, float (&out)[12],
                                                  const float2 *__restrict__ cam4, const float2 *__restrict__ proj_rays, const uint32_t (&idx)[4])
 {
     uint32_t ill = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], cb[j], sb[j], k);
+        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], th[j], k);
         const bool ok = (valid >> j) & 1u;
-        const float s = ok ? (k.tl * sb[j]) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
-        if (GUARD) ill |= tri_flat(t, sb[j]) ? (1u << j) : 0u;
+        const float s = ok ? (k.tl * t.nb) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
+        if (GUARD) ill |= tri_flat(t) ? (1u << j) : 0u;
         out[3 * j] = t.ex * s;
         out[3 * j + 1] = t.ey * s;
         out[3 * j + 2] = t.ez * s;
@@ -162,16 +173,16 @@ __device__ __forceinline__ void triangulate4(const float (&cx)[4], const float (
 // The fast pass alone: XYZ of the lane's four pixels by the float32 form, and which of them are flat (bit j of the result; decodable pixels
 // only).  The caller redoes the flagged pixels through law_of_sines_mirror -- the fused scan kernel compacts them over the WAVE first
 // (decode.hip), so a wave pays one pass per 64 flagged pixels instead of one pass per flagged position of its lanes.
-__device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], const float (&cy)[4], const float (&cb)[4], const float (&sb)[4],
+__device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], const float (&cy)[4], const float (&th)[4],
                                                       uint32_t valid, const TriF32 &k, float (&out)[12])
 {
     uint32_t ill = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], cb[j], sb[j], k);
+        const TriFastTerms t = tri_fast_terms(cx[j], cy[j], th[j], k);
         const bool ok = (valid >> j) & 1u;
-        const float s = ok ? (k.tl * sb[j]) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
-        ill |= tri_flat(t, sb[j]) ? (1u << j) : 0u;
+        const float s = ok ? (k.tl * t.nb) * __builtin_amdgcn_rcpf(t.Dn) : __builtin_nanf("");
+        ill |= tri_flat(t) ? (1u << j) : 0u;
         out[3 * j] = t.ex * s;
         out[3 * j + 1] = t.ey * s;
         out[3 * j + 2] = t.ez * s;
@@ -182,13 +193,13 @@ __device__ __forceinline__ uint32_t triangulate4_flag(const float (&cx)[4], cons
 // One pixel through the same arithmetic as triangulate4 (bit-identical results): the x-major scatter of slgc_cloud_dev triangulates a pixel where
 // it writes it.  cam_exact / proj_ray = this pixel's entries of the exact per-pixel camera table and of the projector RAY table (read only on the guarded path).
 template <bool GUARD>
-__device__ __forceinline__ Xyzf triangulate1(float cx, float cy, float cb, float sb, const TriF32 &k, const double (&T)[3], double t_len,
+__device__ __forceinline__ Xyzf triangulate1(float cx, float cy, float th, const TriF32 &k, const double (&T)[3], double t_len,
                                              const float2 *__restrict__ cam_exact, const float2 *__restrict__ proj_ray)
 {
-    const TriFastTerms t = tri_fast_terms(cx, cy, cb, sb, k);
-    const float s = (k.tl * sb) * __builtin_amdgcn_rcpf(t.Dn);
+    const TriFastTerms t = tri_fast_terms(cx, cy, th, k);
+    const float s = (k.tl * t.nb) * __builtin_amdgcn_rcpf(t.Dn);
     Xyzf r{t.ex * s, t.ey * s, t.ez * s};
-    if (GUARD && tri_flat(t, sb)) {
+    if (GUARD && tri_flat(t)) {
         const float2 cr = *cam_exact, pr = *proj_ray;
         r = law_of_sines_mirror(Ray2{cr.x, cr.y}, Ray2{pr.x, pr.y}, T, t_len);
     }

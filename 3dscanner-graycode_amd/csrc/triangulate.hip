@@ -254,9 +254,9 @@ __global__ void __launch_bounds__(256) k_check_cam_nodes_direct(const Calib c, i
     if ((threadIdx.x & 63) == 0 && __float_as_uint(err) > *reinterpret_cast<volatile unsigned *>(worst)) atomicMax(worst, __float_as_uint(err));
 }
 
-// Both halves of the projector table, same tiled index: lut = the float32 rays cv2.undistortPoints returns (exact kernels, the guarded redo),
-// lut_cs = (cos(beta), sin(beta)) of each ray against the baseline (tri_math.h: what the fast form gathers).
-__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, float2 *__restrict__ lut_cs, int proj_w, int proj_h, int tiles_x,
+// Both parts of the projector table, same tiled index: lut = the float32 rays cv2.undistortPoints returns (exact kernels, the guarded redo),
+// lut_th = tan(beta / 2) of each ray against the baseline, ONE float32 per projector pixel (tri_math.h: what the fast form gathers).
+__global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *__restrict__ lut, float *__restrict__ lut_th, int proj_w, int proj_h, int tiles_x,
                                                         size_t nslots, int wide)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -264,14 +264,15 @@ __global__ void __launch_bounds__(256) k_build_proj_lut(const Calib c, float2 *_
     const int sh = wide ? 7 : 6, tw = wide ? 16 : 8;                        // slots per tile = 8 rows x tw pixels (proj_lut_index)
     const int tile = (int)(p >> sh), in = (int)(p & ((1u << sh) - 1u));
     const int pu = (tile % tiles_x) * tw + (in & (tw - 1)), pv = (tile / tiles_x) * 8 + (in / tw);
-    float2 o = make_float2(0.f, 0.f), cs = make_float2(0.f, 1.f);
+    float2 o = make_float2(0.f, 0.f);
+    float th = 1.0f;
     if (pu < proj_w && pv < proj_h) {
         const Ray2 b = undistort_point((float)pu, (float)pv, c.proj_k, c.proj_d, nullptr);
         o = make_float2(b.x, b.y);
-        proj_cos_sin(b.x, b.y, c.T, c.t_len, cs.x, cs.y);
+        th = proj_tan_half(b.x, b.y, c.T, c.t_len);
     }
     lut[p] = o;
-    lut_cs[p] = cs;
+    lut_th[p] = th;
 }
 
 struct TriConst {
@@ -292,7 +293,7 @@ struct TriConst {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc, int16_t *__restrict__ h, int16_t *__restrict__ v,
                                                               const uint32_t *__restrict__ wire, const float2 *__restrict__ cam_lut,
-                                                              const float2 *__restrict__ proj_lut, const float2 *__restrict__ proj_cs, size_t ngroups, int proj_w,
+                                                              const float2 *__restrict__ proj_lut, const float *__restrict__ proj_th, size_t ngroups, int proj_w,
                                                               int proj_h, int tiles_x, float *__restrict__ xyz,
                                                               unsigned long long *__restrict__ count, uint32_t xcd_chunk, int nt_store, int wide,
                                                               const CamNodes cn)
@@ -334,20 +335,40 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     }
     s_idx[tid] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
     __syncthreads();
-    float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
     const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
-    float2 gr[4];           // four independent, unconditional gathers in flight per lane (an undecodable pixel reads entry 0, unused)
+    // four independent, unconditional gathers in flight per lane (an undecodable pixel reads entry 0, unused).  Exact mode: the float32 rays
+    // (8 bytes each); fast form: tan(beta / 2) of each ray against the baseline (4 bytes each)
+    float px[4], py[4];
+    if constexpr (MODE == SLGC_TRI_EXACT) {
+        float2 *s_ray = reinterpret_cast<float2 *>(s_buf);
+        float2 gr[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const uint32_t i = s_idx1[it * 256 + tid];
-        gr[it] = (MODE == SLGC_TRI_EXACT ? proj_lut : proj_cs)[i != 0xffffffffu ? i : 0u];      // exact mode: the rays; fast form: their (cos, sin) against the baseline
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = s_idx1[it * 256 + tid];
+            gr[it] = proj_lut[i != 0xffffffffu ? i : 0u];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) s_ray[it * 256 + tid] = gr[it];
+        __syncthreads();
+        const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
+        px[0] = r01.x, px[1] = r01.z, px[2] = r23.x, px[3] = r23.z;
+        py[0] = r01.y, py[1] = r01.w, py[2] = r23.y, py[3] = r23.w;
+    } else {
+        float *s_th = reinterpret_cast<float *>(s_buf);
+        float gt[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t i = s_idx1[it * 256 + tid];
+            gt[it] = proj_th[i != 0xffffffffu ? i : 0u];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) s_th[it * 256 + tid] = gt[it];
+        __syncthreads();
+        const float4 t4 = s_buf[tid];
+        px[0] = t4.x, px[1] = t4.y, px[2] = t4.z, px[3] = t4.w;
+        py[0] = py[1] = py[2] = py[3] = 0.f;
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) s_ray[it * 256 + tid] = gr[it];
     __syncthreads();
-    const float4 r01 = s_buf[2 * tid], r23 = s_buf[2 * tid + 1];
-    __syncthreads();
-    const float px[4] = {r01.x, r01.z, r23.x, r23.z}, py[4] = {r01.y, r01.w, r23.y, r23.w};
     float out[12];
     const uint32_t valid = (idx[0] != 0xffffffffu ? 1u : 0u) | (idx[1] != 0xffffffffu ? 2u : 0u) | (idx[2] != 0xffffffffu ? 4u : 0u) |
                            (idx[3] != 0xffffffffu ? 8u : 0u);
@@ -370,7 +391,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
     }
     uint32_t ill = 0;
     if constexpr (MODE != SLGC_TRI_EXACT) {
-        ill = triangulate4_flag(cx, cy, px, py, valid, tc.kf, out);      // px / py hold the gathered (cos(beta), sin(beta))
+        ill = triangulate4_flag(cx, cy, px, valid, tc.kf, out);          // px holds the gathered tan(beta / 2)
         if (MODE == 2) ill = 0;                                          // MODE 2: unguarded (A/B, diagnostic build)
     }
     s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
@@ -460,7 +481,7 @@ __global__ void __launch_bounds__(256) k_undistort_list(const Calib c, int which
 // Diagnostic: how many decodable pixels of a band take the guarded (float32-mirror) path of triangulate4 -- the same
 // tri_is_flat test on the same table rays.  counts[0] += decodable pixels, counts[1] += flagged pixels.
 __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const int16_t *__restrict__ h, const int16_t *__restrict__ v,
-                                                     const float2 *__restrict__ cam_lut, const float2 *__restrict__ proj_cs, size_t npix,
+                                                     const float2 *__restrict__ cam_lut, const float *__restrict__ proj_th, size_t npix,
                                                      int proj_w, int proj_h, int tiles_x, int wide, unsigned long long *__restrict__ counts)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -469,8 +490,9 @@ __global__ void __launch_bounds__(256) k_guard_count(const TriConst tc, const in
         const int hv = h[p], vv = v[p];
         if (!(hv == -1 || vv == -1)) {
             ok = 1;
-            const float2 c = cam_lut[p], q = proj_cs[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
-            flat = tri_is_flat(c.x, c.y, q.x, q.y, tc.kf) ? 1u : 0u;
+            const float2 c = cam_lut[p];
+            const float q = proj_th[proj_lut_index(min(proj_w - 1, hv), min(proj_h - 1, vv), tiles_x, wide)];
+            flat = tri_is_flat(c.x, c.y, q, tc.kf) ? 1u : 0u;
         }
     }
     unsigned packed = ok | (flat << 16);                       // 64 lanes: both sums fit 16 bits
@@ -503,7 +525,7 @@ int launch_guard_count(slgc_ctx *ctx, const int16_t *d_h, const int16_t *d_v, in
     tc.t_len = ctx->calib.t_len;
     tc.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     hipLaunchKernelGGL(k_guard_count, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, tc, d_h, d_v, (const float2 *)ctx->lut_cam,
-                       (const float2 *)ctx->lut_proj_cs, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
+                       (const float *)ctx->lut_proj_th, npix, proj_w, proj_h, proj_tiles_x(ctx, proj_w), ctx->tune_proj_tile, d_counts);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }
@@ -603,16 +625,16 @@ int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h
             (void)hipFree(ctx->lut_proj);
             ctx->lut_proj = nullptr;
         }
-        void *proj = nullptr;                                  // one allocation: [rays | (cos, sin)], nproj entries each (nproj is a multiple of 64)
-        if (hipMalloc(&proj, 2 * nproj * sizeof(float2) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
-        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)proj, (float2 *)proj + nproj, proj_w,
+        void *proj = nullptr;                                  // one allocation: [rays (float2) | tan(beta / 2) (float)], nproj entries each (nproj is a multiple of 64)
+        if (hipMalloc(&proj, nproj * (sizeof(float2) + sizeof(float)) + 64) != hipSuccess) return slgc_fail(ctx, SLGC_ENOMEM, "projector ray table");
+        hipLaunchKernelGGL(k_build_proj_lut, dim3((unsigned)((nproj + 255) / 256)), dim3(256), 0, ctx->stream, ctx->calib, (float2 *)proj, (float *)((float2 *)proj + nproj), proj_w,
                            proj_h, tiles_x, nproj, wide);
         if (hipGetLastError() != hipSuccess) {
             (void)hipFree(proj);
             return slgc_fail(ctx, SLGC_EHIP, "projector ray table build failed to launch");
         }
         ctx->lut_proj = proj;
-        ctx->lut_proj_cs = (float2 *)proj + nproj;
+        ctx->lut_proj_th = (float2 *)proj + nproj;
         ctx->lut_proj_ver = ctx->calib_ver; ctx->lut_proj_w = proj_w; ctx->lut_proj_h = proj_h; ctx->lut_proj_tile = wide;
     }
     return SLGC_OK;
@@ -673,15 +695,15 @@ static int launch_triangulate_maps_body(slgc_ctx *ctx, const int16_t *d_h_in, co
         ctx->last_guard = mode == SLGC_TRI_EXACT ? 0 : 1;
         if (mode == SLGC_TRI_EXACT)
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_EXACT>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float *)ctx->lut_proj_th, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #ifdef SLGC_DIAG      // A/B of the guard's cost: only in the diagnostic build
         else if (xcd_env("SLGC_TRI_UNGUARDED", 0))
             hipLaunchKernelGGL(k_triangulate_maps_lds<2>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float *)ctx->lut_proj_th, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
 #endif
         else
             hipLaunchKernelGGL(k_triangulate_maps_lds<SLGC_TRI_ALGEBRAIC>, dim3(blocks), dim3(256), 0, ctx->stream, tc, d_h, d_v, d_wire32,
-                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float2 *)ctx->lut_proj_cs, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
+                               (const float2 *)ctx->lut_cam, (const float2 *)ctx->lut_proj, (const float *)ctx->lut_proj_th, groups, proj_w, proj_h, proj_tiles_x(ctx, proj_w), d_xyz, d_count, xcd_chunk_for(ctx, blocks), tri_nt, ctx->tune_proj_tile, cn);
         HIP_TRY(ctx, hipGetLastError());
         const size_t done = groups * 4;
         if (done == npix) return SLGC_OK;
