@@ -268,15 +268,34 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
 #endif
 };
 
+// Everything in k_decode_pk that is NOT the product, named in one place.  Diag<0> is the shipped kernel: every flag below is false and every
+// `if constexpr (D::...)` folds away; the timing-only ablations (diagnostic build `make diag`, results wrong on purpose unless noted) and the
+// stamp build (make variant NAME=stamps EXTRA=-DSLGC_STAMPS; tools/time_stamps.py) are the other instantiations.
+template <int ABL>
+struct Diag {
+    static constexpr bool product = ABL == 0;
+    static constexpr bool skip_threshold_frames = ABL == 1 || ABL == 2;   // the 14 threshold-frame loads and the thresholds are replaced by constants
+    static constexpr bool loads_only = ABL == 2;                          // frames are fetched, nothing is classified
+    static constexpr bool cheap_thresholds = ABL == 3;                    // integer stand-in for the float64 threshold arithmetic
+    static constexpr bool stores_never = ABL == 5;                        // XYZ stores behind a condition that is never true
+    static constexpr bool no_gather = ABL == 6;                           // projector-table gathers replaced by a constant
+    static constexpr bool cam_rays_cached = ABL == 7;                     // every lane reads the same 2 KB of the camera table
+    static constexpr bool unguarded = ABL == 8;                           // no flat-triangle redo
+    static constexpr bool branchy_gather = ABL == 9;                      // round 1's gather form (correct results): a branch around every gather
+};
+
+// stamp i of the wave (stamp build only; compiles to nothing otherwise): 0 wave started, 1 thresholds computed, 2 every frame consumed,
+// 3 tail done and stores issued, 4 stores acknowledged
+template <int FUSE, int BLOCK, typename Args>
+__device__ __forceinline__ void stamp(const Args &a, int i)
+{
 #ifdef SLGC_STAMPS
-#define SLGC_STAMP(i)                                                                                                              \
-    do {                                                                                                                           \
-        if (FUSE != 0 && a.f.stamps && (threadIdx.x & 63) == 0)                                                                    \
-            a.f.stamps[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 5 + (i)] = __builtin_amdgcn_s_memrealtime();     \
-    } while (0)
+    if (FUSE != 0 && a.f.stamps && (threadIdx.x & 63) == 0)
+        a.f.stamps[((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 5 + i] = __builtin_amdgcn_s_memrealtime();
 #else
-#define SLGC_STAMP(i) do { } while (0)
+    (void)a; (void)i;
 #endif
+}
 
 // cv2.cvtColor(BGR2GRAY) on 8-bit pixels inside the frame load (src/3-capture_decode.py:66): Y = (B*BY + G*GY + R*RY + rnd) >> shift.
 // A lane's 4 pixels arrive as 12 bytes B0 G0 R0 B1 G1 R1 B2 G2 R2 B3 G3 R3 in three dwords; pixel 0 IS dword 0 with a zero coefficient for
@@ -434,8 +453,7 @@ constexpr int kWaveLdsBytes = 4096;     // LDS block of one wave: fused tail [in
 constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pixels (one byte each), behind the blocks of all waves -- inside the same
                                         // 1280-byte LDS allocation granule of gfx950 as the two 4 KB blocks (8704 -> 8960 B, as 8192 is): no wave less per CU
 
-// ABL (timing-only diagnostic builds, results are wrong): 0 = real kernel; 1 = skip the 14 threshold-frame loads;
-// 2 = loads only (no classification arithmetic).
+// ABL: 0 = the product; anything else selects a timing-only ablation, see Diag<ABL> above (diagnostic build only).
 // NS > 0: specialised for NS frames per run (compile-time frame indices, bit loop fully unrolled) -- the 12 frames that feed the
 // per-pixel thresholds are parked in lane-private LDS words after their first use, so the bit loop reads them from LDS instead of
 // fetching them a second time (the re-reads are L2 hits, but each still costs a vector-memory instruction and its L2 -> CU trip:
@@ -451,6 +469,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
     static_assert(!BGR || (NS > 0 && NW == 1), "the BGR kernels are the specialised ones");
     constexpr int NP = PX / 2;      // pixel-pair registers per lane
     constexpr bool SPEC = NS > 0;
+    using D = Diag<ABL>;
     using FS = FrameSpec<SPEC ? NS : 14>;
     static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * (kWaveLdsBytes + (FUSE == 3 ? kWaveListBytes : 0)) : 16];
@@ -463,7 +482,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
             bid -= scan * a.f.batch_bps;
         }
     }
-    SLGC_STAMP(0);                                   // wave started
+    stamp<FUSE, BLOCK>(a, 0);
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t voff = BGR ? 3u * off : off;      // byte offset of the lane's pixels inside a plane
     const uint32_t ps = a.plane_stride;
@@ -498,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
             const int f_hn = 2 + 2 * (FS::L - 1 - t), f_vn = 3 + 2 * t;
             fr[0] = fetch(f_hn); fr[1] = fetch(f_hn + 2 * FS::L); fr[2] = fetch(f_vn); fr[3] = fetch(f_vn + 2 * FS::L);
         };
-        if constexpr (ABL == 1 || ABL == 2) {
+        if constexpr (D::skip_threshold_frames) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) { KA[p] = 0x7fb07fb0u + off; KB[p] = 0x7fd07fd0u; C1[p] = 0x00020002u; C2[p] = 0x00010001u; }
         } else {
@@ -565,7 +584,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
                     const int lmax = (int)((j & 2) ? (mxp >> 16) : (mxp & 0xffffu));
                     const int lmin = (int)((j & 2) ? (mnp >> 16) : (mnp & 0xffffu));
                     const int black = (int)((bl.w[q] >> (8 * j)) & 0xffu), white = (int)((wh.w[q] >> (8 * j)) & 0xffu);
-                    if constexpr (ABL == 3) { tt[j] = ((lmax - lmin) & 0xff) | ((black + white) << 15 & 0xff0000); cc[j] = a.e + 1; }
+                    if constexpr (D::cheap_thresholds) { tt[j] = ((lmax - lmin) & 0xff) | ((black + white) << 15 & 0xff0000); cc[j] = a.e + 1; }
                     else pixel_thresholds(black, white, lmax, lmin, a.e, tt[j], cc[j]);
                 }
                 // pair registers: even = pixels (0, 2), odd = pixels (1, 3) of this dword
@@ -579,14 +598,14 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         uint32_t aB_h[NP], aB_v[NP], aV_h[NP], aV_v[NP];
 #ifdef SLGC_STAMPS
         asm volatile("" : "+v"(KA[0]), "+v"(KB[0]), "+v"(C1[0]), "+v"(C2[0]));      // the thresholds exist
-        SLGC_STAMP(1);                                   // threshold frames arrived, thresholds computed
 #endif
+        stamp<FUSE, BLOCK>(a, 1);
 #pragma unroll
         for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
         // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
         auto step = [&](const Frame<NW, NT> &hn, const Frame<NW, NT> &hi, const Frame<NW, NT> &vn, const Frame<NW, NT> &vi, uint32_t t) {
             const uint32_t sh = 15u - t, mk = 0x00010001u << t;
-            if constexpr (ABL == 2) {
+            if constexpr (D::loads_only) {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) { aB_h[2 * q] ^= hn.w[q] + hi.w[q]; aB_v[2 * q] ^= vn.w[q] + vi.w[q]; }
             } else {
@@ -634,8 +653,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
 
 #ifdef SLGC_STAMPS
     asm volatile("" : "+v"(mB_h[0]), "+v"(mB_v[0]), "+v"(mV_h[0]), "+v"(mV_v[0]));
-    SLGC_STAMP(2);                                       // every frame consumed
 #endif
+    stamp<FUSE, BLOCK>(a, 2);
     // accumulators hold the L code bits in bits 0 .. L-1 of each half
     const uint32_t full = ((1u << L) - 1u) * 0x00010001u;
     uint32_t oh[NP], ov[NP];
@@ -691,7 +710,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         // FUSE == 3 (default): flat triangles are compacted over the wave before they are redone (below); FUSE == 2: redone lane by lane (A/B).
         static_assert(FUSE == 0 || NW == 1, "fused tail is written for 4 pixels per lane");
         constexpr bool WAVE = FUSE >= 2;
-        constexpr bool GLIST = FUSE == 3 && ABL == 0;
+        constexpr bool GLIST = FUSE == 3 && D::product;
         constexpr int SPAN = WAVE ? 64 : BLOCK;                     // lanes that exchange with each other
         const int tid = threadIdx.x;
         const int t = WAVE ? (tid & 63) : tid;                      // index inside the exchanging group
@@ -715,7 +734,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
                 c01 = make_float4(n01.x, n01.y, n01.z, n01.w);
                 c23 = make_float4(n23.x, n23.y, n23.z, n23.w);
             } else {
-                const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (ABL == 7 ? (off & 255u) : off));
+                const float4 *cl = reinterpret_cast<const float4 *>(a.f.cam_lut + (D::cam_rays_cached ? (off & 255u) : off));
                 c01 = cl[0];
                 c23 = cl[1];
             }
@@ -732,7 +751,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         const uint32_t *s_idx1 = reinterpret_cast<const uint32_t *>(s_idx);
         // four independent gathers in flight per lane: the loads are unconditional (an undecodable pixel reads entry 0, its ray is
         // never used), so no branch separates them and none waits for the one before
-        if constexpr (ABL == 9) {        // A/B (diagnostic build, correct results): the round-1 form, a branch around every gather
+        if constexpr (D::branchy_gather) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
@@ -743,7 +762,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t i = s_idx1[it * SPAN + t];
-                gr[it] = (ABL != 6) ? a.f.proj_th[i != 0xffffffffu ? i : 0u] : 0.5f;
+                gr[it] = D::no_gather ? 0.5f : a.f.proj_th[i != 0xffffffffu ? i : 0u];
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) s_th[it * SPAN + t] = gr[it];
@@ -762,7 +781,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         }
         uint32_t ill = 0;
         if constexpr (GLIST) ill = triangulate4_flag(fx, fy, pth, valid, a.f.kf, out);      // pth holds the gathered tan(beta / 2)
-        else triangulate4<ABL != 8>(fx, fy, pth, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);   // ABL 8: unguarded (A/B)
+        else triangulate4<!D::unguarded>(fx, fy, pth, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
         s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
         s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
         s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
@@ -815,7 +834,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         float4 *dst = reinterpret_cast<float4 *>(a.f.xyz + (size_t)scan * a.npix * 3) + (size_t)first * 3;
 #pragma unroll
         for (int it = 0; it < 3; ++it)
-            if ((uint32_t)(it * SPAN + t) < nvec && (ABL != 5 || s_buf[it * SPAN + t].x == 12345.678f)) {
+            if ((uint32_t)(it * SPAN + t) < nvec && (!D::stores_never || s_buf[it * SPAN + t].x == 12345.678f)) {
                 if (a.f.nt_store & 1) {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const float4 q = s_buf[it * SPAN + t];
@@ -824,11 +843,11 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
                     dst[it * SPAN + t] = s_buf[it * SPAN + t];
                 }
             }
+        stamp<FUSE, BLOCK>(a, 3);
 #ifdef SLGC_STAMPS
-        SLGC_STAMP(3);                                   // tail done, stores issued
-        __builtin_amdgcn_s_waitcnt(0);                   // ... and acknowledged
-        SLGC_STAMP(4);
+        __builtin_amdgcn_s_waitcnt(0);                   // (stamp 4 = the stores are acknowledged)
 #endif
+        stamp<FUSE, BLOCK>(a, 4);
     }
 }
 

@@ -488,6 +488,8 @@ def run_rank(args, rank, local_rank, world):
             x_el, x_kms, x_kn, _, x_samples = xyz_only
             xr = kernel_roofline("fused" if xyz_only_executed["path"] == "fused" else "split", x_kms, x_kn, x_samples, xyz_only_executed)
             xr.pop("frac_incl_maps", None), xr.pop("frac_incl_maps_note", None)
+            xr["bound_note"] = ("N bytes read + 12 written per pixel: a read-dominated stream (bound \"hbm\"); the store-bound stage of this library is "
+                                "the x-major list build -- reference_product.list_stage_roofline carries bound \"hbm-write\" and the write ceiling measured in-run")
             xr["traffic"] = None                              # the committed counters are of the kernel that also stores the maps
             xr.pop("traffic_source", None), xr.pop("traffic_scene", None)
             if movement is not None and xyz_only_executed["path"] == "fused":
