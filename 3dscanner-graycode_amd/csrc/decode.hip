@@ -392,31 +392,29 @@ __device__ __forceinline__ uint32_t and_or_full_rate(uint32_t a, uint32_t b, uin
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA);
 }
 
-// One (normal, inverse) pair register through the rule table: bit 15 / bit 31 of `bit` = the code bit, of `ok` = "classified".
-__device__ __forceinline__ void classify_bits(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t K1, uint32_t K2, uint32_t &bit, uint32_t &ok)
-{
-    const uint32_t Na = N + KA, Nb = N + KB, Ia = I + KA, Ib = I + KB;
-    const uint32_t D = N - I;
-    const uint32_t R1 = D + K1, R2 = D + K2;
-    // five v_bitop3_b32 (truth-table index = a << 2 | b << 1 | c), spelled out: left to itself the compiler closes these expressions
-    // with v_and_or_b32 / v_or3_b32, which issue at half rate
-    const uint32_t r4 = __builtin_amdgcn_bitop3_b32(Nb, Ia, Nb, 0x30);         // Nb & ~Ia
-    const uint32_t n3 = __builtin_amdgcn_bitop3_b32(Na, Ib, Na, 0xF3);         // Na | ~Ib            = ~r3
-    bit = __builtin_amdgcn_bitop3_b32(R1, n3, r4, 0xEA);                       // (R1 & ~r3) | r4
-    const uint32_t r23 = __builtin_amdgcn_bitop3_b32(Na, Ib, R2, 0x5D);        // (~Na & Ib) | ~R2    = r3 | r2
-    ok = __builtin_amdgcn_bitop3_b32(R1, r23, r4, 0xFE);                       // r1 | r2 | r3 | r4
-}
-
-// ... and into the accumulators: step t deposits at bit t of each half (shift = 15 - t, mask = 0x00010001 << t).
+// One (normal, inverse) pair register through the rule table and into the accumulators: bit 15 / bit 31 of every intermediate = the
+// pixel's answer; step t deposits its code bit at bit t of each half (shift = 15 - t, mask = 0x00010001 << t).
+// v_bitop3_b32 throughout (truth-table index = a << 2 | b << 1 | c), spelled out: left to itself the compiler closes these expressions
+// with v_and_or_b32 / v_or3_b32, which issue at half rate.  Single run (MULTI = false): "classified" is folded straight into the running
+// AND -- accV & (u1 | u2) is one three-input op, so the pair costs 7 additions + 5 boolean ops + 2 for the deposit (round 4: 15).
 template <bool MULTI>
 __device__ __forceinline__ void classify_pk(uint32_t N, uint32_t I, uint32_t KA, uint32_t KB, uint32_t K1, uint32_t K2,
                                             uint32_t &accB, uint32_t &accV, uint32_t shift, uint32_t mask)
 {
-    uint32_t bit, ok;
-    classify_bits(N, I, KA, KB, K1, K2, bit, ok);
+    const uint32_t Na = N + KA, Nb = N + KB, Ia = I + KA, Ib = I + KB;
+    const uint32_t D = N - I;
+    const uint32_t R1 = D + K1, R2 = D + K2;
+    const uint32_t t1 = __builtin_amdgcn_bitop3_b32(R1, Na, Ib, 0xD0);         // R1 & (Na | ~Ib)              = r1 & ~r3
+    const uint32_t bit = __builtin_amdgcn_bitop3_b32(Nb, Ia, t1, 0xBA);        // (Nb & ~Ia) | t1              = r4 | (r1 & ~r3)
+    const uint32_t u1 = __builtin_amdgcn_bitop3_b32(Na, Ib, R2, 0x5D);         // (~Na & Ib) | ~R2             = r3 | r2
+    const uint32_t u2 = __builtin_amdgcn_bitop3_b32(Nb, Ia, R1, 0xBA);         // (Nb & ~Ia) | R1              = r4 | r1
     accB = and_or_full_rate(bit >> shift, mask, accB);
-    if constexpr (MULTI) accV = and_or_full_rate(ok >> shift, mask, accV);
-    else accV &= ok;
+    if constexpr (MULTI) {
+        const uint32_t ok = u1 | u2;                                           // r1 | r2 | r3 | r4
+        accV = and_or_full_rate(ok >> shift, mask, accV);
+    } else {
+        accV = __builtin_amdgcn_bitop3_b32(accV, u1, u2, 0xE0);                // accV & (u1 | u2)
+    }
 }
 
 // Compile-time twin of slgc_make_geom (decode_codes.py:109-111, :149) for the frame counts the generator and BASELINE.json use:
