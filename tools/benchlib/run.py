@@ -249,6 +249,16 @@ def run_rank(args, rank, local_rank, world):
                 o_valid, o_flag = scene_stats(st)
                 o_dec, o_dec_exec = time_decode(st)
                 scene_legs[name] = [o_el, o_kms, o_kn, o_samples, o_exec, o_valid, o_flag, None, o_dec, o_dec_exec]
+    # The same step with EVERY launch bracketed by its event pair.  A bracketed launch is fenced off from its neighbours (the step grows by the
+    # ~5 us the pairs cost), an unbracketed one starts in the drain of the launch before it: at 4096x3000 the two agree, a 25 us kernel
+    # (1920x1080) measures 23.2 us fenced and 24.9 us back to back on the same box (tools/jobs/r5_c2_conditions.sh).  roofline.frac stays the
+    # timed region's; this is the kernel by itself.
+    isolated = None
+    if extras:
+        with leg("isolated launches"):
+            use_rig(SCENES[args.scene]["rig"])
+            i_el, i_kms, i_kn, _, i_samples = timed(min(40, max(10, args.steps)), W_leg, stride=1, preheat=False)
+            isolated = (i_kms, i_kn, i_samples, ctx.last_scan_path())
     head_dec = None
     if extras:
         with leg("decode kernel alone"):
@@ -463,6 +473,13 @@ def run_rank(args, rank, local_rank, world):
             "device": ctx.device_name(),
             "pmc": {"requested": getattr(args, "pmc", "off"), "result": getattr(args, "pmc_note", None)},
         }
+        if isolated is not None and isolated[3]["path"] in ("fused", "split"):
+            ir = kernel_roofline("fused" if isolated[3]["path"] == "fused" else "split", isolated[0], isolated[1], isolated[2], isolated[3])
+            out["roofline"]["isolated_frac"] = ir["frac"]
+            out["roofline"]["isolated"] = {"frac": ir["frac"], "frac_mean": ir["frac_mean"], "median_launch_ms": ir.get("median_launch_ms"), "avg_launch_ms": ir["avg_launch_ms"],
+                                           "launches_timed": ir["launches_timed"], "outliers": ir.get("outliers"),
+                                           "note": "the same step right after the timed region with every launch bracketed by its HIP-event pair (fenced off from its "
+                                                   "neighbours); `frac` above is the timed region's own launches, every event_stride-th bracketed, the rest back to back"}
         if shard_info:
             out["sharded"] = shard_info
         if verify is not None:

@@ -70,12 +70,24 @@ for key, k in (("c3_4096x3000x44/g1/split/s-scene", kernel_key(False)), ("c3_409
               "csrc_fingerprint": fp, "source": note}
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{tag}_bench_default.json"))
-line = [ln for ln in open(os.path.join(src, "bench_under_rocprof.log")) if ln.startswith("{")][0]
-open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(line)
-for f in glob.glob(os.path.join(src, "bench_*.json")):
-    if os.path.basename(f) != "bench_default.json":
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "line_*.json")):       # full reports (bench_*) and the printed lines (line_*)
+    if os.path.basename(f) not in ("bench_default.json",) and not re.search(r"bench_steps20_run[2-5]", f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
-b, p = json.load(open(os.path.join(dst, f"{tag}_bench_default.json"))), json.loads(line)
+if os.path.exists(os.path.join(src, "driver_runs.txt")):
+    shutil.copy(os.path.join(src, "driver_runs.txt"), os.path.join(dst, f"{tag}_driver_runs.txt"))
+    with open(os.path.join(dst, f"{tag}_driver_runs.txt"), "a") as fo:                       # mean vs median of every leg of the five runs
+        for i in range(1, 6):
+            try:
+                jj = json.load(open(os.path.join(src, f"bench_steps20_run{i}.json")))
+            except OSError:
+                continue
+            legs = {"headline": jj["roofline"]}
+            legs.update({"scene " + k: v["roofline"] for k, v in jj.get("scenes", {}).items() if "roofline" in v})
+            if "decode_kernel_headline" in jj:
+                legs["decode kernel"] = jj["decode_kernel_headline"]["roofline"]
+            fo.write(f"run {i}: value {jj['value']} " + "; ".join(f"{k}: frac {r['frac']} mean {r['frac_mean']} outliers {r.get('outliers')}" for k, r in legs.items()) +
+                     f" | seconds {jj.get('leg_seconds')}\n")
+b, p = json.load(open(os.path.join(dst, f"{tag}_bench_default.json"))), json.load(open(os.path.join(src, "bench_under_rocprof.json")))
 for name, j in (("plain", b), ("under rocprof", p)):
     print(f"{name:14s} value {j['value']:9.1f}  fused kernel {j['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['roofline']['frac']:.3f} | split decode "
           f"{j['split_pipeline']['roofline']['avg_launch_ms'] * 1e3:6.1f} us frac {j['split_pipeline']['roofline']['frac']:.3f} | decode alone "
@@ -88,9 +100,8 @@ print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / (alg[k.s
 try:
     print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), newest("kt_c2/**/*kernel_trace.csv"),
                           os.path.join(dst, f"{tag}_kernel_stats_by_grid_c2_1920x1080x44.csv")], capture_output=True, text=True).stdout.split("k_synth")[0])
-    line2 = [ln for ln in open(os.path.join(src, "bench_c2_under_rocprof.log")) if ln.startswith("{")][0]
-    open(os.path.join(dst, f"{tag}_bench_c2_1920x1080x44_under_rocprof.json"), "w").write(line2)
-except (ValueError, IndexError) as e_:
+    shutil.copy(os.path.join(src, "bench_c2_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_c2_1920x1080x44_under_rocprof.json"))
+except (ValueError, IndexError, OSError) as e_:
     print("no 1920x1080 kernel trace", e_)
 for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_stats_list_stage")):
     try:

@@ -7,22 +7,29 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
-python3 bench.py > "$out/bench_default.log" 2>&1
-grep '^{' "$out/bench_default.log" | tail -1 > "$out/bench_default.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py > "$out/bench_under_rocprof.log" 2>&1
+# bench.py prints ONE compact line (kept as line_*.json) and writes the full report to --extras-file (kept as bench_*.json)
+python3 bench.py --extras full --extras-file "$out/bench_default.json" > "$out/bench_default.log" 2>&1
+grep '^{' "$out/bench_default.log" | tail -1 > "$out/line_default.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --extras full --extras-file "$out/bench_under_rocprof.json" > "$out/bench_under_rocprof.log" 2>&1
 bash tools/pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 tail -3 "$out/pmc.log"
 # the other BASELINE configurations (physical scene = the default; the S-scene rides along as other_scene), 1920x1080 also under the kernel trace
 for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
-  python3 bench.py --workload $w --no-cpu-baseline --no-throughput-mode 2>/dev/null | tail -1 > "$out/bench_$w.json"
+  python3 bench.py --workload $w --extras full --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_$w.json" 2>/dev/null | tail -1 > "$out/line_$w.json"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --no-cpu-baseline --no-throughput-mode > "$out/bench_c2_under_rocprof.log" 2>&1
-python3 bench.py --scene s-scene --no-cpu-baseline --no-throughput-mode --no-small-images 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sscene_headline.json"
-python3 bench.py --scene physical-survey --no-cpu-baseline --no-throughput-mode --no-small-images 2>/dev/null | grep '^{' | tail -1 > "$out/bench_physical_survey_headline.json"
-python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' | tail -1 > "$out/bench_steps20.json"      # what the driver runs
-python3 bench.py --force-sharded --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_maps.json"
-python3 bench.py --force-sharded --exchange xyz --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_xyz.json"
-python3 bench.py --force-sharded --exchange records --no-extras 2>/dev/null | grep '^{' | tail -1 > "$out/bench_sharded_records.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --extras full --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_c2_under_rocprof.json" > "$out/bench_c2_under_rocprof.log" 2>&1
+python3 bench.py --scene s-scene --extras full --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_sscene_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_sscene_headline.json"
+python3 bench.py --scene physical-survey --extras full --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_physical_survey_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_physical_survey_headline.json"
+# what the driver runs, five times in a row (wall seconds, line size; VERDICT r4: no leg whose mean and median differ by > 5 %)
+for i in 1 2 3 4 5; do
+  t0=$(date +%s%N)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras-file "$out/bench_steps20_run$i.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_steps20_run$i.json"
+  echo "driver run $i: wall $(( ($(date +%s%N) - t0) / 1000000 )) ms, line $(wc -c < "$out/line_steps20_run$i.json") bytes" >> "$out/driver_runs.txt"
+done
+for ex in maps xyz records; do
+  python3 bench.py --force-sharded --exchange $ex --no-extras --extras-file "$out/bench_sharded_$ex.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_sharded_$ex.json"
+done
+python3 bench.py --force-sharded --exchange maps --exchange-impl direct --no-extras --extras-file "$out/bench_sharded_maps_direct.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_sharded_maps_direct.json"
 # the "next" rows, the list stage and the whole reference-shaped product under the kernel trace, the store-pattern microbenchmark
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_next" -- python3 tools/time_next_rows.py > "$out/next_rows.log" 2>&1
 LISTS_ROUTE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_lists" -- python3 tools/time_lists.py --rounds 2 --knobs lists_lines=1 > "$out/lists.log" 2>&1
