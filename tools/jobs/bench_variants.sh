@@ -15,17 +15,17 @@ except Exception as e:
     print("rc", sys.argv[2], "|", sys.argv[3], "| NO JSON", e)
 PY
 done <<'LIST'
---no-extras
+--extras none
 --pipeline split --no-throughput-mode
---mode exact --no-extras
+--mode exact --extras none
 --tri direct --no-extras --workload c2_1920x1080x44
---workload b8_4096x375x44 --image-rows 3000 --no-extras
---workload b8_4096x375x44 --no-extras
---scene s-scene --no-extras
---force-sharded --scene s-scene --no-extras
---force-sharded --exchange xyz --workload c2_1920x1080x44 --no-extras
+--workload b8_4096x375x44 --image-rows 3000 --extras none
+--workload b8_4096x375x44 --extras none
+--scene s-scene --extras none
+--force-sharded --scene s-scene --extras none
+--force-sharded --exchange xyz --workload c2_1920x1080x44 --extras none
 --force-sharded --exchange records --no-extras --workload t_516x1031x44
---workload c3_4096x3000x46 --no-extras
---workload t_516x1031x44 --no-extras
---plane-pad 64 --no-extras
+--workload c3_4096x3000x46 --extras none
+--workload t_516x1031x44 --extras none
+--plane-pad 64 --extras none
 LIST
