@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(64) k_flags_wait(const FlagList f)
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(sys_load(f.p[i]) - f.v[i]) < 0) {
         __builtin_amdgcn_s_sleep(32);
+        if (sys_load(f.error)) return;          // some wait of the job has already given up: the polls queued behind it must not each sit out their own deadline
         if (wall_clock64() - t0 > f.timeout_ticks) {
             sys_store(f.error, f.who);           // (a plain store: atomics on host memory would need PCIe atomics)
             return;

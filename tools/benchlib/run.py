@@ -643,6 +643,7 @@ def run_rank(args, rank, local_rank, world):
             try:
                 STAGE[0] = f"sharded alternatives: {label}"
                 if impl == "direct":
+                    os.environ.setdefault("SLGC_DIRECT_TIMEOUT_S", "5")     # an extra after the counted region: a healthy exchange takes well under a millisecond
                     alt_exch = exch if args.exchange_impl == "direct" else sharded.DirectExchange(ctx, rank, G, direct_key + "_alt")
                 else:
                     alt_exch = sharded.RcclExchange(ctx)
