@@ -5,7 +5,10 @@ MI355X_MICROARCH.md, rocprofv3 PMC slots): `rocprofv3 --pmc <counter> -- python3
 behind `--`, no tracing flag beside --pmc.  The child's counter CSV is reduced to bytes per launch of the scan kernel:
     HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 (FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies the 128-byte requests of a coalesced streaming read at 64 bytes -- the
-guide's correction, calibrated here on the decode kernel, which cannot read less than its N bytes per pixel: 0.98 x algorithmic)."""
+guide's correction, calibrated here on the decode kernel, which cannot read less than its N bytes per pixel: 0.98 x algorithmic).
+Round 5 checked the raw request counters behind it (tools/jobs/r5_pmc_rdreq.sh, profiles/r05_pmc_rdreq.txt): on gfx950 TCC_BUBBLE and TCC_EA0_RDREQ_32B are 0
+for these kernels, so FETCH_SIZE is 64 B x TCC_EA0_RDREQ while every request is a whole 128-byte line (decode kernel: 131 B of frames per request) -- the
+factor 2 holds for the streaming loads and for the table gathers alike; WRITE_SIZE is exact (64 B x TCC_EA0_WRREQ_64B)."""
 import csv
 import glob
 import os
