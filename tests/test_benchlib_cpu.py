@@ -119,11 +119,13 @@ def test_printed_line_is_compact_and_carries_the_contract_keys():
     # a multi-rank report: the sharded summary and the verification verdict ride along, long strings are cut
     multi = dict(full, n_gpus=8, sharded={"rccl_nranks": 8, "exchange": "maps", "wire": "hv24", "overlap": True, "with_exchange_value": 1.0, "compute_only_value": 2.0,
                                           "exchange_bytes_per_rank": {"sent": 1, "received": 7}, "compute_only_note": "x" * 5000},
-                 verify={"ok": True, "note": "y" * 5000}, error="z" * 5000)
+                 verify={"ok": True, "note": "y" * 5000}, error="z" * 5000,
+                 sharded_alternatives={"maps_int16": {"value": 5.0, "note": "n" * 900}, "xyz": {"error": "e" * 900}, "maps_hv24_direct": {"value": 7.5}})
     multi["config"] = dict(full["config"], workload="w" * 3000, pipeline="p" * 3000)
     s = L.dump_line(multi, None)
     j = json.loads(s)
-    assert len(s) < L.LINE_LIMIT and j["sharded"]["rccl_nranks"] == 8 and j["verify_ok"] is True and set(j["sharded"]) == set(L.SHARDED_KEYS)
+    assert len(s) < L.LINE_LIMIT and j["sharded"]["rccl_nranks"] == 8 and j["verify_ok"] is True and set(j["sharded"]) == set(L.SHARDED_KEYS) | {"alternatives"}
+    assert j["sharded"]["alternatives"] == {"maps_int16": 5.0, "xyz": "error", "maps_hv24_direct": 7.5}
     assert len(j["config"]["workload"]) <= 120 and len(j["error"]) <= 200
     # a report without any extras (--extras none): the keys are there, empty
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",

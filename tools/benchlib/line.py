@@ -57,6 +57,9 @@ def compact_line(report, extras_file=None):
     line["throughput_mode_value"] = (thr.get("batched") or {}).get("value") or thr.get("value")
     sh = report.get("sharded")
     line["sharded"] = _pick(sh, SHARDED_KEYS) if sh else None
+    alts = report.get("sharded_alternatives")
+    if sh and isinstance(alts, dict):                     # the other exchange forms timed after the counted region: label -> Mpixels/s (or "error")
+        line["sharded"]["alternatives"] = {_cut(k, 24): (v.get("value") if isinstance(v, dict) and "value" in v else "error") for k, v in list(alts.items())[:6]}
     ver = report.get("verify")
     line["verify_ok"] = None if ver is None else bool(ver.get("ok"))
     line["extras_file"] = extras_file

@@ -640,6 +640,18 @@ def run_rank(args, rank, local_rank, world):
                                         (f"maps_{sharded_scanner.wire}_{other_impl}", "maps", sharded_scanner.wire, other_impl)):
             if wire == "hv24" and int((N - 2) / 4) > _native.WIRE_MAX_CODE_BITS:
                 continue
+            if impl == "direct" and args.exchange_impl != "direct" and os.environ.get("SLGC_BENCH_NO_DIRECT_ALT") == "1":
+                continue
+            if impl != args.exchange_impl and rank == 0:
+                # the exchange implementation that has never run on this kind of machine goes last, after what is known so far is on disk: if it
+                # takes the process down the side file still has the rest (the printed line needs this process alive: exactly ONE line is printed)
+                try:
+                    side = getattr(args, "extras_file", None) or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+                    os.makedirs(os.path.dirname(side), exist_ok=True)
+                    with open(side, "w") as f:
+                        json.dump(dict(out, sharded_alternatives=dict(alternatives), provisional=f"written before the {label} alternative ran"), f, indent=1)
+                except OSError:
+                    pass
             try:
                 STAGE[0] = f"sharded alternatives: {label}"
                 if impl == "direct":
