@@ -96,7 +96,9 @@ __host__ __device__ inline float proj_tan_half(float px, float py, const double 
     const float qn = sqrtf((px * px + py * py) + 1.0f);                                                    // norm inside triangulate.py:92 (float32)
     const double c = ((T[0] * (double)px + T[1] * (double)py) + T[2]) / (t_len * (double)qn);             // :92
     const double s = sqrt(fmax(0.0, 1.0 - c * c));
-    return (float)(c >= 0.0 ? s / (1.0 + c) : (1.0 - c) / s);                                             // the well-conditioned form on each side
+    const double th = c >= 0.0 ? s / (1.0 + c) : (1.0 - c) / s;                                           // the well-conditioned form on each side
+    return (float)fmin(th, 1e9);      // beta -> pi (a ray back along the baseline): th -> inf; capped so that (1 + th^2)^2 stays finite in float32 and the
+                                      // flat test sends the pixel to the exact path (4 th^2 * 60 < (1 + th^2)^2 from th = 15.4 on); a NaN ray takes the cap too (fmin) and gets its NaN from the exact path
 }
 
 struct TriFastTerms {
