@@ -292,6 +292,7 @@ extern "C" int slgc_create(int device, slgc_ctx **out)
     ctx->tune_park = xcd_env("SLGC_PARK", 1);
     ctx->tune_guard_list = xcd_env("SLGC_GUARD_LIST", 1);
     ctx->tune_fuse_xcd = xcd_env("SLGC_FUSE_XCD", 0);
+    ctx->tune_prio = xcd_env("SLGC_PRIO", -1);           // -1 = by launch shape (launch_scan_fused)
     ctx->tune_cam_nodes = xcd_env("SLGC_CAM_NODES", 1);
     ctx->lut_nodes_err = -1.0f;
     ctx->tune_lists_lines = xcd_env("SLGC_LISTS_LINES", 1);
@@ -351,6 +352,7 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "park")) ctx->tune_park = value != 0;
     else if (!strcmp(name, "guard_list")) ctx->tune_guard_list = value != 0;
     else if (!strcmp(name, "fuse_xcd")) ctx->tune_fuse_xcd = value < 0 ? 0 : value;
+    else if (!strcmp(name, "prio")) ctx->tune_prio = value < 0 ? -1 : value;
     else if (!strcmp(name, "cam_nodes")) ctx->tune_cam_nodes = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "lists_lines")) ctx->tune_lists_lines = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "lists_order")) ctx->tune_lists_order = value < 0 ? 0 : (value > 64 ? 64 : value);

@@ -257,6 +257,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     int proj_w, proj_h, tiles_x, wide;   // projector table geometry (proj_lut_index)
     int nt_store;             // bit 0: XYZ, bit 1: maps leave with non-temporal stores (products nothing re-reads); bit 2: the maps are not stored at all
     int wave_tail;            // 1: wave-local LDS exchange in the tail (no workgroup barriers)
+    int prio_head, prio_body, prio_tail;   // s_setprio of a wave while it fetches its threshold frames and computes its thresholds / walks the bit loop / runs the tail
     uint32_t xcd_chunk;       // XCD-aware workgroup -> tile map (slgc_internal.h: xcd_block), 0 = identity
     uint32_t xcd_run;         // ... or its fine-grained form (xcd_block_fine): tiles per XCD inside a group of 8 * xcd_run, 0 = off
     uint32_t batch_bps, batch_magic;   // slgc_scan_batch_dev: workgroups per scan (0 = one scan) and ceil(2^32 / batch_bps) for the division
@@ -267,6 +268,19 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
     unsigned long long *stamps;
 #endif
 };
+
+// Issue priority of the wave among the waves of its SIMD (s_setprio takes an immediate: a wave-uniform switch selects it).  Which phase of
+// k_decode_pk goes first decides how full the memory pipeline stays (round 5, NOTES.md): a wave that still has to ask for its threshold
+// frames goes first at every size; in launches of a single round of resident waves the tail goes last.
+__device__ __forceinline__ void set_prio(int p)
+{
+    switch (p) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
 
 // Everything in k_decode_pk that is NOT the product, named in one place.  Diag<0> is the shipped kernel: every flag below is false and every
 // `if constexpr (D::...)` folds away; the timing-only ablations (diagnostic build `make diag`, results wrong on purpose unless noted) and the
@@ -481,6 +495,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         }
     }
     stamp<FUSE, BLOCK>(a, 0);
+    set_prio(a.f.prio_head);
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
     const uint32_t voff = BGR ? 3u * off : off;      // byte offset of the lane's pixels inside a plane
     const uint32_t ps = a.plane_stride;
@@ -598,6 +613,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         asm volatile("" : "+v"(KA[0]), "+v"(KB[0]), "+v"(C1[0]), "+v"(C2[0]));      // the thresholds exist
 #endif
         stamp<FUSE, BLOCK>(a, 1);
+        set_prio(a.f.prio_body);
 #pragma unroll
         for (int p = 0; p < NP; ++p) { aB_h[p] = aB_v[p] = 0u; aV_h[p] = aV_v[p] = MULTI ? 0u : 0xffffffffu; }
         // step t: column code bit k = L-1-t (its weight 2^t), row code bit k = t (its weight 2^t)
@@ -699,6 +715,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         }
     }
     if constexpr (FUSE != 0) {
+        set_prio(a.f.prio_tail);
         // K3 appended: the maps never leave registers before they are triangulated (triangulate.py:56-61, 86-95 in the
         // cancelled algebraic form; rays from the per-calibration tables).  Same LDS exchange as k_triangulate_maps_lds:
         // indices -> pixel-per-lane gathers -> per-lane triangulation -> wave-contiguous XYZ stores.
@@ -1166,6 +1183,20 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const int nt_policy = ctx->tune_fuse_nt >= 0 ? (ctx->tune_fuse_nt & 3) : (npix4 * (size_t)(n_batch > 1 ? n_batch : 1) >= (4u << 20) ? 1 : 3);
     b.f.nt_store = nt_policy | ((d_h == nullptr || d_v == nullptr) ? 4 : 0);
     b.f.wave_tail = ctx->tune_fuse_tail;
+    {
+        // Issue priority per phase (slgc_tune "prio" = head * 100 + body * 10 + tail, each 0..3; -1 = by launch shape, the default).  A launch
+        // that fills most of the chip's 8 192 wave slots in ONE round has every wave in the same phase at the same time: with the head (threshold
+        // frames) first, the bit loop second and the tail last the memory pipeline stays full while the first waves finish -- 1920x1080x44
+        // 23.3-23.8 -> 22.4-22.9 us on five boxes, 4096x375 (6 000 waves) 18.6 -> 18.2; below half of the slots (1280x720: 3 600 waves) it is a
+        // wash, and a launch of more than one round needs its tails to finish to make room: 210 costs 4096x750 +6 %, 4096x3000 +8 %.  Raising only
+        // the head (200 / 300) gave -4 to -8 % at 4096x3000 on two slow boxes (127-134 us) and +0.5 to +1.7 % on eleven fast ones (117-119): left at 0.
+        int pr = ctx->tune_prio;
+        if (pr < 0) {
+            const uint64_t waves = (uint64_t)((b.npix / 4 + 127) / 128) * 2u * (uint64_t)(n_batch > 1 ? n_batch : 1);
+            pr = (!bgr_bits && waves > 4096 && waves <= 8192) ? 210 : 0;
+        }
+        b.f.prio_head = (pr / 100) % 10; b.f.prio_body = (pr / 10) % 10; b.f.prio_tail = pr % 10;
+    }
     b.f.kf = make_tri_f32(ctx->calib.T, ctx->calib.t_len);
     memcpy(b.f.T, ctx->calib.T, sizeof b.f.T);
     b.f.t_len = ctx->calib.t_len;

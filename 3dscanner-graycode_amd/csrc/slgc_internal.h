@@ -56,6 +56,7 @@ struct slgc_ctx {
     int tune_tri_nt;        // dense triangulation kernel: XYZ with non-temporal stores
     int tune_xcd;           // dense triangulation kernel: XCD-aware workgroup -> tile map
     int tune_fuse_xcd;      // the same map for the fused scan kernel
+    int tune_prio;          // fused scan kernel: s_setprio per phase, head * 100 + body * 10 + tail (decode.hip: set_prio)
     int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
     int tune_lists_lines;   // slgc_cloud_dev's scatter: 1 = k_xmajor_lines (whole 128-byte lines) for images of >= 2048 tiles (default), 2 = wherever the shape allows, 0 = k_xmajor_scatter<.., 2, ..>
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)

@@ -30,6 +30,9 @@ extern "C" {
  * whole-lines scatter k_xmajor_lines only) column-major in runs of n consecutive tiles per XCD, so that a tile and the tile below it -- whose rows it also
  * reads -- share an L2 (n = 4: 218.8 -> 210.5 us).  The two scatter kernels read the value differently: the tile-run scatter k_xmajor_scatter treats
  * every value other than 0 and 2 as plain column-major (1).
+ * "prio" = head * 100 + body * 10 + tail: s_setprio (0..3) of a wave of the fused scan kernel while it fetches its threshold frames and computes its thresholds /
+ * walks the bit loop / runs the triangulation tail; -1 (default) = by launch shape: 210 for launches that fill more than half of the chip's 8 192 wave slots in one
+ * round (1920x1080: -3.5 %), 0 otherwise (NOTES.md round 5).
  * "guard_list" 1 (default) = the fused scan kernel compacts its flat triangles over the wave and redoes 64 of them per float64 pass / 0 = redoes them lane by
  * lane (bit-identical XYZ; scattered wrong codes make the lane-by-lane form walk the float64 path in nearly every wave).
  * "lists_lines" 1 (default) = slgc_cloud_dev's list build writes whole aligned 128-byte lines (k_xmajor_lines; see slgc_last_list_kernel) for images of at
@@ -38,7 +41,7 @@ extern "C" {
  * and accuracy check -- is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether one GPU scans the image or N GPUs
  * scan its bands (0, the default: the band is the image).
  * Defaults can also be set with the environment (SLGC_FUSE_TAIL, SLGC_PROJ_TILE, SLGC_PARK, SLGC_FUSE_NT, SLGC_TRI_NT, SLGC_XCD,
- * SLGC_FUSE_XCD, SLGC_CAM_NODES, SLGC_LISTS_LINES, SLGC_LISTS_ORDER, SLGC_GUARD_LIST), read when the context is created.  Other environment
+ * SLGC_FUSE_XCD, SLGC_PRIO, SLGC_CAM_NODES, SLGC_LISTS_LINES, SLGC_LISTS_ORDER, SLGC_GUARD_LIST), read when the context is created.  Other environment
  * switches (read once per process, A/B only): SLGC_FD_SEGS (segment count of the frame-difference kernel), SLGC_PAR_DOWNLOAD, SLGC_F64_PACK. */
 
 
