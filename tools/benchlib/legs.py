@@ -17,6 +17,10 @@ def throughput_lanes(_native, device, per_rank, n_streams=2, scene="s-scene"):
     for sidx in range(max(1, n_streams)):
         c = _native.Context(device)
         c.set_calibration(*calibration(cw, ch, pw, ph, rig=SCENES[scene]["rig"]))
+        if n_streams > 1:
+            # several contexts share the GPU here: the per-phase issue priorities the library gives a launch that fills the chip in one round
+            # ("tail last") assume the launch is alone -- with a second stream's kernel beside it they cost 12 % (90 -> 79 k Mpixels/s)
+            c.tune("prio", 0)
         stacks = []
         for b in range(max(2, -(-max(per_rank, 4) // max(1, n_streams)))):
             st = c.alloc(n * px)
