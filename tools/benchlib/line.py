@@ -11,7 +11,7 @@ TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "config", "roofline", "cpu_baseline", "s_scene_frac", "decode_kernel_frac", "throughput_mode_value", "sharded", "verify_ok", "extras_file")
 CONFIG_KEYS = ("workload", "pipeline", "scene_name", "rig", "executed_path", "valid_fraction", "extras")
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_mean", "isolated_frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_launch_ms",
-                 "median_launch_ms", "max_launch_ms", "launches_timed", "outliers", "algorithmic_bytes_per_launch")
+                 "median_launch_ms", "launch_ms_used", "max_launch_ms", "launches_timed", "outliers", "algorithmic_bytes_per_launch")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "c_oracle_value", "c_oracle_all_cores_value", "c_oracle_all_cores")
 SHARDED_KEYS = ("rccl_nranks", "exchange", "exchange_impl", "wire", "overlap", "with_exchange_value", "compute_only_value")
 
