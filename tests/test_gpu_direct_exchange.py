@@ -39,7 +39,7 @@ def _worker_exchange(rank, world, key, q):
         total = displs[-1] + counts[-1] + 64
         bufs = [ctx.alloc(total).zero() for _ in range(3)]
         ex.register(bufs)
-        for it in range(25):
+        for it in range(int(os.environ.get("SLGC_DIRECT_TEST_ROUNDS", "25"))):      # (soak: SLGC_DIRECT_TEST_ROUNDS=400)
             # the rank's band of every buffer gets this round's pattern; everything before (the previous round's readers: the downloads
             # below, already synchronised) is done with the buffers -> release, then push
             ex.release(bufs)
@@ -185,9 +185,9 @@ def _run(target, world, *args, timeout=120):
     return results
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4] + ([8] if os.environ.get("SLGC_DIRECT_TEST_ROUNDS") else []))
 def test_direct_exchange_layouts_and_release_protocol(world):
-    _run(_worker_exchange, world)
+    _run(_worker_exchange, world, timeout=120 + 2 * int(os.environ.get("SLGC_DIRECT_TEST_ROUNDS", "25")))
 
 
 @pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (5, 3)])
