@@ -29,14 +29,14 @@ WORKLOADS = {
 BASELINE_CONFIG = {"c1_1280x720x42": 0, "c2_1920x1080x44": 1, "c3_4096x3000x44": 2}      # --workload -> index into BASELINE.json "configs"
 
 
-def workload_label(name, cam_w, cam_h, proj_w, proj_h, N, sharded_over=0):
+def workload_label(name, cam_w, cam_h, proj_w, proj_h, N, sharded_over=0, exchange="RCCL"):
     idx = BASELINE_CONFIG.get(name)
     if idx is None:
         tag = "not a BASELINE.json config: a variant / test / band workload"
     elif sharded_over and idx == 2:
-        tag = f"BASELINE.json configs[2] row-sharded over {sharded_over} GPU(s) + RCCL exchange = configs[3]"
+        tag = f"BASELINE.json configs[2] row-sharded over {sharded_over} GPU(s) + {exchange} exchange = configs[3]"
     elif sharded_over:
-        tag = f"BASELINE.json configs[{idx}] row-sharded over {sharded_over} GPU(s) + RCCL exchange"
+        tag = f"BASELINE.json configs[{idx}] row-sharded over {sharded_over} GPU(s) + {exchange} exchange"
     else:
         tag = f"BASELINE.json configs[{idx}]"
     return f"{cam_w}x{cam_h} cam, {proj_w}x{proj_h} proj, {N} uint8 frames ({tag})"

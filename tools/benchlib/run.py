@@ -452,7 +452,7 @@ def run_rank(args, rank, local_rank, world):
             "metric": "Mpixels/s decode+triangulate", "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": G,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload_label(args.workload, cam_w, cam_h, proj_w, proj_h, N, G if use_comm else 0),
+            "config": {"workload": workload_label(args.workload, cam_w, cam_h, proj_w, proj_h, N, G if use_comm else 0, "direct (IPC push)" if args.exchange_impl == "direct" else "RCCL"),
                        "pipeline": ({"maps": "decode kernel per band, map bands all-gathered, full-image triangulation kernel on every rank",
                                      "xyz": "fused kernel per band, map + XYZ bands all-gathered in place",
                                      "records": "fused kernel per band, compaction, 16-byte XYZ+key records all-gatherv'ed"}[args.exchange] if use_comm
