@@ -140,8 +140,9 @@ def main():
     ap.add_argument("--no-small-images", action="store_true", help="skip the BASELINE configs[1] / configs[0] fused-kernel legs of the default run")
     ap.add_argument("--image-rows", type=int, default=0,
                     help="single-GPU band workloads: height of the whole image the band belongs to (slgc_tune image_rows; 0 = the band is the image)")
-    ap.add_argument("--sustained", type=float, default=1.0,
-                    help="seconds of back-to-back headline scans in the extra 'sustained' leg (0 = skip); long enough for SMI samplers to see the GPU busy")
+    ap.add_argument("--sustained", type=float, default=5.5,
+                    help="seconds of back-to-back headline scans in the extra 'sustained' leg (0 = skip); longer than the 5 s cadence of the driver's SMI "
+                         "sampler, so that something outside this script sees the GPU busy (round 4's 1 s leg never was)")
     ap.add_argument("--buffers", type=int, default=0,
                     help="distinct input stacks rotated between steps (0 = as many as needed to exceed the 256 MB Infinity Cache, >= 2)")
     args = ap.parse_args()

@@ -116,6 +116,7 @@ def test_printed_line_is_compact_and_carries_the_contract_keys():
     assert j["s_scene_frac"] == full["scenes"]["s-scene"]["frac"] and j["decode_kernel_frac"] == full["decode_kernel_alone"]["roofline"]["frac"]
     assert j["throughput_mode_value"] == full["throughput_mode"]["batched"]["value"]
     assert j["sharded"] is None and j["verify_ok"] is None and j["extras_file"] == "gpurun_out/bench_extras.json"
+    assert j["sustained"]["value"] == full["sustained"]["value"] and j["sustained"]["gpu_busy_percent_mean"] == full["sustained"]["gpu"]["gpu_busy_percent_mean"]
     # a multi-rank report: the sharded summary and the verification verdict ride along, long strings are cut
     multi = dict(full, n_gpus=8, sharded={"rccl_nranks": 8, "exchange": "maps", "wire": "hv24", "overlap": True, "with_exchange_value": 1.0, "compute_only_value": 2.0,
                                           "exchange_bytes_per_rank": {"sent": 1, "received": 7}, "compute_only_note": "x" * 5000},

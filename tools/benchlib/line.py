@@ -8,7 +8,7 @@ import json
 LINE_LIMIT = 4096
 
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-            "config", "roofline", "cpu_baseline", "s_scene_frac", "decode_kernel_frac", "throughput_mode_value", "sharded", "verify_ok", "extras_file")
+            "config", "roofline", "cpu_baseline", "s_scene_frac", "decode_kernel_frac", "throughput_mode_value", "sustained", "sharded", "verify_ok", "extras_file")
 CONFIG_KEYS = ("workload", "pipeline", "scene_name", "rig", "executed_path", "valid_fraction", "extras")
 ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_mean", "isolated_frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_launch_ms",
                  "median_launch_ms", "launch_ms_used", "max_launch_ms", "launches_timed", "outliers", "algorithmic_bytes_per_launch")
@@ -55,6 +55,9 @@ def compact_line(report, extras_file=None):
     line["decode_kernel_frac"] = ((dk or {}).get("roofline") or {}).get("frac")
     thr = report.get("throughput_mode") or {}
     line["throughput_mode_value"] = (thr.get("batched") or {}).get("value") or thr.get("value")
+    su = report.get("sustained")
+    line["sustained"] = None if not su else {"value": su.get("value"), "seconds": su.get("seconds"), "sclk_mhz_mean": (su.get("gpu") or {}).get("sclk_mhz_mean"),
+                                             "gpu_busy_percent_mean": (su.get("gpu") or {}).get("gpu_busy_percent_mean")}
     sh = report.get("sharded")
     line["sharded"] = _pick(sh, SHARDED_KEYS) if sh else None
     alts = report.get("sharded_alternatives")

@@ -284,7 +284,7 @@ def run_rank(args, rank, local_rank, world):
 
     sustained = None
     use_rig(SCENES[args.scene]["rig"])
-    if single and args.extras == "full" and args.sustained > 0:
+    if single and args.extras != "none" and args.sustained > 0:
         with leg("sustained"):
             sustained = sustained_leg(ctx, step, drain, args.sustained, cam_w * rows / 1e6)
 
