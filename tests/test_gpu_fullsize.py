@@ -571,3 +571,36 @@ def test_movement_yardstick_runs_and_refuses_bad_shapes(ctx):
             ctx.move_only_dev(stack.ptr, px, kw["N"], kw["npix"], d_h=kw["d_h"], d_v=kw["d_v"], d_xyz=kw["d_xyz"])
     for b in (stack, maps, xyz):
         b.free()
+
+
+@pytest.mark.parametrize("workload", ["c2_1920x1080x44", "b8_4096x375x44", "c3_4096x3000x44"])
+def test_issue_priorities_change_no_bit(ctx, workload):
+    """slgc_tune "prio" (s_setprio per phase of the fused kernel; -1 = the library's choice by launch shape) is a scheduling knob: maps and XYZ
+    are bit-identical under every setting, and against the oracle under the default."""
+    from scanner import _native
+    W, H, pw, ph, N = bench.WORKLOADS[workload]
+    calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(N * px)
+    ctx.synth_scene_dev(stack.ptr, px, N, H, W, row0=0, rows=H, seed=5, noise=3, shadow=True)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    got = {}
+    try:
+        for prio in (-1, 0, 210, 321, 13):
+            ctx.tune("prio", prio)
+            maps.zero()
+            xyz.zero()
+            ctx.scan_dev(stack.ptr, 1, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=_native.TRI_ALGEBRAIC)
+            ctx.synchronize()
+            assert ctx.last_scan_path()["path"] == "fused"
+            got[prio] = (maps.download((2, H, W), np.int16), xyz.download((H, W, 3), np.float32))
+    finally:
+        ctx.tune("prio", -1)
+    for prio, (m, x) in got.items():
+        assert np.array_equal(m, got[-1][0]) and np.array_equal(x.view(np.uint32), got[-1][1].view(np.uint32)), prio
+    st = stack.download((N, H, W), np.uint8)
+    ref_h, ref_v, ref_xyz = oc.scan_dense(st, (pw, ph), *calib)
+    compare_scan(got[-1][0][0], got[-1][0][1], got[-1][1], ref_h, ref_v, ref_xyz, f"{workload} default priorities")
+    for b in (stack, maps, xyz):
+        b.free()
