@@ -1285,7 +1285,7 @@ extern "C" int slgc_diag_stamps(slgc_ctx *ctx, unsigned long long *host, size_t 
     if (!ctx || !host || !n_waves) return SLGC_EINVAL;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const size_t n = ctx->stamp_waves < cap_waves ? ctx->stamp_waves : cap_waves;
-    if (n) HIP_TRY(ctx, hipMemcpy(host, ctx->ws[11], n * 5 * 8, hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(ctx, hipMemcpy(host, ctx->ws[12], n * 5 * 8, hipMemcpyDeviceToHost));      // (slot 12: launch_scan_fused)
     *n_waves = ctx->stamp_waves;
     return SLGC_OK;
 }
