@@ -12,10 +12,9 @@ lines = [ln for ln in open(sys.argv[1]) if ln.startswith("{")]
 if not lines:
     print("N", sys.argv[3], "rc", sys.argv[2], "NO JSON"); sys.exit(0)
 j = json.loads(lines[-1])
-print("N", sys.argv[3], "rc", sys.argv[2], "json lines", len(lines), "| value", j.get("value"), "| scaling", j.get("scaling"), "| verify", (j.get("verify") or {}).get("ok"),
-      "| sharded", {k: (j.get("sharded") or {}).get(k) for k in ("rccl_nranks", "exchange", "with_exchange_value", "compute_only_value")},
-      "| thr", (j.get("throughput_mode") or {}).get("value"), "| alt", {k: (v.get("value"), v.get("maps_equal_main_strategy_on_every_rank"), v.get("error")) for k, v in (j.get("sharded_alternatives") or {}).items()} if isinstance(j.get("sharded_alternatives"), dict) else j.get("sharded_alternatives"),
-      "| err", j.get("error"))
+# (round 5: the printed line is the compact object -- verify_ok, sharded.alternatives, throughput_mode_value)
+print("N", sys.argv[3], "rc", sys.argv[2], "json lines", len(lines), "bytes", len(lines[-1]), "| value", j.get("value"), "| scaling", j.get("scaling"), "| verify_ok", j.get("verify_ok"),
+      "| sharded", j.get("sharded"), "| thr", j.get("throughput_mode_value"), "| err", j.get("error"))
 PY
   tail -2 $O/n$n.err | cut -c1-300
 done
