@@ -339,7 +339,8 @@ int slgc_comm_wait(slgc_ctx *ctx, int slot);
  *   slgc_direct_wait           compute stream waits until every peer's band of that exchange has arrived here
  *   slgc_direct_release        compute stream: work enqueued so far is done with what the last exchange left in these buffers; peers may overwrite.
  *                              Call it before re-using a buffer set (the first exchange on a buffer needs none).
- *   slgc_direct_barrier / _allgather_i64   small host-side collectives over the segment (both streams drained first)
+ *   slgc_direct_barrier / _allgather_i64   small host-side collectives over the segment (both streams drained first).  Call slgc_direct_barrier before
+ *                              slgc_direct_destroy (or slgc_destroy) and before freeing a registered buffer: a peer may still be pushing into it.
  * A peer that never shows up costs a failed call (SLGC_ECOMM after a 20 s GPU-side / 120 s host-side timeout), never a hung GPU. */
 int slgc_direct_init(slgc_ctx *ctx, int rank, int nranks, const char *key);
 int slgc_direct_destroy(slgc_ctx *ctx);
