@@ -1207,7 +1207,7 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
 
 // The scan straight from the camera's BGR frames (src/3-capture_decode.py:66-70: cv2.cvtColor(BGR2GRAY) into the grey stack, :75 get_codes on it):
 // d_bgr = [n_runs][N][rows][W][3] uint8, plane_stride = bytes between consecutive frames (>= 3 * rows * W).  One kernel when the shape allows
-// (N = 42 / 44 / 46, 4-byte aligned planes, algebraic mode, no count): the luma is formed in registers inside the frame loads and the grey stack
+// (N = 42 / 44 / 46 / 50 / 54, 4-byte aligned planes, algebraic mode, no count): the luma is formed in registers inside the frame loads and the grey stack
 // never exists in HBM -- 3 N + 12 bytes per pixel instead of 3 N + N (written) + N (read back) + 12.  Any other shape: slgc_to_gray_dev into
 // scratch of the context, then slgc_scan_dev.  Maps and XYZ are bit-identical either way (same luma, same kernels behind it).
 extern "C" int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int row0,

@@ -1111,6 +1111,8 @@ static int spec_frames(const slgc_ctx *ctx, const DecodeGeom &g)
     if (spec_matches<44>(g)) return 44;
     if (spec_matches<46>(g)) return 46;
     if (spec_matches<42>(g)) return 42;
+    if (spec_matches<50>(g)) return 50;      // 4K projectors: 4 * ceil(log2(3840)) + 2 frames (generate_codes.py:22-25,53), L = 12 code bits
+    if (spec_matches<54>(g)) return 54;      // 8K: L = 13
     return 0;
 }
 
@@ -1140,7 +1142,7 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
             if (a.g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 0, NSV>), dim3(blocks), dim3(128), a);  \
             else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 0, NSV>), dim3(blocks), dim3(128), a);         \
         }
-        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42)
+        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42) SLGC_SPEC(50) SLGC_SPEC(54)
 #undef SLGC_SPEC
     }
     if (ns == 0) {
@@ -1243,7 +1245,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
                 if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 3, NSV, 1>), dim3(blocks), dim3(128), b);    \
                 else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 3, NSV, 1>), dim3(blocks), dim3(128), b);                \
             }
-            SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42)
+            SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42) SLGC_BGR(50) SLGC_BGR(54)
 #undef SLGC_BGR
             if (ns == 0) return slgc_fail(ctx, SLGC_EINVAL, "internal: BGR scan launched without a specialised frame count");
             HIP_TRY(ctx, hipGetLastError());
@@ -1260,7 +1262,7 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
                 else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 2, NSV>), dim3(blocks), dim3(128), b);            \
             }                                                                                                      \
         }
-        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42)
+        SLGC_SPEC(44) SLGC_SPEC(46) SLGC_SPEC(42) SLGC_SPEC(50) SLGC_SPEC(54)
 #undef SLGC_SPEC
         if (ns == 0) {
             if (g.n_runs > 1) {
@@ -1327,7 +1329,7 @@ int launch_decode_bgr(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
         if (g.n_runs > 1) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, true, 0, 0, NSV, 1>), dim3(blocks), dim3(128), b);    \
         else SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 0, 0, NSV, 1>), dim3(blocks), dim3(128), b);                \
     }
-    SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42)
+    SLGC_BGR(44) SLGC_BGR(46) SLGC_BGR(42) SLGC_BGR(50) SLGC_BGR(54)
 #undef SLGC_BGR
     if (ns == 0) return slgc_fail(ctx, SLGC_EINVAL, "internal: BGR decode launched without a specialised frame count");
     HIP_TRY(ctx, hipGetLastError());

@@ -65,7 +65,7 @@ struct slgc_ctx {
                             // for the whole image, so a pixel gets the same rays -- and bit-identical XYZ -- whether one GPU scans the image or N GPUs its bands
     // slgc_last_scan_path: what the last slgc_scan_dev / slgc_scan_batch_dev / slgc_decode_dev / slgc_triangulate_maps_dev call launched (written by the launchers)
     int last_scan_path;     // SLGC_PATH_*
-    int last_ns;            // frames-per-run specialisation of the decode / fused kernel (42 / 44 / 46), 0 = generic kernel
+    int last_ns;            // frames-per-run specialisation of the decode / fused kernel (42 / 44 / 46 / 50 / 54), 0 = generic kernel
     int last_nodes;         // 1 = the triangulation read the camera node table, 0 = the per-pixel table (or evaluated the rays per pixel)
     int last_guard;         // 1 = float32 fast form with the flat-triangle guard, 0 = exact (acos / sin) mode, -1 = unguarded (diagnostic build only)
     int last_list_kernel;   // SLGC_LISTS_*: which scatter the last x-major list build launched
@@ -74,7 +74,7 @@ struct slgc_ctx {
     int decode_pending;     // 1 = the last scan-related call was slgc_decode_dev: the slgc_triangulate_maps_dev / _wire_dev that follows completes a two-kernel
                             // scan and inherits its raggedness; a triangulation on its own reports only its own
     int tune_guard_list;    // fused scan: 1 = flat triangles compacted over the wave and redone 64 per pass (default), 0 = redone lane by lane
-    int tune_park;          // decode / fused kernels at N = 42, 44, 46: park the 12 threshold frames in LDS instead of fetching them twice
+    int tune_park;          // decode / fused kernels at N = 42, 44, 46, 50, 54: park the 12 threshold frames in LDS instead of fetching them twice
     int tune_fuse_abl;      // diagnostic build only: timing-only ablations of the fused kernel (wrong results)
     void *dl_stage;         // pinned ring the large device-to-host results land in (api.hip: download_par)
     hipEvent_t dl_ev[4];

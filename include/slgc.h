@@ -82,7 +82,7 @@ int slgc_last_input_path(slgc_ctx *ctx);
 /* Which kernels the last slgc_scan_dev / slgc_scan_batch_dev / slgc_cloud_dev call (or slgc_decode_dev + slgc_triangulate_maps_dev pair) on this context launched (slgc_scan_dev silently takes the two-kernel
  * path when a buffer is misaligned, the band is ragged, a count is requested or the mode asks for it): returns one of SLGC_PATH_* (or a
  * negative status).  Optional outputs: *ns_frames = the frames-per-run specialisation the decode / fused kernel was compiled for (42, 44,
- * 46; 0 = the generic kernel); *node_table = 1 if the triangulation read the every-4th-column camera table; *guard = 1 float32 fast form
+ * 46, 50, 54; 0 = the generic kernel); *node_table = 1 if the triangulation read the every-4th-column camera table; *guard = 1 float32 fast form
  * with the flat-triangle guard, 0 exact (acos / sin) mode.  bench.py reports its pipeline from this, not from its own arguments. */
 enum {
     SLGC_PATH_NONE = 0,
@@ -219,7 +219,7 @@ int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_
 /* slgc_scan_dev straight from the camera's BGR frames -- replaces the cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) + grey-stack fill of
  * src/3-capture_decode.py:66-70 together with :75 (get_codes) and src/4-triangulate.py:50-64.  d_bgr: uint8 [n_runs][N][rows][W][3] (OpenCV's
  * pixel order), plane_stride = BYTES between consecutive frames (>= 3 * rows * W), run_stride = bytes between runs; coeff_bits as slgc_to_gray.
- * With N = 42 / 44 / 46, 4-byte aligned planes, SLGC_TRI_ALGEBRAIC and no count: ONE kernel, the luma formed in registers inside the frame
+ * With N = 42 / 44 / 46 / 50 / 54 (what the reference's generator emits for projectors up to 1024 / 2048 / 2048 / 4096 / 8192 pixels), 4-byte aligned planes, SLGC_TRI_ALGEBRAIC and no count: ONE kernel, the luma formed in registers inside the frame
  * loads (3 N + 12 bytes per pixel; the grey stack never exists in HBM; slgc_last_scan_path = SLGC_PATH_FUSED_BGR).  Otherwise
  * slgc_to_gray_dev into scratch of the context + slgc_scan_dev.  Results bit-identical with that chain either way. */
 int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W, int row0,

@@ -16,7 +16,7 @@ extern "C" {
 /* ------------------------------------------------------------------ A/B knobs */
 /* slgc_tune (declared in slgc.h) -- the knobs for same-process A/B timing; no setting but the last one named here changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;
- * "park" 1 = at 42 / 44 / 46 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
+ * "park" 1 = at 42 / 44 / 46 / 50 / 54 frames the kernels park the 12 threshold frames in LDS instead of fetching them twice (default) /
  * 0 = generic kernels; "wire" 1 = slgc_scan_sharded_dev exchanges the maps in the 3-byte wire format / 0 = int16 (default;
  * experimental until measured on real xGMI); "fuse_nt" bit 0 XYZ, bit 1 maps non-temporal in the fused kernel (default -1: 1 from 4 Mpixels per launch up, 3 below);
  * "tri_nt" (1); "xcd" XCD-aware tile map of the dense triangulation kernel (1), "fuse_xcd" the same for the fused scan kernel (0 = off,

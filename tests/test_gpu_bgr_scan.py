@@ -69,6 +69,8 @@ CASES = [
     (260, 33, 42, 1, 12, 15, "s-uniform", True),
     (512, 96, 46, 1, 0, 14, "s-scene", True),
     (512, 96, 46, 2, 4, 14, "s-uniform", True),
+    (512, 96, 50, 1, 0, 15, "s-uniform", True),     # a 4K projector's frame count (L = 12)
+    (256, 64, 54, 2, 0, 15, "s-uniform", True),     # 8K (L = 13)
     (130, 31, 44, 1, 0, 15, "s-scene", False),      # 130 * 31 is not a multiple of 4 pixels
     (256, 64, 26, 1, 0, 15, "s-scene", False),      # no specialised kernel for 26 frames
     (256, 64, 44, 1, 2, 15, "s-scene", False),      # planes not 4-byte aligned

@@ -604,3 +604,44 @@ def test_issue_priorities_change_no_bit(ctx, workload):
     compare_scan(got[-1][0][0], got[-1][0][1], got[-1][1], ref_h, ref_v, ref_xyz, f"{workload} default priorities")
     for b in (stack, maps, xyz):
         b.free()
+
+
+@pytest.mark.parametrize("N,proj", [(50, (3840, 2160)), (54, (7680, 4320))])
+def test_4k_and_8k_projector_frame_counts_take_the_specialised_kernels(ctx, N, proj):
+    """The reference's generator emits 4 * ceil(log2(max(w, h))) + 2 frames (generate_codes.py:22-25,53): 50 for a 4K projector (L = 12 code
+    bits), 54 for 8K (L = 13).  Both have their own compiled specialisation of the decode / fused / BGR kernels (threshold frames parked in
+    LDS): every pixel of a 1920x1080 capture against the oracle -- fused, split, two runs -- and the executed path says which kernel ran."""
+    from scanner import _native
+    W, H = 1920, 1080
+    pw, ph = proj
+    calib = bench.calibration(W, H, pw, ph)
+    ctx.set_calibration(*calib)
+    px = W * H
+    stack = ctx.alloc(2 * N * px)
+    maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
+    L = (N - 2) // 4
+    for scene in ("s-scene", "s-uniform"):
+        if scene == "s-scene":                                                           # dense, smooth codes (the low bits) ...
+            ctx.synth_scene_dev(stack.at(0), px, N, H, W, seed=1, noise=3, shadow=True)
+            ctx.synth_scene_dev(stack.at(N * px), px, N, H, W, seed=2, noise=9, shadow=False)
+        else:                                                                            # ... and every byte random: arbitrary codes, every bit of the L in use
+            ctx.synth_uniform_dev(stack.at(0), px, N, H, W, seed=3)
+            ctx.synth_uniform_dev(stack.at(N * px), px, N, H, W, seed=4)
+        ctx.synchronize()
+        st = stack.download((2, N, H, W), np.uint8)
+        for n_runs in (1, 2):
+            ref_h, ref_v, ref_xyz = oc.scan_dense(st[0] if n_runs == 1 else st, (pw, ph), *calib)
+            if scene == "s-uniform":
+                assert int(ref_h.max()) >= (1 << (L - 1)) and int(ref_v.max()) >= (1 << (L - 1))       # the top code bit is in use
+            for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT):
+                maps.zero()
+                xyz.zero()
+                ctx.scan_dev(stack.ptr, n_runs, N * px, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2), mode=mode)
+                ctx.synchronize()
+                path = ctx.last_scan_path()
+                assert path["ns_frames"] == N and path["path"] == ("fused" if mode == _native.TRI_ALGEBRAIC else "split"), path
+                valid, worst = compare_scan(maps.download((H, W), np.int16), maps.download((H, W), np.int16, px * 2), xyz.download((H, W, 3), np.float32),
+                                            ref_h, ref_v, ref_xyz, f"N={N} {scene} runs={n_runs} mode={mode}")
+                assert valid > (0.5 if scene == "s-scene" else 0.05) * px
+    for b in (stack, maps, xyz):
+        b.free()

@@ -18,6 +18,9 @@ WORKLOADS = {
     "c3_4096x3000x46": (4096, 3000, 1920, 1200, 46),
     "c1_1280x720x42": (1280, 720, 1280, 800, 42),
     "c2_1920x1080x46": (1920, 1080, 1920, 1080, 46),
+    # a 4K / an 8K projector: the frame counts the reference's generator emits for them (generate_codes.py:22-25,53), specialised kernels since round 5
+    "c3_4096x3000x50": (4096, 3000, 3840, 2160, 50),
+    "c3_4096x3000x54": (4096, 3000, 7680, 4320, 54),
     # small test workloads (tests/test_gpu_rccl_multi.py): an odd height (ragged bands at any G) and an even one
     "t_516x1031x44": (516, 1031, 300, 200, 44),
     "t_512x1024x44": (512, 1024, 300, 200, 44),
