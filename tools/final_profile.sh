@@ -7,19 +7,20 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
+# (--sustained 1 on the --extras full / traced runs: the default 5.5 s leg is 45 000 launches -- 240 000 at 1920x1080 -- and the kernel traces must fit gpurun's 64 MB)
 # bench.py prints ONE compact line (kept as line_*.json) and writes the full report to --extras-file (kept as bench_*.json)
-python3 bench.py --extras full --extras-file "$out/bench_default.json" > "$out/bench_default.log" 2>&1
+python3 bench.py --extras full --sustained 1 --extras-file "$out/bench_default.json" > "$out/bench_default.log" 2>&1
 grep '^{' "$out/bench_default.log" | tail -1 > "$out/line_default.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --extras full --extras-file "$out/bench_under_rocprof.json" > "$out/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --extras full --sustained 1 --extras-file "$out/bench_under_rocprof.json" > "$out/bench_under_rocprof.log" 2>&1
 bash tools/pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 tail -3 "$out/pmc.log"
 # the other BASELINE configurations (physical scene = the default; the S-scene rides along as other_scene), 1920x1080 also under the kernel trace
 for w in c1_1280x720x42 c2_1920x1080x44 c3_4096x3000x46; do
-  python3 bench.py --workload $w --extras full --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_$w.json" 2>/dev/null | tail -1 > "$out/line_$w.json"
+  python3 bench.py --workload $w --extras full --sustained 1 --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_$w.json" 2>/dev/null | tail -1 > "$out/line_$w.json"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --extras full --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_c2_under_rocprof.json" > "$out/bench_c2_under_rocprof.log" 2>&1
-python3 bench.py --scene s-scene --extras full --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_sscene_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_sscene_headline.json"
-python3 bench.py --scene physical-survey --extras full --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_physical_survey_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_physical_survey_headline.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt_c2" -- python3 bench.py --workload c2_1920x1080x44 --extras full --sustained 1 --no-cpu-baseline --no-throughput-mode --extras-file "$out/bench_c2_under_rocprof.json" > "$out/bench_c2_under_rocprof.log" 2>&1
+python3 bench.py --scene s-scene --extras full --sustained 1 --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_sscene_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_sscene_headline.json"
+python3 bench.py --scene physical-survey --extras full --sustained 1 --no-cpu-baseline --no-throughput-mode --no-small-images --extras-file "$out/bench_physical_survey_headline.json" 2>/dev/null | grep '^{' | tail -1 > "$out/line_physical_survey_headline.json"
 # what the driver runs, five times in a row (wall seconds, line size; VERDICT r4: no leg whose mean and median differ by > 5 %)
 for i in 1 2 3 4 5; do
   t0=$(date +%s%N)
