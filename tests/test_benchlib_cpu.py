@@ -142,3 +142,15 @@ def test_launch_statistics_are_robust_to_one_slow_launch():
     st = launch_stats([0.1] * 19 + [10.0])
     assert st["median_launch_ms"] == 0.1 and st["max_launch_ms"] == 10.0 and st["outliers"] == 1
     assert launch_stats([0.1, 0.11, 0.12])["outliers"] == 0 and launch_stats([]) == {}
+
+
+def test_a_direct_exchange_child_that_dies_costs_an_error_entry_not_the_run(monkeypatch):
+    """N > 1: the direct exchange is timed in child processes (tools/benchlib/direct_child.py).  Here there is no GPU: the child cannot even
+    create its context -- the parent gets {"error": ...} with the child's exit code and the tail of its stderr, and goes on."""
+    import types
+
+    from benchlib import sharded_legs
+    args = types.SimpleNamespace(scene="physical", plane_pad=0)
+    monkeypatch.setenv("SLGC_BENCH_DIRECT_CHILD_TIMEOUT_S", "120")
+    got = sharded_legs.direct_children(args, 0, 2, 0, "cpu_test_key", (64, 48), (64, 48), 26, "hv24", 2, 0, 0x1234, 1, 3)
+    assert set(got) == {"error"} and "child of rank 0" in got["error"] and "exit code" in got["error"], got

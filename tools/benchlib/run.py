@@ -11,7 +11,7 @@ from .common import (BASELINE_CONFIG, HBM_PEAK_GBS, PREHEAT_S, ROOT, SCENES, STA
 from .cpu import cpu_baseline
 from .line import dump_line
 from .legs import ingest_leg, physical_accuracy, reference_product, small_image_legs, sustained_leg, throughput_batched, throughput_mode
-from .sharded_legs import sharded_report, verify_sharded
+from .sharded_legs import direct_children, sharded_report, verify_sharded
 
 
 def run_rank(args, rank, local_rank, world):
@@ -661,6 +661,13 @@ def run_rank(args, rank, local_rank, world):
                         json.dump(dict(out, sharded_alternatives=dict(alternatives), provisional=f"written before the {label} alternative ran"), f, indent=1)
                 except OSError:
                     pass
+            if impl == "direct" and args.exchange_impl != "direct" and os.environ.get("SLGC_BENCH_DIRECT_IN_PROCESS") != "1":
+                # ... and it runs in CHILD processes, one per rank (direct_child.py): a fault in a path that has never crossed a link takes a
+                # child down, not the rank that still owes the line
+                STAGE[0] = f"sharded alternatives: {label} (child processes)"
+                alternatives[label] = direct_children(args, rank, G, device, direct_key + "_child", (cam_w, cam_h), (proj_w, proj_h), N, sharded_scanner.wire,
+                                                      len(stacks), last_stack, main_digest, mode, max(5, args.steps // 2))
+                continue
             try:
                 STAGE[0] = f"sharded alternatives: {label}"
                 if impl == "direct":

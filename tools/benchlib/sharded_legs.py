@@ -1,4 +1,8 @@
 """bench.py: report and self-verification of the row-sharded scan (N > 1 or --force-sharded)."""
+import json
+import os
+import subprocess
+import sys
 import time
 
 import numpy as np
@@ -67,3 +71,25 @@ def verify_sharded(ctx, scanner, G, rank, N, cam_w, cam_h, proj_size, seed, plan
                     "stack, and its digest with every other rank's"}
 
 
+def direct_children(args, rank, G, device, key, cam, proj, N, wire, n_buffers, last_stack, main_digest, mode, steps):
+    """Every rank starts tools/benchlib/direct_child.py on its own GPU and waits for it (bounded); -> the child's report, or {"error": ...}.
+    Collective by construction: all ranks call this at the same point, the children meet each other through the direct exchange's segment."""
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "direct_child.py"), "--rank", str(rank), "--nranks", str(G),
+           "--device", str(device), "--key", key, "--cam", f"{cam[0]}x{cam[1]}", "--proj", f"{proj[0]}x{proj[1]}", "--frames", str(N), "--scene", args.scene,
+           "--wire", wire, "--buffers", str(n_buffers), "--plane-pad", str(args.plane_pad), "--steps", str(steps), "--last-stack", str(last_stack),
+           "--main-digest", f"{main_digest:016x}", "--mode", str(int(mode))]
+    limit = float(os.environ.get("SLGC_BENCH_DIRECT_CHILD_TIMEOUT_S", "60"))
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child of rank {rank} did not finish within {limit:.0f} s"}
+    except OSError as e:
+        return {"error": f"child of rank {rank} could not start: {e}"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        tail = " | ".join(ln for ln in r.stderr.strip().splitlines()[-3:])
+        return {"error": f"child of rank {rank}: exit code {r.returncode}; {tail[-300:]}"}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"child of rank {rank}: unreadable report ({e})"}
