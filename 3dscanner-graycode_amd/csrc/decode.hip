@@ -797,9 +797,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
         uint32_t ill = 0;
         if constexpr (GLIST) ill = triangulate4_flag(fx, fy, pth, valid, a.f.kf, out);      // pth holds the gathered tan(beta / 2)
         else triangulate4<!D::unguarded>(fx, fy, pth, valid, a.f.kf, a.f.T, a.f.t_len, out, a.f.cam_lut + off, a.f.proj_lut, idx);
-        s_buf[3 * t] = make_float4(out[0], out[1], out[2], out[3]);
-        s_buf[3 * t + 1] = make_float4(out[4], out[5], out[6], out[7]);
-        s_buf[3 * t + 2] = make_float4(out[8], out[9], out[10], out[11]);
+        stage_xyz12(s_buf + 3 * t, out);
         if constexpr (GLIST) {
             // Flat triangles (tri_math.h: error amplification > kGuardAmp) are redone on the reference's float32 intermediates in float64.  A lane-level
             // loop makes the whole wave walk that path once per flagged POSITION (up to 4 times, each for a handful of lanes -- and scattered

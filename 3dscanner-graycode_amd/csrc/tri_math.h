@@ -281,6 +281,21 @@ __device__ __forceinline__ uint32_t proj_lut_index(int pu, int pv, int tiles_x, 
                 : (((row + (uint32_t)(pu >> 3)) << 6) | (in_y << 3) | (uint32_t)(pu & 7));
 }
 
+// A lane's 12 floats of XYZ into the LDS staging block as three WHOLE 16-byte stores.  Left to itself the compiler writes the 48 bytes as one
+// ds_write_b96 and four or five ds_write2_b32 (whatever pairs become ready together); a dword store is banked over 32 lanes and 32 banks, and with
+// lanes 12 dwords apart only 8 distinct banks come up -- 4-way conflicts, 54 of the 166 LDS cycles a wave of the fused kernel spent (round 5:
+// SQ_LDS_BANK_CONFLICT 2 592 000 per launch at 4096x3000, the same number in the dense kernel).  ds_write_b128 is banked over 8 contiguous lanes:
+// 12 i mod 32 is distinct for i = 0..7 -- conflict-free.  One vector store each through an LDS-address-space pointer keeps them whole.
+typedef float lds_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_v4f *lds_v4f_ptr;
+__device__ __forceinline__ void stage_xyz12(float4 *slot, const float (&out)[12])      // slot: 16-byte aligned, in LDS
+{
+    lds_v4f_ptr q = (lds_v4f_ptr)slot;
+    q[0] = lds_v4f{out[0], out[1], out[2], out[3]};
+    q[1] = lds_v4f{out[4], out[5], out[6], out[7]};
+    q[2] = lds_v4f{out[8], out[9], out[10], out[11]};
+}
+
 // Ordering point for data exchanged through LDS between the lanes of ONE wave: LDS operations of a wave execute in program
 // order, so no s_barrier is needed -- only the compiler must not move the reads above the writes.
 __device__ __forceinline__ void wave_lds_sync()

@@ -394,9 +394,7 @@ __global__ void __launch_bounds__(256) k_triangulate_maps_lds(const TriConst tc,
         ill = triangulate4_flag(cx, cy, px, valid, tc.kf, out);          // px holds the gathered tan(beta / 2)
         if (MODE == 2) ill = 0;                                          // MODE 2: unguarded (A/B, diagnostic build)
     }
-    s_buf[3 * tid] = make_float4(out[0], out[1], out[2], out[3]);
-    s_buf[3 * tid + 1] = make_float4(out[4], out[5], out[6], out[7]);
-    s_buf[3 * tid + 2] = make_float4(out[8], out[9], out[10], out[11]);
+    stage_xyz12(s_buf + 3 * tid, out);
     if constexpr (MODE != SLGC_TRI_EXACT) {
         // Flat triangles (tri_math.h) are redone in float64 on the reference's float32 intermediates.  Like the fused scan kernel this one compacts
         // them first -- here over the whole WORKGROUP, which exchanges through LDS anyway: ballots + per-wave counts rank the flagged pixels of the
