@@ -53,6 +53,8 @@ for label, key in (("fused physical", "k_decode_pk<4, 128, 1, false, 0, 3, 44, 0
     if "SQ_ACTIVE_INST_VALU" in pm[k] and "GRBM_GUI_ACTIVE" in pm[k]:
         va, gui = pm[k]["SQ_ACTIVE_INST_VALU"]["mean"] * 4 / 1024, pm[k]["GRBM_GUI_ACTIVE"]["mean"] / 8
         extra = f"; VALU busy {va / 1e3:.0f} k of {gui / 1e3:.0f} k cycles = {va / gui:.2f}"
+    if "SQ_LDS_BANK_CONFLICT" in pm[k] and "SQ_LDS_IDX_ACTIVE" in pm[k]:
+        extra += f"; LDS bank-conflict cycles {pm[k]['SQ_LDS_BANK_CONFLICT']['mean']:.0f} of {pm[k]['SQ_LDS_IDX_ACTIVE']['mean'] / 1e6:.2f} M LDS-array cycles"
     print(f"PMC {label}: FETCH_SIZE {F:.0f} KB x2 + WRITE_SIZE {Wr:.0f} KB = {(2 * F + Wr) * 1024 / 1e6:.1f} MB per launch (n={pm[k]['FETCH_SIZE']['n']}){extra}")
 for name, row in j.get("scenes", {}).items():
     print(f"scene {name}: fused {row['avg_launch_ms'] * 1e3:.1f} us frac {row['frac']:.3f} ({row['fused_time_over_s_scene']} x S-scene), valid {row['valid_pixels_per_scan']}, flagged {row['guard_flagged_pixels']}, "
