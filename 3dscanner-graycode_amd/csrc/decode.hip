@@ -474,7 +474,7 @@ constexpr int kWaveListBytes = 256;     // FUSE == 3: the wave's list of flat pi
 // OpenCV's 8-bit luma in registers -- the grey stack of src/3-capture_decode.py:66-70 never exists in HBM.  Raw frames in flight are three
 // registers each: 4 waves per SIMD (<= 128 VGPRs), every wave with three times the bytes in flight.
 template <int PX, int BLOCK, int NT, bool MULTI, int ABL = 0, int FUSE = 0, int NS = 0, int BGR = 0>
-__global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC_MIN_WAVES) : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
+__global__ void __launch_bounds__(BLOCK, (PX == 4 && (ABL == 0 || (ABL == 3 && NS != 0))) ? (BGR ? 4 : SLGC_MIN_WAVES) : 1) k_decode_pk(const PkArgs a)      // 4 px / lane: 8 waves per SIMD (<= 64 VGPRs)
 {
     constexpr int NW = PX / 4;      // dwords per lane per frame
     constexpr int NR = BGR ? 3 : NW;      // ... as loaded
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && ABL == 0) ? (BGR ? 4 : SLGC
     constexpr bool SPEC = NS > 0;
     using D = Diag<ABL>;
     using FS = FrameSpec<SPEC ? NS : 14>;
-    static_assert(!SPEC || (NW == 1 && FUSE != 1 && ABL == 0), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations");
+    static_assert(!SPEC || (NW == 1 && FUSE != 1 && (ABL == 0 || ABL == 3)), "the specialised kernel is 4 pixels per lane, wave-local tail, no ablations but the cheap thresholds");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(FUSE != 0 || SPEC) ? (BLOCK / 64) * (kWaveLdsBytes + (FUSE == 3 ? kWaveListBytes : 0)) : 16];
     uint32_t *const park = reinterpret_cast<uint32_t *>(s_raw + (threadIdx.x >> 6) * kWaveLdsBytes) + (threadIdx.x & 63);   // + slot * 64
     uint32_t bid = FUSE != 0 ? (a.f.xcd_run ? xcd_block_fine(blockIdx.x, a.f.xcd_run, gridDim.x) : xcd_block(blockIdx.x, a.f.xcd_chunk)) : blockIdx.x;   // fused scan: optional XCD-aware tile maps (A/B)
@@ -1127,8 +1127,11 @@ static int launch_pk_t(slgc_ctx *ctx, const PkArgs &a, int abl = 0)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 1>), dim3(blocks), dim3(BLOCK), a);
     else if (abl == 2)
         SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 2>), dim3(blocks), dim3(BLOCK), a);
-    else if (abl == 3)
-        SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), a);
+    else if (abl == 3) {
+        // (the NS = 44 specialisation with the integer stand-in, when the launch would have taken it: the fair partner of the product kernel)
+        if (PX == 4 && BLOCK == 128 && NT == 1 && spec_frames(ctx, a.g) == 44) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 3, 0, 44>), dim3(blocks), dim3(128), a);
+        else SLGC_LAUNCH(ctx, (k_decode_pk<PX, BLOCK, NT, false, 3>), dim3(blocks), dim3(BLOCK), a);
+    }
     else
 #else
     if (abl != 0) return slgc_fail(ctx, SLGC_EINVAL, "ablation variants exist only in the diagnostic build (make -C 3dscanner-graycode_amd diag)");
@@ -1223,7 +1226,8 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     const bool wave = b.f.wave_tail != 0;
 #ifdef SLGC_DIAG      // timing-only ablation builds (wrong results on purpose): only in lib/libslgc_diag.so (make diag)
     const int fabl = ctx->tune_fuse_abl;
-    if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, 2>), dim3(blocks), dim3(128), b);
+    if (fabl == 3 && wave && spec_frames(ctx, g) == 44) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 3, 3, 44>), dim3(blocks), dim3(128), b);
+    else if (fabl == 5) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 5, 2>), dim3(blocks), dim3(128), b);
     else if (fabl == 6) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 6, 2>), dim3(blocks), dim3(128), b);
     else if (fabl == 7) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 7, 2>), dim3(blocks), dim3(128), b);
     else if (fabl == 8) SLGC_LAUNCH(ctx, (k_decode_pk<4, 128, 1, false, 8, 2>), dim3(blocks), dim3(128), b);
