@@ -100,7 +100,6 @@ print({k: (v["hbm_bytes_per_launch"], round(v["hbm_bytes_per_launch"] / (alg[k.s
 try:
     print(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats_by_grid.py"), newest("kt_c2/**/*kernel_trace.csv"),
                           os.path.join(dst, f"{tag}_kernel_stats_by_grid_c2_1920x1080x44.csv")], capture_output=True, text=True).stdout.split("k_synth")[0])
-    shutil.copy(os.path.join(src, "bench_c2_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_c2_1920x1080x44_under_rocprof.json"))
 except (ValueError, IndexError, OSError) as e_:
     print("no 1920x1080 kernel trace", e_)
 for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_stats_list_stage")):
