@@ -787,6 +787,64 @@ extern "C" int slgc_frame_diff_counts_dev(slgc_ctx *ctx, const void *d_frames, i
 }
 
 // ------------------------------------------------------------------------------------------ whole pipeline, one upload
+// Steps 2-4 of the device-resident chain shared by slgc_pipeline_count and slgc_compute_count: from int64 maps already in HBM to the lists of
+// get_cam_proj_pts (slot 8), the float64 (3,M) points of triangulate (slot 9) and, with a threshold, the kept points / colours of filter_3d_pts
+// (slot 10).  Leaves the pipe_* bookkeeping that slgc_pipeline_fetch reads; synchronises (the two list lengths are needed on the host).
+static int lists_tri_filter(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,
+                            const uint8_t *white_rgb, int order, int mode, double threshold)
+{
+    int rc;
+    const size_t npix = (size_t)cam_w * cam_h;
+    // 2. correspondences (slot 8: colours | cam | proj), colour source in slot 1
+    void *d_white = nullptr, *d_corr, *d_total;
+    if ((rc = slgc_ws(ctx, 8, npix * (8 + 8 + (white_rgb ? 24 : 0)) + 64, &d_corr))) return rc;
+    if ((rc = slgc_ws(ctx, 7, 64, &d_total))) return rc;
+    if (white_rgb) {
+        if ((rc = slgc_ws(ctx, 1, npix * 3, &d_white))) return rc;
+        if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_white, white_rgb, npix * 3, hipMemcpyHostToDevice, ctx->stream));
+    }
+    double *d_colors = (double *)d_corr;
+    float *d_cam = (float *)((char *)d_corr + (white_rgb ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
+    if ((rc = launch_correspond(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, (const uint8_t *)d_white, order, d_cam, d_proj, d_colors,
+                                (unsigned long long *)d_total)))
+        return rc;
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // 3. triangulate (slot 9: xyz (3,M) float64)
+    void *d_xyz;
+    if ((rc = slgc_ws(ctx, 9, (size_t)total * 24, &d_xyz))) return rc;
+    if ((rc = launch_triangulate_list(ctx, d_cam, d_proj, (int64_t)total, mode, (double *)d_xyz))) return rc;
+    ctx->pipe_M_raw = (int64_t)total;
+    ctx->pipe_npix = npix;
+    ctx->pipe_colors = white_rgb != nullptr;
+    ctx->pipe_filtered = false;
+    ctx->pipe_M = (int64_t)total;
+    // 4. optional box filter (slot 10: xyz' | colours')
+    if (!std::isnan(threshold)) {
+        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, nullptr, nullptr,
+                                (unsigned long long *)d_total, 0)))
+            return rc;
+        unsigned long long kept = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        void *d_f;
+        if ((rc = slgc_ws(ctx, 10, (size_t)kept * (24 + (white_rgb ? 24 : 0)), &d_f))) return rc;
+        double *d_fx = (double *)d_f, *d_fc = white_rgb ? d_fx + 3 * (size_t)kept : nullptr;
+        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, d_fx, d_fc,
+                                (unsigned long long *)d_total, 1)))
+            return rc;
+        ctx->pipe_filtered = true;
+        ctx->pipe_M = (int64_t)kept;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pend_M = -1;
+    ctx->filt_M = -1;
+    ctx->pipe_gen[0] = ctx->ws_gen[3]; ctx->pipe_gen[1] = ctx->ws_gen[8]; ctx->pipe_gen[2] = ctx->ws_gen[9]; ctx->pipe_gen[3] = ctx->ws_gen[10];
+    return SLGC_OK;
+}
+
+
 // Driver glue of the reference in one device-resident pass: src/3-capture_decode.py:75-100 (get_codes per run, merge,
 // gray_to_decimal) followed by src/4-triangulate.py:50-71 (get_cam_proj_pts, triangulate, filter_3d_pts).
 extern "C" int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int dtype, int n_runs, int N, int H, int W, double eps,
@@ -824,54 +882,62 @@ extern "C" int slgc_pipeline_count(slgc_ctx *ctx, const void *const *stacks, int
                                    nullptr, d_h, d_v);
     }
     if (rc) return rc;
-    // 2. correspondences (slot 8: colours | cam | proj), colour source in slot 1
-    void *d_white = nullptr, *d_corr, *d_total;
-    if ((rc = slgc_ws(ctx, 8, npix * (8 + 8 + (white_rgb ? 24 : 0)) + 64, &d_corr))) return rc;
-    if ((rc = slgc_ws(ctx, 7, 64, &d_total))) return rc;
-    if (white_rgb) {
-        if ((rc = slgc_ws(ctx, 1, npix * 3, &d_white))) return rc;
-        if (npix) HIP_TRY(ctx, hipMemcpyAsync(d_white, white_rgb, npix * 3, hipMemcpyHostToDevice, ctx->stream));
-    }
-    double *d_colors = (double *)d_corr;
-    float *d_cam = (float *)((char *)d_corr + (white_rgb ? npix * 24 : 0)), *d_proj = d_cam + 2 * npix;
-    if ((rc = launch_correspond(ctx, d_h, d_v, W, H, proj_w, proj_h, (const uint8_t *)d_white, order, d_cam, d_proj, d_colors,
-                                (unsigned long long *)d_total)))
-        return rc;
-    unsigned long long total = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // 3. triangulate (slot 9: xyz (3,M) float64)
-    void *d_xyz;
-    if ((rc = slgc_ws(ctx, 9, (size_t)total * 24, &d_xyz))) return rc;
-    if ((rc = launch_triangulate_list(ctx, d_cam, d_proj, (int64_t)total, mode, (double *)d_xyz))) return rc;
-    ctx->pipe_M_raw = (int64_t)total;
-    ctx->pipe_npix = npix;
-    ctx->pipe_colors = white_rgb != nullptr;
-    ctx->pipe_filtered = false;
-    ctx->pipe_M = (int64_t)total;
-    // 4. optional box filter (slot 10: xyz' | colours')
-    if (!std::isnan(threshold)) {
-        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, nullptr, nullptr,
-                                (unsigned long long *)d_total, 0)))
-            return rc;
-        unsigned long long kept = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        void *d_f;
-        if ((rc = slgc_ws(ctx, 10, (size_t)kept * (24 + (white_rgb ? 24 : 0)), &d_f))) return rc;
-        double *d_fx = (double *)d_f, *d_fc = white_rgb ? d_fx + 3 * (size_t)kept : nullptr;
-        if ((rc = launch_filter(ctx, (const double *)d_xyz, white_rgb ? d_colors : nullptr, (int64_t)total, threshold, d_fx, d_fc,
-                                (unsigned long long *)d_total, 1)))
-            return rc;
-        ctx->pipe_filtered = true;
-        ctx->pipe_M = (int64_t)kept;
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pend_M = -1;
-    ctx->filt_M = -1;
-    ctx->pipe_gen[0] = ctx->ws_gen[3]; ctx->pipe_gen[1] = ctx->ws_gen[8]; ctx->pipe_gen[2] = ctx->ws_gen[9]; ctx->pipe_gen[3] = ctx->ws_gen[10];
+    if ((rc = lists_tri_filter(ctx, d_h, d_v, W, H, proj_w, proj_h, white_rgb, order, mode, threshold))) return rc;
     *M = ctx->pipe_M;
     return SLGC_OK;
+}
+
+// Triangulation.compute() of the drop-in class (the fused entry BASELINE.json's north star names): what src/4-triangulate.py:62-71 does with a
+// Triangulate object -- get_cam_proj_pts (triangulate.py:39-71), triangulate (:73-97), filter_3d_pts (:99-122) -- as ONE upload, the same three
+// kernels the three host entry points launch (bit-identical results by construction), and ONE download of what the script keeps.
+extern "C" int slgc_compute_count(slgc_ctx *ctx, const int64_t *h_pixels, const int64_t *v_pixels, int cam_w, int cam_h, int proj_w, int proj_h,
+                                  const uint8_t *white_rgb, int order, int mode, double threshold, int64_t *M, int64_t *M_unfiltered)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->pipe_M = -1;
+    if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
+    if (!h_pixels || !v_pixels || !M) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
+    if (cam_w < 0 || cam_h < 0 || (order != SLGC_ORDER_X && order != SLGC_ORDER_ROW)) return slgc_fail(ctx, SLGC_EINVAL, "bad size / order");
+    if (mode != SLGC_TRI_EXACT && mode != SLGC_TRI_ALGEBRAIC) return slgc_fail(ctx, SLGC_EINVAL, "bad mode");
+    const size_t npix = (size_t)cam_w * cam_h;
+    void *d_maps;
+    if ((rc = slgc_ws(ctx, 3, npix * 16, &d_maps))) return rc;
+    int64_t *d_h = (int64_t *)d_maps, *d_v = d_h + npix;
+    ctx->last_input_path = 2;
+    static const int pack = xcd_env("SLGC_I64_PACK", 1);          // 0: always ship int64 (A/B of the narrowing)
+    bool narrowed = false;
+    if (npix && pack) {          // the maps hold -1 or a projector coordinate: 2 of their 8 bytes cross the link, narrowed by host threads into pinned memory
+        void *st;
+        if ((rc = host_staging(ctx, npix * 4, &st))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));          // the staging buffer may still feed the previous call's copy
+        const int64_t *maps[2] = {h_pixels, v_pixels};
+        const int ok = slgc_host::narrow_i64_to_i16(maps, 2, npix, (int16_t *)st);
+        if (ok < 0) return slgc_fail(ctx, SLGC_ENOMEM, "host threads for the int64 -> int16 narrowing");
+        if (ok) {
+            void *d16;
+            if ((rc = slgc_ws(ctx, 2, npix * 4, &d16))) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(d16, st, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+            if ((rc = launch_widen_maps(ctx, (const int16_t *)d16, (const int16_t *)d16 + npix, npix, d_h, d_v))) return rc;
+            narrowed = true;
+            ctx->last_input_path = 1;
+        }
+    }
+    if (npix && !narrowed) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_h, h_pixels, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_v, v_pixels, npix * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = lists_tri_filter(ctx, d_h, d_v, cam_w, cam_h, proj_w, proj_h, white_rgb, order, mode, threshold))) return rc;
+    *M = ctx->pipe_M;
+    if (M_unfiltered) *M_unfiltered = ctx->pipe_M_raw;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_pixels, double *xyz, double *colors, int64_t *M_unfiltered,
+                                   float *cam_pts, float *proj_pts);
+extern "C" int slgc_compute_fetch(slgc_ctx *ctx, double *xyz, double *colors)
+{
+    return slgc_pipeline_fetch(ctx, nullptr, nullptr, xyz, colors, nullptr, nullptr, nullptr);
 }
 
 extern "C" int slgc_pipeline_fetch(slgc_ctx *ctx, int64_t *h_pixels, int64_t *v_pixels, double *xyz, double *colors, int64_t *M_unfiltered,

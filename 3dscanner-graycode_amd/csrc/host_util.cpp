@@ -70,6 +70,64 @@ int narrow_f64_to_u8(const void *const *stacks, int n_runs, size_t elems, uint8_
     }
 }
 
+int narrow_i64_to_i16(const int64_t *const *maps, int n_maps, size_t elems, int16_t *dst, int max_threads, size_t chunk_values)
+{
+    try {
+        const size_t total = elems * (size_t)n_maps;
+        if (total == 0) return 1;
+        if (chunk_values == 0) chunk_values = 1;
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nthr = hw ? hw : 4;
+        if (max_threads < 1) max_threads = 1;
+        if (nthr > (size_t)max_threads) nthr = (size_t)max_threads;
+        const size_t nchunks = (total + chunk_values - 1) / chunk_values;
+        if (nthr > nchunks) nthr = nchunks;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&]() {
+            for (;;) {
+                const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+                if (c >= nchunks || bad.load(std::memory_order_relaxed)) return;
+                const size_t lo = c * chunk_values, hi = lo + chunk_values < total ? lo + chunk_values : total;
+                size_t i = lo;
+                while (i < hi) {
+                    const size_t m = i / elems, off = i - m * elems;
+                    const size_t n = (hi - i) < (elems - off) ? (hi - i) : (elems - off);     // stay inside map m
+                    const int64_t *src = maps[m] + off;
+                    int16_t *out = dst + i;
+                    uint64_t wrong = 0;
+                    for (size_t k = 0; k < n; ++k) {
+                        const int64_t x = src[k];
+                        out[k] = (int16_t)x;
+                        wrong |= ((uint64_t)x + 32768u) >> 16;                                // non-zero iff x is outside [-32768, 32767]
+                    }
+                    if (wrong) {
+                        bad.store(true, std::memory_order_relaxed);
+                        return;
+                    }
+                    i += n;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        pool.reserve(nthr);
+        struct Joiner {
+            std::vector<std::thread> &p;
+            ~Joiner()
+            {
+                for (auto &t : p)
+                    if (t.joinable()) t.join();
+            }
+        } joiner{pool};
+        for (size_t t = 1; t < nthr; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        return bad.load() ? 0 : 1;
+    } catch (...) {
+        return -1;
+    }
+}
+
 int ring_download(void *dst, size_t bytes, void *stage_v, size_t chunk, int slots, int parts, int nthr, const RingOps &ops, int copy)
 {
     if (bytes == 0) return 0;

@@ -12,6 +12,12 @@ namespace slgc_host {
 // first thread to see one stops the others, dst is garbage); -1 = a thread or an allocation could not be made (nothing thrown across the C-ABI).
 int narrow_f64_to_u8(const void *const *stacks, int n_runs, size_t elems, uint8_t *dst, int max_threads = 16, size_t chunk_samples = 1u << 20);
 
+// Triangulate's h_pixels / v_pixels are int64 arrays (decode_codes.py:134-146 builds them with np.zeros(..., dtype=int)) whose values are -1 or a
+// projector coordinate.  Writes n_maps maps of `elems` int64 each as int16 into dst (dst[m * elems + i]) on host threads while checking that
+// every value survives the narrowing (-32768 .. 32767).  Returns 1 = dst holds all values; 0 = some value does not fit (dst is garbage; the
+// caller ships int64); -1 = thread / allocation failure.
+int narrow_i64_to_i16(const int64_t *const *maps, int n_maps, size_t elems, int16_t *dst, int max_threads = 16, size_t chunk_values = 1u << 20);
+
 // The transport behind the staging ring of a large device-to-host result: HIP in the library (hipMemcpyAsync into a pinned slot + an event),
 // plain memcpy in the CPU tests.  Both return 0 on success.
 struct RingOps {

@@ -57,6 +57,8 @@ SIGNATURES = {
     "slgc_undistort_points": (_i, [_vp, _i, _vp, _i64, _vp]),
     "slgc_filter_count": (_i, [_vp, _vp, _vp, _i64, _d, C.POINTER(_i64)]),
     "slgc_filter_fetch": (_i, [_vp, _vp, _vp]),
+    "slgc_compute_count": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _d, C.POINTER(_i64), C.POINTER(_i64)]),
+    "slgc_compute_fetch": (_i, [_vp, _vp, _vp]),
     "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slgc_to_gray_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
     "slgc_frame_diff_counts": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
@@ -527,6 +529,29 @@ class Context:
         co = None if c is None else _out((kept.value, 3), np.float64)
         self._ck(lib().slgc_filter_fetch(self._h, _ptr(xo), _ptr(co)))
         return xo, co
+
+    def compute(self, h_pixels, v_pixels, cam_size, proj_size, img_white=None, threshold=None, order=ORDER_X, mode=TRI_EXACT):
+        """get_cam_proj_pts -> triangulate -> filter_3d_pts (triangulate.py:39-122) as one device-resident chain (slgc_compute_count /
+        _fetch; set_calibration first): one upload of the maps (int16 on the link when they fit) and the white image, one download of
+        the kept points (3,M) float64 and colours [M,3] float64 (None without img_white).  Returns (pts, colors, n_unfiltered)."""
+        cw, ch = int(cam_size[0]), int(cam_size[1])
+        h = np.ascontiguousarray(np.asarray(h_pixels)[:ch, :cw], dtype=np.int64)
+        v = np.ascontiguousarray(np.asarray(v_pixels)[:ch, :cw], dtype=np.int64)
+        if h.shape != (ch, cw) or v.shape != (ch, cw):
+            raise ValueError("h_pixels / v_pixels smaller than cam_size")
+        wh = None
+        if img_white is not None:
+            wh = np.ascontiguousarray(np.asarray(img_white)[:ch, :cw, :3], dtype=np.uint8)
+            if wh.shape != (ch, cw, 3):
+                raise ValueError("img_white must be [H,W,3]")
+        M, raw = C.c_int64(), C.c_int64()
+        thr = float("nan") if threshold is None else float(threshold)
+        self._ck(lib().slgc_compute_count(self._h, _ptr(h), _ptr(v), cw, ch, int(proj_size[0]), int(proj_size[1]), _ptr(wh), int(order),
+                                          int(mode), thr, C.byref(M), C.byref(raw)))
+        pts = _out((3, M.value), np.float64)
+        col = _out((M.value, 3), np.float64) if wh is not None else None
+        self._ck(lib().slgc_compute_fetch(self._h, _ptr(pts), _ptr(col)))
+        return pts, col, int(raw.value)
 
     def to_gray(self, images, coeff_bits=15):
         im = np.ascontiguousarray(np.asarray(images).astype(np.uint8, copy=False))

@@ -81,9 +81,24 @@ class Triangulate(object):
 
 
 class Triangulation(Triangulate):
-    """``Triangulate`` plus a fused ``compute()``: correspondences -> XYZ (-> box filter)."""
+    """``Triangulate`` plus the fused ``compute()``: correspondences -> XYZ (-> box filter) in ONE device-resident call."""
 
     def compute(self, img_white=None, threshold=None, exact=True, order="x"):
+        """What src/4-triangulate.py:62-71 does with a ``Triangulate`` -- ``get_cam_proj_pts(img_white)`` (triangulate.py:39-71), then
+        ``triangulate`` (:73-97), then, with a ``threshold``, ``filter_3d_pts`` (:99-122) -- as one call: the maps go up once, the three
+        kernels of the three methods run back to back in HBM, the kept points and colours come down once (slgc_compute_count / _fetch).
+        Returns ``(pts, colors)`` exactly as the three-call composition does: float64 (3,M) x-major, float64 [M,3] or None; bit-identical
+        to it (same kernels, same order).  ``compute_by_calls`` is that composition, kept for comparison."""
+        self._send_calibration()
+        o = _native.ORDER_X if order == "x" else _native.ORDER_ROW
+        pts, colors, n_raw = self._context().compute(self.h_pixels, self.v_pixels, (self.cam_w, self.cam_h), (self.proj_w, self.proj_h),
+                                                     img_white, threshold, o, _native.TRI_EXACT if exact else _native.TRI_ALGEBRAIC)
+        if n_raw == 0 and colors is not None:
+            colors = colors.reshape(0)          # the reference's empty colour array has shape (0,) (triangulate.py:66-69), and :121 keeps it
+        return pts, colors
+
+    def compute_by_calls(self, img_white=None, threshold=None, exact=True, order="x"):
+        """The three methods one after the other (three host round trips): the definition ``compute`` is tested against."""
         cam_pts, proj_pts, colors = self.get_cam_proj_pts(img_white, order=order)
         pts = self.triangulate(cam_pts, proj_pts, exact=exact)
         if threshold is not None:

@@ -76,7 +76,8 @@ int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
  * integers in [0,255] (what src/3-capture_decode.py:66-70 builds), narrowed to uint8 on host threads into pinned staging and
  * uploaded as 1 byte per sample; 2 = float64 shipped as it is (a fraction / negative / NaN was found) and decoded by the float64
- * kernel.  Results are identical on all three. */
+ * kernel.  Results are identical on all three.  slgc_compute_count reports its int64 maps the same way: 1 = narrowed to int16 on host threads
+ * (every value fits), 2 = shipped as int64. */
 int slgc_last_input_path(slgc_ctx *ctx);
 
 /* Which kernels the last slgc_scan_dev / slgc_scan_batch_dev / slgc_cloud_dev call (or slgc_decode_dev + slgc_triangulate_maps_dev pair) on this context launched (slgc_scan_dev silently takes the two-kernel
@@ -157,6 +158,16 @@ int slgc_undistort_points(slgc_ctx *ctx, int which, const float *pts, int64_t M,
 /* filter_3d_pts(Pts, colors, threshold) -- triangulate.py:99-122.  _count then _fetch (order preserved). */
 int slgc_filter_count(slgc_ctx *ctx, const double *xyz, const double *colors, int64_t M, double threshold, int64_t *kept);
 int slgc_filter_fetch(slgc_ctx *ctx, double *xyz_out, double *colors_out);
+
+/* Triangulation.compute() -- the fused call BASELINE.json's north star names for the drop-in class: what src/4-triangulate.py:62-71 does with a
+ * Triangulate object (get_cam_proj_pts :39-71 -> triangulate :73-97 -> filter_3d_pts :99-122) as one device-resident chain.  The int64 maps
+ * cross the link ONCE, as int16 when every value fits (narrowed by host threads into pinned memory; otherwise as they are); the same three
+ * kernels as the three entry points above run back to back in HBM (results bit-identical to calling them one after the other); only what the
+ * script keeps comes back: _count returns M = points kept (and the unfiltered list length), _fetch copies out xyz float64 (3,M) and colours
+ * float64 [M][3] (NULL when white_rgb was NULL).  threshold = NaN: no box filter.  Needs slgc_set_calibration. */
+int slgc_compute_count(slgc_ctx *ctx, const int64_t *h_pixels, const int64_t *v_pixels, int cam_w, int cam_h, int proj_w, int proj_h,
+                       const uint8_t *white_rgb, int order, int mode, double threshold, int64_t *M, int64_t *M_unfiltered);
+int slgc_compute_fetch(slgc_ctx *ctx, double *xyz, double *colors);
 
 /* ------------------------------------------------------------------ ingest (the frames either side of the path) */
 

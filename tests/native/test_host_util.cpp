@@ -65,6 +65,43 @@ static void test_narrow()
                 }
 }
 
+// ---------------------------------------------------------------- narrow_i64_to_i16
+static void test_narrow_maps()
+{
+    unsigned seed = 11;
+    for (int n_maps = 1; n_maps <= 2; ++n_maps)
+        for (size_t elems : {(size_t)0, (size_t)1, (size_t)63, (size_t)1000, (size_t)4099})
+            for (size_t chunk : {(size_t)1, (size_t)7, (size_t)1000, (size_t)(1u << 20)})
+                for (int thr : {1, 2, 5, 16}) {
+                    if (g_light && (elems == 1 || elems == 63 || chunk == 1 || thr == 1 || thr == 16)) continue;
+                    std::vector<std::vector<int64_t>> maps((size_t)n_maps, std::vector<int64_t>(elems));
+                    std::vector<const int64_t *> ptrs;
+                    for (auto &m : maps) {
+                        for (auto &x : m) x = (int64_t)(rnd(seed) >> 16) - 32768;            // the whole int16 range, -1 included
+                        ptrs.push_back(m.data());
+                    }
+                    if (elems) { maps[0][0] = -32768; maps[(size_t)n_maps - 1][elems - 1] = 32767; }
+                    std::vector<int16_t> dst(elems * (size_t)n_maps + 1, (int16_t)0x5A5A);
+                    CHECK(slgc_host::narrow_i64_to_i16(ptrs.data(), n_maps, elems, dst.data(), thr, chunk) == 1);
+                    bool same = true;
+                    for (int m = 0; m < n_maps; ++m)
+                        for (size_t i = 0; i < elems; ++i) same &= (int64_t)dst[(size_t)m * elems + i] == maps[(size_t)m][i];
+                    CHECK(same);
+                    CHECK(dst.back() == (int16_t)0x5A5A);
+                    if (elems == 0) continue;
+                    const int64_t bads[] = {32768, -32769, (int64_t)1 << 16, (int64_t)1 << 40, std::numeric_limits<int64_t>::max(),
+                                            std::numeric_limits<int64_t>::min(), -((int64_t)1 << 16) - 1, ((int64_t)1 << 32) - 1};
+                    for (int64_t bad : bads)
+                        for (size_t pos : {(size_t)0, elems / 2, elems - 1}) {
+                            const int m = (int)(rnd(seed) % (unsigned)n_maps);
+                            const int64_t keep = maps[(size_t)m][pos];
+                            maps[(size_t)m][pos] = bad;
+                            CHECK(slgc_host::narrow_i64_to_i16(ptrs.data(), n_maps, elems, dst.data(), thr, chunk) == 0);
+                            maps[(size_t)m][pos] = keep;
+                        }
+                }
+}
+
 // ---------------------------------------------------------------- ring_download against a memcpy "device"
 struct FakeDevice {
     const char *src;
@@ -160,6 +197,7 @@ int main(int argc, char **argv)
 {
     g_light = argc > 1 && std::strcmp(argv[1], "light") == 0;
     test_narrow();
+    test_narrow_maps();
     test_ring();
     if (g_failed) {
         std::fprintf(stderr, "%d check(s) failed\n", g_failed);

@@ -16,6 +16,7 @@ import bench  # noqa: E402
 from scanner import _native  # noqa: E402
 from scanner.grayCode.decode_codes import codes_to_pixels, get_codes  # noqa: E402
 from scanner.triangulation import Triangulate  # noqa: E402
+from scanner.triangulation.triangulate import Triangulation  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="c3_4096x3000x44")
@@ -50,10 +51,17 @@ for rep in range(8):
     cam, proj, col = clock("get_cam_proj_pts(img_white)             4:62", lambda: tri.get_cam_proj_pts(white), times)
     pts = clock("triangulate(cam_pts, proj_pts)          4:63", lambda: tri.triangulate(cam, proj), times)
     fp, fc = clock("filter_3d_pts(pts, colors, 0.5)         4:71", lambda: tri.filter_3d_pts(pts, col, threshold=0.5), times)
-    del hc, vc, hp, vp, cam, proj, col, pts
+    pm2 = pk.copy()
+    t0 = time.perf_counter()
+    fused = Triangulation(hp, vp, (W, H), K, cd, (pw, ph), (pw, ph), pm2, pd, R, T, None).compute(white, threshold=0.5)
+    t_fused = (time.perf_counter() - t0) * 1e3
+    assert np.array_equal(fused[0], fp) and np.array_equal(fused[1], fc)
+    del hc, vc, hp, vp, cam, proj, col, pts, fused
     print(f"pass {rep + 1}: {sum(t for _, t in times):.1f} ms" + ("   (one scan in a fresh process, as the reference's scripts run)" if rep == 0 else ""))
 total = sum(t for _, t in times)
 print(f"{args.workload}, {'float64' if args.float64 else 'uint8'} stack, last pass ({fp.shape[1]} points kept):")
 for label, t in times:
     print(f"  {label:58s} {t:8.1f} ms")
+three = sum(t for label, t in times if "4:6" in label or "4:7" in label)
+print(f"  {'Triangulation.compute(img_white, threshold=0.5): the three calls of 4:62-71 as ONE device-resident call':58s} {t_fused:8.1f} ms = {t_fused / three:.2f} x the three calls ({three:.1f} ms), bit-identical")
 print(f"  {'both scripts, call by call':58s} {total:8.1f} ms = {px / 1e6 / (total * 1e-3):.0f} Mpixels/s   (reference: ~0.05 Mpixels/s)")

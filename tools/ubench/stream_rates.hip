@@ -6,6 +6,7 @@
 //   F    the fused scan kernel's mix with the XYZ stored as a lane holds it (48 B per lane, 16 B at a time)           (N + 16 B/px)
 //   Ft   ... with the XYZ stored wave-contiguously, as the fused kernel's LDS transpose leaves it; Ft' without the maps (N + 12 B/px)
 //   D8 / D16 / Dp   D with 8 / 16 bytes per lane and plane, or lane pairs splitting two planes: the width of the loads does not matter
+//   Dc / Dc1 / Dt / Dt4   the same bytes read contiguously or from a tile-interleaved stack (round 6: `./stream_rates L` runs only these)
 //   S / Sp          D in the decode kernel's real schedule (14 threshold planes, then steps of 4 behind a ring of DEPTH steps, with and
 //                   without dependent arithmetic), singly or in plane pairs: neither depth, arithmetic nor pairing moves it
 // One box (round 3): R 6.9 TB/s, W 3.9 (4.2 with ordinary stores), C 5.3-5.6; D 101 us (the decode kernel: 93-103 us); Ft 123 us (the fused kernel, which also gathers its
@@ -224,6 +225,68 @@ __global__ void __launch_bounds__(128) k_staged_pair(const unsigned *in, size_t 
     store_like_the_kernels<WD>(x, g, npix4, out);
 }
 
+// Dc: the read stream of R (16 B per lane, contiguous, grid-stride) with the decode kernel's 4 B/px written beside it: after every 11 loads
+// (176 B = 4 pixels x 44 planes) a lane stores its two 8-byte map pieces.  "Contiguous read + 4 B/px write": is the 8-10 % between the
+// additive bound and D the 44-stream planar layout, or the read/write mix itself?
+__global__ void __launch_bounds__(256) k_contig_rw(const v4u *in, size_t npix4, unsigned *out)
+{
+    const size_t T = (size_t)gridDim.x * 256, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // chunk c of 11 x T vectors: lane reads in[(11 c + k) T + t], k = 0..10 (each of the 11 sweeps is one contiguous T x 16 B run), writes pixel group c T + t
+    for (size_t c = 0; c * T < npix4; ++c) {
+        const size_t g = c * T + t;
+        if (g >= npix4) break;
+        v4u acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc ^= __builtin_nontemporal_load(in + (11 * c + k) * T + t);
+        store_like_the_kernels<4>(acc.x ^ acc.y ^ acc.z ^ acc.w, g, npix4, out);
+    }
+}
+// Dc1: one pass, every lane owns 4 pixels: its 176 B are the 11 vectors in[11 blockbase + 256 k + tid] of its WORKGROUP's contiguous 44 KB
+__global__ void __launch_bounds__(256) k_contig_block(const v4u *in, size_t npix4, unsigned *out)
+{
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= npix4) return;
+    const v4u *base = in + (size_t)blockIdx.x * 256 * 11 + threadIdx.x;
+    v4u acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) acc ^= __builtin_nontemporal_load(base + 256 * k);
+    store_like_the_kernels<4>(acc.x ^ acc.y ^ acc.z ^ acc.w, g, npix4, out);
+}
+// Dt: a tile-interleaved stack [tile][NP][TILE lanes x 4 B]: a tile's NP plane pieces are contiguous (TILE = 64: one wave's 44 x 256 B = 11 KB),
+// the lane still gets its own 4 pixels of one plane per dword load -- the decode kernel's register layout unchanged
+template <int NP, int TILE>
+__global__ void __launch_bounds__(128) k_tiled(const unsigned *in, size_t npix4, unsigned *out)
+{
+    const size_t g = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (g >= npix4) return;
+    const unsigned *base = in + (g / TILE) * (size_t)(TILE * NP) + (g % TILE);
+    unsigned v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = __builtin_nontemporal_load(base + p * TILE);
+    unsigned x = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) x = ((x << 1) | (x >> 31)) ^ v[p];
+    store_like_the_kernels<4>(x, g, npix4, out);
+}
+// Dt4: [tile][NP / 4][TILE lanes][4 planes x 4 px]: one 16-byte load hands a lane its 4 pixels of FOUR planes (11 loads instead of 44)
+template <int NP, int TILE>
+__global__ void __launch_bounds__(128) k_tiled4(const v4u *in, size_t npix4, unsigned *out)
+{
+    const size_t g = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (g >= npix4) return;
+    const v4u *base = in + (g / TILE) * (size_t)(TILE * NP / 4) + (g % TILE);
+    v4u v[NP / 4];
+#pragma unroll
+    for (int p = 0; p < NP / 4; ++p) v[p] = __builtin_nontemporal_load(base + p * TILE);
+    unsigned x = 0;
+#pragma unroll
+    for (int p = 0; p < NP / 4; ++p) {
+        x = ((x << 1) | (x >> 31)) ^ v[p].x; x = ((x << 1) | (x >> 31)) ^ v[p].y;
+        x = ((x << 1) | (x >> 31)) ^ v[p].z; x = ((x << 1) | (x >> 31)) ^ v[p].w;
+    }
+    store_like_the_kernels<4>(x, g, npix4, out);
+}
+
 template <class F>
 static void timeit(const char *name, double bytes, F launch)
 {
@@ -245,17 +308,19 @@ static void timeit(const char *name, double bytes, F launch)
     printf("%-78s %8.1f us  %6.2f TB/s  (best %6.2f)\n", name, t[4] * 1e3, bytes / (t[4] * 1e-3) / 1e12, bytes / (t[0] * 1e-3) / 1e12);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool layout_only = argc > 1 && argv[1][0] == 'L';
     const size_t npix = 4096ull * 3000, npix4 = npix / 4, big = 44 * npix;          // the 4096 x 3000 x 44 stack: 541 MB
     void *a, *b, *sink;
-    CK(hipMalloc(&a, 2 * big));                                                         // two stacks: rotated like bench.py (> Infinity Cache)
+    CK(hipMalloc(&a, 2 * big + (256ull << 20)));                                                         // two stacks: rotated like bench.py (> Infinity Cache)
     CK(hipMalloc(&b, big));                                                             // outputs: 16 B / pixel at most (197 MB)
     CK(hipMalloc(&sink, 64));
-    CK(hipMemset(a, 1, 2 * big));
+    CK(hipMemset(a, 1, 2 * big + (256ull << 20)));
     CK(hipMemset(b, 0, big));
     int flip = 0;
     const int grid = 256 * 16;
+    if (!layout_only) {
     timeit("R  read only, 541 MB", (double)big, [&] { flip ^= 1; hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const v4u *)((char *)a + flip * big), big / 16, (unsigned *)sink); });
     timeit("W  write only, 541 MB", (double)big, [&] { hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
     timeit("W'  write only, ordinary (cacheable) stores", (double)big, [&] { hipLaunchKernelGGL(k_write_plain, dim3(grid), dim3(256), 0, 0, (v4u *)b, big / 16); });
@@ -276,6 +341,28 @@ int main()
     STAGED(2, 64) STAGED(2, 256) STAGED(8, 256) STAGED(2, 512) STAGED(8, 512)
 #define STAGEDP(D, SP) timeit("Sp decode schedule in plane PAIRS, ring depth " #D ", " #SP " dependent multiply-adds", 48.0 * npix, [&] { flip ^= 1; hipLaunchKernelGGL((k_staged_pair<D, 4, SP>), dim3(blocks), dim3(128), 0, 0, (const unsigned *)((char *)a + flip * big), npix4, (unsigned *)b); });
     STAGEDP(1, 512) STAGEDP(2, 512) STAGEDP(3, 512) STAGEDP(4, 512) STAGEDP(5, 512) STAGEDP(6, 512) STAGEDP(8, 512) STAGEDP(8, 0)
+    }
+    // ---- layout question (round 6): planar D against contiguous / tile-interleaved reads of the same bytes, at 4096 x 3000 and 1920 x 1080
+    for (int sz = 0; sz < 2; ++sz) {
+        const size_t w = sz ? 1920 : 4096, h = sz ? 1080 : 3000, np = w * h, np4 = np / 4, bg = 44 * np;
+        const int nrot = sz ? 8 : 2;                                                // rotate over > 256 MB of stacks so that nothing is served from the Infinity Cache
+        int rot = 0;
+        auto src = [&]() { rot = (rot + 1) % nrot; return (char *)a + (size_t)rot * bg; };
+        const unsigned bl = (unsigned)((np4 + 127) / 128), bl256 = (unsigned)((np4 + 255) / 256);
+        char nm[160];
+        auto T = [&](const char *s) { snprintf(nm, sizeof nm, "%s  [%zux%zu]", s, w, h); return nm; };
+        timeit(T("R   read only, the stack"), (double)bg, [&] { hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const v4u *)src(), bg / 16, (unsigned *)sink); });
+        timeit(T("D   planar decode mix (44 plane streams, 4 B/px written)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_planes<44, 4>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        timeit(T("S   planar, the kernel's schedule (ring depth 2, arithmetic)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_staged<2, 4, 512>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        timeit(T("Dc  contiguous grid-stride read (R's stream) + 4 B/px written, 4096 workgroups"), 48.0 * np, [&] { hipLaunchKernelGGL(k_contig_rw, dim3(grid), dim3(256), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
+        timeit(T("Dc' the same, 1024 workgroups"), 48.0 * np, [&] { hipLaunchKernelGGL(k_contig_rw, dim3(1024), dim3(256), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
+        timeit(T("Dc1 contiguous, one pass: a workgroup reads its own 44 KB, writes its 1 KB + 1 KB"), 48.0 * np, [&] { hipLaunchKernelGGL(k_contig_block, dim3(bl256), dim3(256), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
+        timeit(T("Dt  tile-interleaved [tile][44][256 B] (one wave = 11 KB contiguous), dword loads"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 64>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        timeit(T("Dt' tile-interleaved [tile][44][512 B] (one workgroup = 22 KB contiguous)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 128>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        timeit(T("Dtk tile-interleaved [tile][44][4 KB] (8 workgroups share 176 KB)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 1024>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        timeit(T("Dt4 tile-interleaved [tile][11][64 lanes][4 planes x 4 px], 16-byte loads"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled4<44, 64>), dim3(bl), dim3(128), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
+        timeit(T("Dt4' the same, tile = workgroup (128 lanes)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled4<44, 128>), dim3(bl), dim3(128), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
+    }
     CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(sink));
     return 0;
 }
