@@ -389,7 +389,7 @@ extern "C" int slgc_synchronize(slgc_ctx *ctx)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SLGC_OK;
+    return slgc_direct_check(ctx);                 // a direct exchange that timed out on the GPU: the work is "done", its results are not (SLGC_ECOMM)
 }
 
 extern "C" int slgc_device_name(slgc_ctx *ctx, char *buf, int buflen)
@@ -994,6 +994,8 @@ extern "C" int slgc_dev_free(slgc_ctx *ctx, void *dptr)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (slgc_direct_is_registered(ctx, dptr))
+        return slgc_fail(ctx, SLGC_ESTATE, "the buffer is registered with the direct exchange: peers hold mappings of it (slgc_direct_unregister first, collectively)");
     if (dptr) HIP_TRY(ctx, hipFree(dptr));
     return SLGC_OK;
 }
@@ -1013,7 +1015,7 @@ extern "C" int slgc_d2h(slgc_ctx *ctx, void *dst_host, const void *src_dev, size
     if (rc) return rc;
     if (bytes && (rc = download_par(ctx, dst_host, src_dev, bytes))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SLGC_OK;
+    return slgc_direct_check(ctx);                 // bytes of a scan whose exchange timed out are not a result
 }
 
 extern "C" int slgc_dev_memset(slgc_ctx *ctx, void *dptr, int value, size_t bytes)

@@ -22,6 +22,9 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;            // the three below: RCCL's own view of a communicator (slgc_comm_info); optional
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     bool ok = false;
 };
 
@@ -38,6 +41,7 @@ Rccl &rccl()
 #define LOAD(sym) x.sym = reinterpret_cast<decltype(x.sym)>(dlsym(x.handle, "nccl" #sym))
         LOAD(GetUniqueId); LOAD(CommInitRank); LOAD(CommDestroy); LOAD(AllReduce); LOAD(AllGather);
         LOAD(Broadcast); LOAD(GroupStart); LOAD(GroupEnd); LOAD(GetErrorString);
+        LOAD(CommCount); LOAD(CommUserRank); LOAD(CommCuDevice);
 #undef LOAD
         x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather && x.Broadcast &&
                x.GroupStart && x.GroupEnd && x.GetErrorString;
@@ -96,7 +100,7 @@ extern "C" int slgc_comm_init(slgc_ctx *ctx, int rank, int nranks, const void *i
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
-    HIP_TRY(ctx, hipMalloc(&ctx->comm_scratch, 8 * (size_t)(nranks + 1)));
+    HIP_TRY(ctx, hipMalloc(&ctx->comm_scratch, SLGC_BUS_ID_BYTES * (size_t)(nranks + 1)));      // an int64 or a bus id per rank, + this rank's own
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_comm_done[i], hipEventDisableTiming));
@@ -156,6 +160,51 @@ extern "C" int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all
     NCCL_TRY(ctx, rccl().AllGather(scratch, scratch + 1, 1, ncclInt64, (ncclComm_t)ctx->comm, ctx->comm_stream));
     HIP_TRY(ctx, hipMemcpyAsync(all, scratch + 1, 8 * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->comm_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    return SLGC_OK;
+}
+
+// RCCL's own account of the communicator -- not what the caller was told: bench.py's N > 1 line quotes these.
+extern "C" int slgc_comm_info(slgc_ctx *ctx, int *nranks, int *rank, int *device)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!rccl().CommCount || !rccl().CommUserRank || !rccl().CommCuDevice)
+        return slgc_fail(ctx, SLGC_ECOMM, "this librccl does not export ncclCommCount / ncclCommUserRank / ncclCommCuDevice");
+    int n = -1, r = -1, d = -1;
+    NCCL_TRY(ctx, rccl().CommCount((ncclComm_t)ctx->comm, &n));
+    NCCL_TRY(ctx, rccl().CommUserRank((ncclComm_t)ctx->comm, &r));
+    NCCL_TRY(ctx, rccl().CommCuDevice((ncclComm_t)ctx->comm, &d));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
+    return SLGC_OK;
+}
+
+// Every rank's PCI bus id (hipDeviceGetPCIBusId of the context's device), all-gathered through the communicator itself: SLGC_BUS_ID_BYTES
+// NUL-padded bytes per rank, in rank order.  *distinct = how many different devices the ranks sit on (N ranks on N GPUs: N).
+extern "C" int slgc_comm_allgather_bus_ids(slgc_ctx *ctx, char *ids, int *distinct)
+{
+    int rc = need_comm(ctx);
+    if (rc) return rc;
+    if (!ids) return slgc_fail(ctx, SLGC_EINVAL, "null output");
+    char mine[SLGC_BUS_ID_BYTES] = {0};
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(mine, SLGC_BUS_ID_BYTES - 1, ctx->device));
+    char *scratch = (char *)ctx->comm_scratch;      // [0] = mine, [1..nranks] = gathered
+    if ((rc = comm_after_compute(ctx))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(scratch, mine, SLGC_BUS_ID_BYTES, hipMemcpyHostToDevice, ctx->comm_stream));
+    NCCL_TRY(ctx, rccl().AllGather(scratch, scratch + SLGC_BUS_ID_BYTES, SLGC_BUS_ID_BYTES, ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ids, scratch + SLGC_BUS_ID_BYTES, SLGC_BUS_ID_BYTES * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->comm_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if (distinct) {
+        int n = 0;
+        for (int a = 0; a < ctx->nranks; ++a) {
+            bool seen = false;
+            for (int b = 0; b < a && !seen; ++b) seen = memcmp(ids + (size_t)a * SLGC_BUS_ID_BYTES, ids + (size_t)b * SLGC_BUS_ID_BYTES, SLGC_BUS_ID_BYTES) == 0;
+            n += !seen;
+        }
+        *distinct = n;
+    }
     return SLGC_OK;
 }
 

@@ -163,6 +163,8 @@ inline int proj_tiles_x(const slgc_ctx *ctx, int proj_w) { return ctx->tune_proj
 bool scan_fused_eligible(const DecodeGeom &g, const RunPtrs &runs, size_t plane_stride, size_t npix, const int16_t *d_h, const int16_t *d_v,
                          const float *d_xyz);
 int ensure_luts(slgc_ctx *ctx, int rows, int W, int row0, int proj_w, int proj_h);
+int slgc_direct_check(slgc_ctx *ctx);                              // direct.hip: SLGC_ECOMM once a GPU-side wait of the direct exchange has timed out (OK without one)
+int slgc_direct_is_registered(slgc_ctx *ctx, const void *d_base);  // direct.hip
 int launch_widen_maps(slgc_ctx *ctx, const int16_t *d_h16, const int16_t *d_v16, size_t npix, int64_t *d_h, int64_t *d_v);
 // correspond.hip
 int launch_correspond(slgc_ctx *ctx, const int64_t *d_h, const int64_t *d_v, int cam_w, int cam_h, int proj_w, int proj_h,

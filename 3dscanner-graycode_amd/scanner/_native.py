@@ -20,6 +20,7 @@ ORDER_X, ORDER_ROW = 0, 1
 WIRE_MAX_CODE_BITS = 11           # slgc.h SLGC_WIRE_MAX_CODE_BITS
 TRI_EXACT, TRI_ALGEBRAIC, TRI_DIRECT, TRI_SPLIT = 0, 1, 2, 4
 UNIQUE_ID_BYTES = 128
+BUS_ID_BYTES = 16
 
 
 class SlgcError(RuntimeError):
@@ -107,6 +108,8 @@ SIGNATURES = {
     "slgc_comm_barrier": (_i, [_vp]),
     "slgc_comm_allreduce_max_f64": (_i, [_vp, C.POINTER(_d)]),
     "slgc_comm_allgather_i64": (_i, [_vp, _i64, C.POINTER(_i64)]),
+    "slgc_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "slgc_comm_allgather_bus_ids": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "slgc_comm_allgatherv": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "slgc_comm_allgatherv_begin": (_i, [_vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
     "slgc_comm_allgatherv_pair_begin": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i]),
@@ -114,6 +117,7 @@ SIGNATURES = {
     "slgc_direct_init": (_i, [_vp, _i, _i, C.c_char_p]),
     "slgc_direct_destroy": (_i, [_vp]),
     "slgc_direct_register": (_i, [_vp, _vp, _sz]),
+    "slgc_direct_unregister": (_i, [_vp, _vp]),
     "slgc_direct_allgatherv_begin": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(C.POINTER(_i64)), C.POINTER(C.POINTER(_i64)), _i]),
     "slgc_direct_wait": (_i, [_vp, _i]),
     "slgc_direct_release": (_i, [_vp, _i, C.POINTER(_vp)]),
@@ -262,7 +266,7 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            lib().slgc_dev_free(self.ctx._h, self.ptr)
+            self.ctx._ck(lib().slgc_dev_free(self.ctx._h, self.ptr))          # refused (SlgcError) while the buffer is registered with the direct exchange
             self.ptr = None
             if self in self.ctx._buffers:
                 self.ctx._buffers.remove(self)
@@ -322,6 +326,7 @@ class Context:
 
     def close(self):
         if self._h:
+            lib().slgc_direct_destroy(self._h)          # closes the peer mappings: registered buffers become ordinary ones (callers barrier before closing, see slgc.h)
             for b in list(self._buffers):
                 b.free()
             lib().slgc_destroy(self._h)
@@ -801,6 +806,21 @@ class Context:
         self._ck(lib().slgc_comm_allgather_i64(self._h, int(mine), out))
         return [int(x) for x in out]
 
+    def comm_info(self) -> dict:
+        """RCCL's own view of the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what comm_init was told."""
+        n, r, d = _i(), _i(), _i()
+        self._ck(lib().slgc_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return {"nranks": n.value, "rank": r.value, "device": d.value}
+
+    def comm_rank_devices(self):
+        """-> ([PCI bus id of rank 0's GPU, rank 1's, ...], number of distinct GPUs), all-gathered over the communicator (collective)."""
+        n = self.comm_info()["nranks"]
+        buf = C.create_string_buffer(BUS_ID_BYTES * n)
+        distinct = _i()
+        self._ck(lib().slgc_comm_allgather_bus_ids(self._h, buf, C.byref(distinct)))
+        raw = buf.raw
+        return [raw[i * BUS_ID_BYTES:(i + 1) * BUS_ID_BYTES].split(b"\0", 1)[0].decode() for i in range(n)], distinct.value
+
     def comm_allgatherv(self, d_send: int, d_recv: int, counts, displs):
         n = self.nranks
         c = (C.c_int64 * n)(*[int(x) for x in counts])
@@ -832,6 +852,10 @@ class Context:
 
     def direct_register(self, d_base: int, nbytes: int):
         self._ck(lib().slgc_direct_register(self._h, d_base, int(nbytes)))
+
+    def direct_unregister(self, d_base: int):
+        """Collective: the buffer leaves the exchange on every rank (do this before freeing it)."""
+        self._ck(lib().slgc_direct_unregister(self._h, _vp(d_base)))
 
     def direct_allgatherv_begin(self, d_bases, layouts, slot: int):
         """d_bases: 1..3 registered buffers (base device pointers); layouts: [(counts, displs)] per buffer, bytes per rank."""

@@ -182,6 +182,13 @@ class DirectExchange:
                 self.ctx.direct_register(b.ptr, b.nbytes)
                 self._base[b.ptr] = b.nbytes
 
+    def unregister(self, buffers):
+        """Collective, same order on every rank: the buffers leave the exchange (before they are freed; their slots can be registered again)."""
+        for b in buffers:
+            if b.ptr in self._base:
+                self.ctx.direct_unregister(b.ptr)
+                del self._base[b.ptr]
+
     def _in_place(self, d_send, d_recv, displs):
         recv = RcclExchange._ptr(d_recv)
         if recv not in self._base:
@@ -311,6 +318,31 @@ class ShardedScanner:
             for s in range(2):
                 exchange.register(self._exchanged[s])
         self._used = [False, False]                                # set s has held an exchange's result (its re-use must be announced)
+
+    def close(self):
+        """Collective (same point on every rank): finish what is in flight, take the scanner's buffers out of the exchange -- a DirectExchange
+        holds peer mappings of them on every rank, and has room for 16 buffers at a time -- and free them.  The scanner is unusable afterwards."""
+        if getattr(self, "_closed", False):
+            return
+        self.flush()
+        self.ctx.synchronize()
+        if hasattr(self.exchange, "unregister"):
+            for s in range(2):
+                self.exchange.unregister(self._exchanged[s])
+        bufs = [self.count]
+        if self.kind in ("maps", "xyz"):
+            bufs += [b for st in self._sets for b in st]
+            bufs += list(self._wire or []) if self.kind == "maps" else []
+            if self.kind == "maps":
+                bufs.append(self.xyz_full)
+        else:
+            bufs += [self.maps, self.xyz, self.records, self.all_records]
+        seen = set()
+        for b in bufs:
+            if b is not None and id(b) not in seen:
+                seen.add(id(b))
+                b.free()
+        self._closed = True
 
     def _reuse(self, s: int):
         """This rank is about to overwrite buffer set s: with an exchange whose peers write into this rank's buffers (DirectExchange) they

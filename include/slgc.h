@@ -324,6 +324,13 @@ int slgc_comm_destroy(slgc_ctx *ctx);
 int slgc_comm_barrier(slgc_ctx *ctx);                                          /* all-reduce of one word + stream sync */
 int slgc_comm_allreduce_max_f64(slgc_ctx *ctx, double *value);                 /* in place, host scalar */
 int slgc_comm_allgather_i64(slgc_ctx *ctx, int64_t mine, int64_t *all);        /* all: host int64[nranks] */
+/* What RCCL ITSELF reports for this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- not what slgc_comm_init was told:
+ * a job's report quotes these, so that "N ranks" is RCCL's statement.  Any output may be NULL. */
+int slgc_comm_info(slgc_ctx *ctx, int *nranks, int *rank, int *device);
+/* Every rank's PCI bus id ("0000:75:00.0"), all-gathered over the communicator: ids = nranks * SLGC_BUS_ID_BYTES NUL-padded bytes in rank
+ * order; *distinct (may be NULL) = number of different devices.  N ranks of one node on N GPUs give distinct == N. */
+#define SLGC_BUS_ID_BYTES 16
+int slgc_comm_allgather_bus_ids(slgc_ctx *ctx, char *ids, int *distinct);
 /* all-gatherv of byte records: rank r contributes counts[r] bytes from d_send; every rank receives all of them at
  * d_recv + displs[r].  Equal counts laid out back to back (displs[r] = r*count) run as ncclAllGather (in place when
  * d_send = d_recv + displs[rank]); anything else as one grouped ncclBroadcast per contributing rank (RCCL has no
@@ -352,10 +359,17 @@ int slgc_comm_wait(slgc_ctx *ctx, int slot);
  *                              Call it before re-using a buffer set (the first exchange on a buffer needs none).
  *   slgc_direct_barrier / _allgather_i64   small host-side collectives over the segment (both streams drained first).  Call slgc_direct_barrier before
  *                              slgc_direct_destroy (or slgc_destroy) and before freeing a registered buffer: a peer may still be pushing into it.
- * A peer that never shows up costs a failed call (SLGC_ECOMM after a 20 s GPU-side / 120 s host-side timeout), never a hung GPU. */
+ *   slgc_direct_unregister     collective: the buffer leaves the exchange on every rank (mappings closed, slot free again; at most 16 buffers are
+ *                              registered at a time).  slgc_dev_free refuses a buffer that is still registered.
+ * Deadlines: a GPU-side poll gives up 20 s (SLGC_DIRECT_TIMEOUT_S) after the peer's HOST has submitted the work that will raise the flag, or
+ * 300 s (SLGC_DIRECT_START_TIMEOUT_S) if the peer never gets that far -- ranks whose hosts are out of step wait for each other, like RCCL; host
+ * barriers give up after 120 s (SLGC_DIRECT_HOST_TIMEOUT_S).  A timeout is sticky: the exchange's later kernels skip their work (nothing is pushed
+ * into buffers that were not released, no half-filled buffer is announced as complete), and slgc_synchronize, slgc_d2h and every slgc_direct_*
+ * call return SLGC_ECOMM from then on -- a scan whose exchange timed out never comes back as data.  A lost peer costs a failed call, never a hung GPU. */
 int slgc_direct_init(slgc_ctx *ctx, int rank, int nranks, const char *key);
 int slgc_direct_destroy(slgc_ctx *ctx);
 int slgc_direct_register(slgc_ctx *ctx, void *d_base, size_t bytes);
+int slgc_direct_unregister(slgc_ctx *ctx, void *d_base);      /* collective; before slgc_dev_free of a registered buffer (which refuses otherwise) */
 int slgc_direct_allgatherv_begin(slgc_ctx *ctx, int nbuf, void *const *d_bases, const int64_t *const *counts, const int64_t *const *displs, int slot);
 int slgc_direct_wait(slgc_ctx *ctx, int slot);
 int slgc_direct_release(slgc_ctx *ctx, int nbuf, void *const *d_bases);

@@ -111,14 +111,15 @@ def test_printed_line_is_compact_and_carries_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch"):
         assert j["roofline"][k] == full["roofline"][k], k
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["peak"] == 8000.0 and j["roofline"]["traffic"] > 0
-    assert set(j["cpu_baseline"]) == set(L.CPU_KEYS) and len(j["cpu_baseline"]["sample"]) <= 120 and j["cpu_baseline"]["kind"] == "port"
+    assert set(j["cpu_baseline"]) == set(L.CPU_KEYS) and len(j["cpu_baseline"]["sample"]) <= 160 and j["cpu_baseline"]["kind"] == "port"
+    assert j["cpu_baseline"]["reference_measured"] == 0.046                 # the reference itself rides beside the port's value
     assert j["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and j["cpu_baseline"]["cores"] == 1
     assert j["s_scene_frac"] == full["scenes"]["s-scene"]["frac"] and j["decode_kernel_frac"] == full["decode_kernel_alone"]["roofline"]["frac"]
     assert j["throughput_mode_value"] == full["throughput_mode"]["batched"]["value"]
     assert j["sharded"] is None and j["verify_ok"] is None and j["extras_file"] == "gpurun_out/bench_extras.json"
     assert j["sustained"]["value"] == full["sustained"]["value"] and j["sustained"]["gpu_busy_percent_mean"] == full["sustained"]["gpu"]["gpu_busy_percent_mean"]
     # a multi-rank report: the sharded summary and the verification verdict ride along, long strings are cut
-    multi = dict(full, n_gpus=8, sharded={"rccl_nranks": 8, "exchange": "maps", "wire": "hv24", "overlap": True, "with_exchange_value": 1.0, "compute_only_value": 2.0,
+    multi = dict(full, n_gpus=8, sharded={"rccl_nranks": 8, "rccl_rank": 0, "distinct_devices": 8, "rank_devices": [f"0000:{0x15 + 16 * r:02x}:00.0" for r in range(8)], "exchange": "maps", "wire": "hv24", "overlap": True, "with_exchange_value": 1.0, "compute_only_value": 2.0,
                                           "exchange_bytes_per_rank": {"sent": 1, "received": 7}, "compute_only_note": "x" * 5000},
                  verify={"ok": True, "note": "y" * 5000}, error="z" * 5000,
                  sharded_alternatives={"maps_int16": {"value": 5.0, "note": "n" * 900}, "xyz": {"error": "e" * 900}, "maps_hv24_direct": {"value": 7.5}})
@@ -127,6 +128,12 @@ def test_printed_line_is_compact_and_carries_the_contract_keys():
     j = json.loads(s)
     assert len(s) < L.LINE_LIMIT and j["sharded"]["rccl_nranks"] == 8 and j["verify_ok"] is True and set(j["sharded"]) == set(L.SHARDED_KEYS) | {"alternatives"}
     assert j["sharded"]["alternatives"] == {"maps_int16": 5.0, "xyz": "error", "maps_hv24_direct": 7.5}
+    # RCCL's own account of the job: rank count from ncclCommCount, one PCI bus id per rank (domain cut), all distinct
+    assert j["sharded"]["distinct_devices"] == 8 and j["sharded"]["rank_devices"] == [f"{0x15 + 16 * r:02x}:00.0" for r in range(8)]
+    # the S-scene's fraction sits inside the roofline object when the run timed it
+    withs = dict(full, roofline=dict(full["roofline"], frac_s_scene=0.7, traffic_over_algorithmic_s_scene=1.147, headline_scene="physical"))
+    jr = json.loads(L.dump_line(withs, None))["roofline"]
+    assert jr["frac_s_scene"] == 0.7 and jr["traffic_over_algorithmic_s_scene"] == 1.147 and jr["headline_scene"] == "physical"
     assert len(j["config"]["workload"]) <= 120 and len(j["error"]) <= 200
     # a report without any extras (--extras none): the keys are there, empty
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",

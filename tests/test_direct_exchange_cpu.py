@@ -81,5 +81,16 @@ def test_sharded_scanner_announces_every_reuse_of_a_buffer_set(kind, wire):
         assert names[r + 1] == band                                          # release -> the band kernel that overwrites the set
     begins = [c for c in ctx.calls if c[0] == "direct_allgatherv_begin"]
     assert len(begins) == 5 * (2 if kind == "xyz" else 1)
+    # close(): every registered buffer leaves the exchange (collectively, registration order) BEFORE anything is freed; a second close is a no-op
+    n = len(ctx.calls)
+    freed = []
+    for b in [x for st in sc._sets for x in st] + list(getattr(sc, "_wire", None) or []) + [sc.count, sc.xyz_full]:
+        b.free = (lambda b=b: freed.append(b.ptr))
+    sc.close()
+    tail = [c[0] for c in ctx.calls[n:]]
+    assert tail.count("direct_unregister") == 2 * per_set and "synchronize" in tail and tail.index("synchronize") < tail.index("direct_unregister")
+    assert len(freed) == len(set(freed)) >= 2 * per_set + 1
+    sc.close()
+    assert [c[0] for c in ctx.calls[n:]].count("direct_unregister") == 2 * per_set
     waits = [c for c in ctx.calls if c[0] == "direct_wait"]
     assert len(waits) == len(begins)                                         # every exchange is waited for exactly once

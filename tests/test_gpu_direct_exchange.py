@@ -104,7 +104,8 @@ def _worker_scanner(rank, world, key, H, q):
             b = np.ascontiguousarray(cp[:, row0:row0 + rows])
             bufs.append(ctx.alloc(max(16, b.nbytes)).upload(b) if rows else ctx.alloc(16))
         total_ok = 0
-        for kind, wire in (("maps", "int16"), ("maps", "hv24"), ("xyz", "int16")):
+        # two rounds of three scanners = 24 registrations against 16 slots: close() must hand the slots back (slgc_direct_unregister)
+        for kind, wire in (("maps", "int16"), ("maps", "hv24"), ("xyz", "int16")) * 2:
             sc = sharded.ShardedScanner(ctx, ex, plan, psize, N, mode=_native.TRI_ALGEBRAIC, exchange_kind=kind, wire=wire)
             outs = []
             for j in range(7):                                                       # seven submits: every buffer set is re-used three times
@@ -122,6 +123,9 @@ def _worker_scanner(rank, world, key, H, q):
                 assert np.array_equal(np.isfinite(gx[..., 0]), okj), (kind, wire, j)
                 np.testing.assert_allclose(gx[okj], np.moveaxis(rx, 0, -1)[okj], rtol=1e-4, atol=0)
                 total_ok += int(okj.sum())
+            with pytest.raises(_native.SlgcError, match="registered"):              # peers hold mappings of it: freeing it now is refused
+                sc._exchanged[0][0].free()
+            sc.close()                                                               # collective: unregister on every rank, then free
         ex.barrier()
         ctx.close()
         q.put((rank, "ok", total_ok))
@@ -131,9 +135,11 @@ def _worker_scanner(rank, world, key, H, q):
 
 
 def _worker_lost_peer(rank, world, key, q):
-    """Rank 1 registers and then never exchanges: rank 0's wait gives up after SLGC_DIRECT_TIMEOUT_S and its next call reports it."""
+    """Rank 1 registers and then never exchanges: rank 0's wait gives up (its peer's host never submits: the START deadline), and from then on
+    nothing of that exchange comes back as a result -- synchronize, the download and the next exchange all fail; the GPU itself is fine."""
     try:
         os.environ["SLGC_DIRECT_TIMEOUT_S"] = "1.0"
+        os.environ["SLGC_DIRECT_START_TIMEOUT_S"] = "1.0"
         _native, sharded, ctx, ex = _setup(rank, world, key)
         buf = ctx.alloc(8192).zero()
         ex.register([buf])
@@ -141,15 +147,83 @@ def _worker_lost_peer(rank, world, key, q):
             t0 = time.time()
             ex.allgatherv_begin(buf.at(0), buf, [4096, 4096], [0, 4096], 0)
             ex.wait(0)
-            ctx.synchronize()                                                       # the polling kernel has given up: the stream drains
+            with pytest.raises(_native.SlgcError, match="timed out"):               # the polling kernel has given up: the stream drains, the scan has FAILED
+                ctx.synchronize()
             waited = time.time() - t0
             assert 0.8 < waited < 15.0, waited
             with pytest.raises(_native.SlgcError, match="timed out"):
+                buf.download((16,), np.uint8)                                        # bytes of a timed-out exchange are not a result
+            with pytest.raises(_native.SlgcError, match="timed out"):
                 ex.allgatherv_begin(buf.at(0), buf, [4096, 4096], [0, 4096], 1)
-            # the GPU itself is fine: an ordinary scan-side call still works on this context
+            # the GPU itself is fine: once the dead exchange is gone, ordinary calls work on this context
+            ctx.direct_destroy()
             assert buf.download((16,), np.uint8).sum() == 0
+            ctx.synchronize()
         else:
             time.sleep(4.0)                                                         # stays alive (mappings valid), never pushes
+        ctx.close()
+        q.put((rank, "ok", 0))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+def _worker_late_peer(rank, world, key, q):
+    """Hosts out of step by more than the (short) GPU-side deadline: rank 1 submits its side 3 s after rank 0, with SLGC_DIRECT_TIMEOUT_S = 1.
+    The short deadline only runs once the peer's host has submitted, so the exchange completes (RCCL would simply have waited, too) -- on the
+    first exchange (rank 0's wait polls for a band nobody has started) and on the second (rank 0's GATE polls for a release nobody has submitted)."""
+    try:
+        os.environ["SLGC_DIRECT_TIMEOUT_S"] = "1.0"
+        _native, sharded, ctx, ex = _setup(rank, world, key)
+        buf = ctx.alloc(8192).zero()
+        ex.register([buf])
+        for it in range(2):
+            if rank == 1:
+                time.sleep(3.0)
+            if it:
+                ex.release([buf])
+            buf.upload(np.full(4096, 10 * it + rank + 1, np.uint8), 4096 * rank)
+            ex.allgatherv_begin(buf.at(4096 * rank), buf, [4096, 4096], [0, 4096], 0)
+            ex.wait(0)
+            ctx.synchronize()
+            got = buf.download((8192,), np.uint8)
+            assert (got[:4096] == 10 * it + 1).all() and (got[4096:] == 10 * it + 2).all(), (it, got[::2048])
+        ex.barrier()
+        ex.unregister([buf])
+        buf.free()
+        ctx.close()
+        q.put((rank, "ok", 0))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail", traceback.format_exc() + repr(e)))
+
+
+def _worker_register_failure(rank, world, key, q):
+    """Ranks register buffers of different sizes: every rank gets the error, nothing of the failed registration stays behind (the same buffers
+    register fine afterwards, in the same slot), and unregistered buffers can be freed."""
+    try:
+        _native, sharded, ctx, ex = _setup(rank, world, key)
+        a, b = ctx.alloc(4096 * (1 + rank)).zero(), ctx.alloc(8192).zero()
+        with pytest.raises(_native.SlgcError, match="different sizes"):
+            ctx.direct_register(a.ptr, a.nbytes)
+        a.free()                                                                    # not registered: free is allowed
+        for _ in range(20):                                                         # 20 > 16 slots: register / unregister recycles them
+            ctx.direct_register(b.ptr, b.nbytes)
+            with pytest.raises(_native.SlgcError, match="already registered"):
+                ctx.direct_register(b.ptr, b.nbytes)
+            ctx.direct_unregister(b.ptr)
+        with pytest.raises(_native.SlgcError, match="not registered"):
+            ctx.direct_unregister(b.ptr)
+        ctx.direct_register(b.ptr, b.nbytes)
+        b.upload(np.full(4096, rank + 1, np.uint8), 4096 * rank)
+        ctx.direct_allgatherv_begin([b.ptr], [([4096, 4096], [0, 4096])], 0)
+        ctx.direct_wait(0)
+        ctx.synchronize()
+        got = b.download((8192,), np.uint8)
+        assert (got[:4096] == 1).all() and (got[4096:] == 2).all()
+        ex.barrier()
+        ctx.direct_unregister(b.ptr)
+        b.free()
         ctx.close()
         q.put((rank, "ok", 0))
     except BaseException as e:  # noqa: BLE001
@@ -199,3 +273,11 @@ def test_sharded_scanner_over_the_direct_exchange_matches_the_oracle(world, H):
 
 def test_a_lost_peer_is_a_failed_call_not_a_hung_gpu():
     _run(_worker_lost_peer, 2, timeout=60)
+
+
+def test_hosts_out_of_step_wait_for_each_other():
+    _run(_worker_late_peer, 2, timeout=60)
+
+
+def test_registration_is_failure_atomic_and_slots_are_recycled():
+    _run(_worker_register_failure, 2, timeout=60)

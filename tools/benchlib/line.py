@@ -10,10 +10,11 @@ LINE_LIMIT = 4096
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
             "config", "roofline", "cpu_baseline", "s_scene_frac", "decode_kernel_frac", "throughput_mode_value", "sustained", "sharded", "verify_ok", "extras_file")
 CONFIG_KEYS = ("workload", "pipeline", "scene_name", "rig", "executed_path", "valid_fraction", "extras")
-ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_mean", "isolated_frac", "traffic", "traffic_over_algorithmic", "traffic_source", "kernel", "avg_launch_ms",
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "frac_mean", "frac_s_scene", "isolated_frac", "traffic", "traffic_over_algorithmic", "traffic_over_algorithmic_s_scene",
+                 "headline_scene", "traffic_source", "kernel", "avg_launch_ms",
                  "median_launch_ms", "launch_ms_used", "max_launch_ms", "launches_timed", "outliers", "algorithmic_bytes_per_launch")
-CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "c_oracle_value", "c_oracle_all_cores_value", "c_oracle_all_cores")
-SHARDED_KEYS = ("rccl_nranks", "exchange", "exchange_impl", "wire", "overlap", "with_exchange_value", "compute_only_value")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "reference_measured", "why_port_differs", "c_oracle_value", "c_oracle_all_cores_value", "c_oracle_all_cores")
+SHARDED_KEYS = ("rccl_nranks", "distinct_devices", "rank_devices", "exchange", "exchange_impl", "wire", "overlap", "with_exchange_value", "compute_only_value")
 
 
 def _cut(s, n):
@@ -45,7 +46,10 @@ def compact_line(report, extras_file=None):
     cpu = report.get("cpu_baseline")
     if cpu:
         c = _pick(cpu, CPU_KEYS)
-        c["sample"] = _cut(c.get("sample") or "", 120)
+        c["sample"] = _cut(c.get("sample") or "", 160)
+        rm = cpu.get("reference_measured")
+        c["reference_measured"] = rm.get("value") if isinstance(rm, dict) else rm          # Mpixels/s: the reference itself, survey container
+        c["why_port_differs"] = _cut(c.get("why_port_differs") or "", 260)
         line["cpu_baseline"] = c
     else:
         line["cpu_baseline"] = None
@@ -60,6 +64,8 @@ def compact_line(report, extras_file=None):
                                              "gpu_busy_percent_mean": (su.get("gpu") or {}).get("gpu_busy_percent_mean")}
     sh = report.get("sharded")
     line["sharded"] = _pick(sh, SHARDED_KEYS) if sh else None
+    if sh and isinstance(sh.get("rank_devices"), list):   # PCI bus ids without the domain ("75:00.0"), at most 16 ranks: 8 GPUs stay under 100 bytes
+        line["sharded"]["rank_devices"] = [_cut(str(d).split(":", 1)[-1] if str(d).count(":") == 2 else d, 12) for d in sh["rank_devices"][:16]]
     alts = report.get("sharded_alternatives")
     if sh and isinstance(alts, dict):                     # the other exchange forms timed after the counted region: label -> Mpixels/s (or "error")
         line["sharded"]["alternatives"] = {_cut(k, 24): (v.get("value") if isinstance(v, dict) and "value" in v else "error") for k, v in list(alts.items())[:6]}

@@ -576,6 +576,14 @@ def run_rank(args, rank, local_rank, world):
             for name, row in table.items():
                 row["fused_time_over_s_scene"] = round(row["median_launch_ms"] / ref_ms, 3) if ref_ms and row.get("median_launch_ms") else None
             out["scenes"] = table
+            # SURVEY.md 8(d) defines the synthetic capture as the S-scene: its fraction rides INSIDE the roofline object next to the headline capture's
+            #  -- the same kernel, same run, same byte definition
+            srow = table.get("s-scene")
+            if srow and out.get("roofline"):
+                sr = srow.get("roofline") or out["roofline"]
+                out["roofline"]["frac_s_scene"] = srow["frac"]
+                out["roofline"]["traffic_over_algorithmic_s_scene"] = sr.get("traffic_over_algorithmic")
+                out["roofline"]["headline_scene"] = args.scene
             if "s-scene" in scene_legs:                      # (kept under its old key as well)
                 row = table["s-scene"]
                 out["other_scene"] = {"scene": "s-scene", "value": row["value"], "unit": "Mpixels/s", "ms_per_step": row["ms_per_step"], "executed": row["executed"],

@@ -24,9 +24,19 @@ def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, c
             ctx.synchronize()
             t_compute = time.perf_counter() - t0
         t_compute = ctx.comm_allreduce_max(t_compute)
+    # RCCL's own account of the job (not WORLD_SIZE): ncclCommCount, and the PCI bus id of every rank's GPU gathered over the communicator
+    comm = ctx.comm_info()
+    devices, distinct = ctx.comm_rank_devices()
+    test_mode = os.environ.get("SLGC_RANKS_AS_HOSTS") == "1"      # several ranks share the one GPU of a test box on purpose
+    if comm["nranks"] != G:
+        raise RuntimeError(f"RCCL reports {comm['nranks']} ranks, the launcher promised {G}")
+    if distinct != comm["nranks"] and not test_mode:
+        raise RuntimeError(f"{comm['nranks']} RCCL ranks sit on {distinct} distinct GPUs ({devices}): one rank per GPU is the plan "
+                           "(SLGC_RANKS_AS_HOSTS=1 is the one-GPU test mode)")
     px = cam_w * cam_h
     per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
-    info = {"rccl_nranks": G, "exchange": args.exchange, "exchange_impl": args.exchange_impl, "wire": scanner.wire if args.exchange == "maps" else None,
+    info = {"rccl_nranks": comm["nranks"], "rccl_rank": comm["rank"], "rank_devices": devices, "distinct_devices": distinct,
+            "ranks_share_gpus_test_mode": bool(test_mode and distinct != comm["nranks"]), "exchange": args.exchange, "exchange_impl": args.exchange_impl, "wire": scanner.wire if args.exchange == "maps" else None,
             "overlap": not args.no_overlap and args.exchange != "records",
             "exchange_bytes_per_rank": {"sent": int(rows * cam_w * per_px), "received": int((px - rows * cam_w) * per_px)},
             "with_exchange_value": round(px / 1e6 * args.steps / elapsed, 1), "unit": "Mpixels/s"}
@@ -79,8 +89,11 @@ def direct_children(args, rank, G, device, key, cam, proj, N, wire, n_buffers, l
            "--wire", wire, "--buffers", str(n_buffers), "--plane-pad", str(args.plane_pad), "--steps", str(steps), "--last-stack", str(last_stack),
            "--main-digest", f"{main_digest:016x}", "--mode", str(int(mode))]
     limit = float(os.environ.get("SLGC_BENCH_DIRECT_CHILD_TIMEOUT_S", "60"))
+    # the children's own host-side deadline ends before this parent's limit does: a child that cannot assemble its job reports why (and rank 0
+    # unlinks the segment) instead of being killed mid-barrier with the name left behind
+    env = dict(os.environ, SLGC_DIRECT_HOST_TIMEOUT_S=os.environ.get("SLGC_DIRECT_HOST_TIMEOUT_S", f"{max(5.0, 0.6 * limit):.0f}"))
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit, text=True, env=env)
     except subprocess.TimeoutExpired:
         return {"error": f"child of rank {rank} did not finish within {limit:.0f} s"}
     except OSError as e:

@@ -360,6 +360,8 @@ int main(int argc, char **argv)
         timeit(T("Dt  tile-interleaved [tile][44][256 B] (one wave = 11 KB contiguous), dword loads"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 64>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
         timeit(T("Dt' tile-interleaved [tile][44][512 B] (one workgroup = 22 KB contiguous)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 128>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
         timeit(T("Dtk tile-interleaved [tile][44][4 KB] (8 workgroups share 176 KB)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, 1024>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+#define DTK(TL, LABEL) timeit(T("Dtk tile-interleaved, plane piece = " LABEL), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled<44, TL>), dim3(bl), dim3(128), 0, 0, (const unsigned *)src(), np4, (unsigned *)b); });
+        DTK(256, "1 KB (tile 44 KB)") DTK(2048, "8 KB (tile 352 KB)") DTK(4096, "16 KB (tile 704 KB)") DTK(16384, "64 KB (tile 2.8 MB)") DTK(65536, "256 KB (tile 11 MB)") DTK(262144, "1 MB (tile 46 MB)")
         timeit(T("Dt4 tile-interleaved [tile][11][64 lanes][4 planes x 4 px], 16-byte loads"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled4<44, 64>), dim3(bl), dim3(128), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
         timeit(T("Dt4' the same, tile = workgroup (128 lanes)"), 48.0 * np, [&] { hipLaunchKernelGGL((k_tiled4<44, 128>), dim3(bl), dim3(128), 0, 0, (const v4u *)src(), np4, (unsigned *)b); });
     }
