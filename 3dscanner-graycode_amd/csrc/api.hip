@@ -189,6 +189,7 @@ int upload_runs(slgc_ctx *ctx, const void *const *stacks, int *dtype, int n_runs
     for (int r = 0; r < n_runs; ++r)
         if (!stacks[r]) return slgc_fail(ctx, SLGC_EINVAL, "stack %d is null", r);
     const size_t elems = (size_t)N * npix;
+    ctx->stack_tile_active = 0;               // host stacks are planar [N][H][W], whatever layout the context's device-resident scans use
     ctx->last_input_path = *dtype == SLGC_U8 ? 0 : 2;
     static const int pack = xcd_env("SLGC_F64_PACK", 1);          // 0: always ship float64 (A/B of the narrowing)
     bool plausible = *dtype == SLGC_F64 && pack && elems;
@@ -357,6 +358,10 @@ extern "C" int slgc_tune(slgc_ctx *ctx, const char *name, int value)
     else if (!strcmp(name, "lists_lines")) ctx->tune_lists_lines = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "lists_order")) ctx->tune_lists_order = value < 0 ? 0 : (value > 64 ? 64 : value);
     else if (!strcmp(name, "image_rows")) ctx->tune_image_rows = value < 0 ? 0 : value;      // the ray tables are rebuilt on the next use
+    else if (!strcmp(name, "stack_tile_log2")) {
+        if (value != 0 && (value < 8 || value > 24)) return slgc_fail(ctx, SLGC_EINVAL, "stack_tile_log2 must be 0 (planar) or 8..24");
+        ctx->tune_stack_tile = value;
+    }
     else if (!strcmp(name, "wire")) ctx->tune_wire = value != 0;      // NOT result-neutral in bytes moved, result-neutral in maps / XYZ
 #ifdef SLGC_DIAG
     else if (!strcmp(name, "fuse_abl")) ctx->tune_fuse_abl = value;
@@ -757,6 +762,34 @@ extern "C" int slgc_to_gray_dev(slgc_ctx *ctx, const uint8_t *d_bgr, size_t npix
     return launch_bgr_to_gray(ctx, d_bgr, d_gray, npix, coeff_bits);
 }
 
+// ---- the tile-interleaved stack layout (slgc_tune "stack_tile_log2"): the two ways a stack gets into it
+extern "C" int slgc_tiled_stack_bytes(int N, size_t npix, int tile_log2, size_t *bytes)
+{
+    if (!bytes || N < 1 || tile_log2 < 8 || tile_log2 > 24) return SLGC_EINVAL;
+    const size_t piece = (size_t)1 << tile_log2;
+    *bytes = ((npix + piece - 1) >> tile_log2) * (size_t)N * piece;
+    return SLGC_OK;
+}
+
+extern "C" int slgc_tile_stack_dev(slgc_ctx *ctx, const uint8_t *d_planar, size_t plane_stride, int N, size_t npix, int tile_log2, uint8_t *d_tiled)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (N < 0 || (N && npix && (!d_planar || !d_tiled)) || plane_stride < npix || tile_log2 < 8 || tile_log2 > 24)
+        return slgc_fail(ctx, SLGC_EINVAL, "null pointer / plane_stride smaller than a frame / tile_log2 outside 8..24");
+    return launch_tile_stack(ctx, d_planar, plane_stride, N, npix, tile_log2, d_tiled);
+}
+
+extern "C" int slgc_to_gray_tiled_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_frames, size_t npix, int coeff_bits, int tile_log2, uint8_t *d_tiled)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
+    if (n_frames < 0 || (n_frames && npix && (!d_bgr || !d_tiled)) || tile_log2 < 8 || tile_log2 > 24)
+        return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative size / tile_log2 outside 8..24");
+    return launch_bgr_to_gray_tiled(ctx, d_bgr, d_tiled, n_frames, npix, coeff_bits, tile_log2);
+}
+
 extern "C" int slgc_frame_diff_counts(slgc_ctx *ctx, const void *frames, int dtype, int n_frames, size_t elems_per_frame, double thresh,
                                       int64_t *counts)
 {
@@ -1107,10 +1140,27 @@ extern "C" int slgc_prof_samples(slgc_ctx *ctx, float *ms, int cap, int *n)
     return SLGC_OK;
 }
 
+struct TileOff {           // the context's tile-interleaved setting suspended for the duration of a call (BGR entry points)
+    slgc_ctx *c;
+    int saved;
+    explicit TileOff(slgc_ctx *ctx) : c(ctx), saved(ctx->tune_stack_tile) { c->tune_stack_tile = 0; c->stack_tile_active = 0; }
+    ~TileOff() { c->tune_stack_tile = saved; c->stack_tile_active = 0; }
+};
+
 static int dev_geom(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W,
                     double eps, DecodeGeom *g, RunPtrs *runs, int *e)
 {
     if (!d_stack) return slgc_fail(ctx, SLGC_EINVAL, "null stack");
+    ctx->stack_tile_active = 0;
+    if (ctx->tune_stack_tile) {              // tile-interleaved stack [tile][N][2^k]: the caller says so twice (slgc_tune + plane_stride = 2^k), d_stack = the band's first tile
+        const size_t piece = (size_t)1 << ctx->tune_stack_tile;
+        if (rows < 0 || W < 0 || plane_stride != piece)
+            return slgc_fail(ctx, SLGC_EINVAL, "stack_tile_log2 = %d is set on this context: plane_stride must be the plane piece, %zu bytes", ctx->tune_stack_tile, piece);
+        const uint64_t tiles = ((uint64_t)rows * W + piece - 1) >> ctx->tune_stack_tile;
+        if (((size_t)rows * W) % 4 || tiles * (uint64_t)N * piece >= 0xfffffff0ull || (uintptr_t)d_stack % 16)
+            return slgc_fail(ctx, SLGC_EINVAL, "a tile-interleaved stack needs a band of a multiple of 4 pixels, under 4 GB, 16-byte aligned");
+        ctx->stack_tile_active = ctx->tune_stack_tile;
+    } else
     if (rows < 0 || W < 0 || plane_stride < (size_t)rows * W) return slgc_fail(ctx, SLGC_EINVAL, "plane_stride smaller than the band");
     if (slgc_make_geom(N, n_runs, g)) return slgc_fail(ctx, SLGC_EINVAL, "unsupported N=%d / n_runs=%d", N, n_runs);
     if (!decode_fast_eligible(eps, e))
@@ -1284,6 +1334,7 @@ extern "C" int slgc_scan_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_runs
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
+    TileOff tile_off(ctx);                       // BGR frames are planar [N][rows][W][3]; so is the grey scratch of the fallback path
     if (!ctx->have_calib) return slgc_fail(ctx, SLGC_ESTATE, "slgc_set_calibration has not been called");
     if (!d_bgr || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
@@ -1328,6 +1379,7 @@ extern "C" int slgc_decode_bgr_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_ru
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
+    TileOff tile_off(ctx);                       // BGR frames are planar [N][rows][W][3]; so is the grey scratch of the fallback path
     if (!d_bgr || !d_h || !d_v) return slgc_fail(ctx, SLGC_EINVAL, "null pointer");
     if (coeff_bits != 14 && coeff_bits != 15) return slgc_fail(ctx, SLGC_EINVAL, "coeff_bits must be 15 (OpenCV 4.x) or 14");
     if (rows < 0 || W < 0 || plane_stride < 3 * (size_t)rows * W) return slgc_fail(ctx, SLGC_EINVAL, "plane_stride smaller than a BGR band");

@@ -340,6 +340,8 @@ struct PkArgs {
     uint32_t plane_stride;   // bytes between frames (< 2^32 / N)
     uint32_t npix;           // pixels in the band (multiple of PX handled here; ragged tail by the byte-wide kernel)
     uint32_t run_bytes;      // (N-1)*plane_stride + npix : bounds of the read descriptor
+    uint32_t tile_log2;      // 0 = planar stack [N][npix]; k = tile-interleaved [tile][N][2^k bytes]: plane_stride = 2^k, a tile's N pieces are contiguous
+    uint32_t tile_bytes;     // N << tile_log2
     int16_t *h;
     int16_t *v;
     DecodeGeom g;
@@ -497,7 +499,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && (ABL == 0 || (ABL == 3 && N
     stamp<FUSE, BLOCK>(a, 0);
     set_prio(a.f.prio_head);
     const uint32_t off = (bid * BLOCK + threadIdx.x) * PX;
-    const uint32_t voff = BGR ? 3u * off : off;      // byte offset of the lane's pixels inside a plane
+    uint32_t voff = BGR ? 3u * off : off;            // byte offset of the lane's pixels inside a plane
+    if (!BGR && a.tile_log2) voff = (off >> a.tile_log2) * a.tile_bytes + (off & ((1u << a.tile_log2) - 1u));      // ... inside plane 0's piece of the lane's tile
     const uint32_t ps = a.plane_stride;
     const int L = SPEC ? FS::L : a.g.L;
     uint32_t mB_h[NP], mB_v[NP], mV_h[NP], mV_v[NP];
@@ -1167,6 +1170,11 @@ int launch_scan_fused(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, s
     b.plane_stride = (uint32_t)plane_stride;
     b.npix = (uint32_t)npix4;
     b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + (bgr_bits ? 3 : 1) * npix4);
+    if (ctx->stack_tile_active) {              // tile-interleaved stack (the caller has checked: not BGR, plane_stride = 2^k, whole launch inside 32 bits)
+        b.tile_log2 = (uint32_t)ctx->stack_tile_active;
+        b.tile_bytes = (uint32_t)g.N << b.tile_log2;
+        b.run_bytes = (uint32_t)(((npix4 + plane_stride - 1) >> b.tile_log2) * b.tile_bytes);
+    }
     if (bgr_bits) {              // OpenCV's fixed-point BGR2GRAY coefficients (ingest.hip has the same two sets), split into bytes for v_dot4_u32_u8
         const uint32_t ry = bgr_bits == 14 ? 4899 : 9798, gy = bgr_bits == 14 ? 9617 : 19235, by = bgr_bits == 14 ? 1868 : 3735;
         b.lum.a_hi = (by >> 8) | ((gy >> 8) << 8) | ((ry >> 8) << 16);
@@ -1391,6 +1399,12 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
         b.plane_stride = (uint32_t)plane_stride;
         b.npix = (uint32_t)main_pix;
         b.run_bytes = (uint32_t)((uint64_t)(g.N - 1) * plane_stride + main_pix);
+        if (ctx->stack_tile_active) {          // tile-interleaved stack: the packed kernel on whole 4-pixel groups only (checked by slgc_stack_tile_ok)
+            if (main_pix != npix) return slgc_fail(ctx, SLGC_EINVAL, "a tile-interleaved stack needs a band of a multiple of %d pixels", px);
+            b.tile_log2 = (uint32_t)ctx->stack_tile_active;
+            b.tile_bytes = (uint32_t)g.N << b.tile_log2;
+            b.run_bytes = (uint32_t)(((main_pix + plane_stride - 1) >> b.tile_log2) * b.tile_bytes);
+        }
         b.h = d_h; b.v = d_v; b.g = g; b.e = e;
         {
             // issue priority (see launch_scan_fused): the decode kernel has no tail to put last, but a wave that still has to ask for its threshold
@@ -1408,6 +1422,7 @@ int launch_decode_fast(slgc_ctx *ctx, const DecodeGeom &g, const RunPtrs &runs, 
 #undef SLGC_PK
     } else {
         if (nt) return slgc_fail(ctx, SLGC_EINVAL, "variant %d: NT only with the packed kernel", variant);
+        if (ctx->stack_tile_active) return slgc_fail(ctx, SLGC_EINVAL, "a tile-interleaved stack needs 4-byte aligned buffers and a band inside 32-bit offsets (the packed kernel)");
         ctx->last_ns = 0;
         ctx->last_ragged = 1;             // the lane-mask kernel: what misaligned bands fall back to
 #define SLGC_CASE(P, B) if (px == P && block == B) rc = launch_fast_t<P, B>(ctx, a, main_pix);

@@ -20,11 +20,20 @@ namespace {
 // lane's: read that way a wave's load instruction touches three times the cache lines it uses.  The workgroup reads its 12 KB with
 // consecutive lanes on consecutive 16-byte pieces (three fully coalesced 1 KB-per-wave loads, non-temporal: every byte is read once), parks
 // them in LDS and every lane picks its own 48 bytes up from there.
+// TILED (slgc_to_gray_tiled_dev): blockIdx.y = frame f of n_frames, npix = pixels of ONE frame, and pixel p of frame f goes to
+// gray[((p >> k) * n_frames + f) << k | (p & (2^k - 1))] -- the tile-interleaved stack [tile][N][2^k] the decode kernels read when slgc_tune
+// "stack_tile_log2" = k: the ingest pass rewrites every byte anyway, so the other layout costs it nothing.
+template <bool TILED>
 __global__ void __launch_bounds__(256) k_bgr_to_gray(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t npix, int ry, int gy,
-                                                     int by, int shift)
+                                                     int by, int shift, int n_frames, int tile_log2)
 {
     typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
     __shared__ uint4 s_in[768];
+    if (TILED) bgr += (size_t)blockIdx.y * 3 * npix;
+    auto out_at = [&](size_t p) -> uint8_t * {      // where pixel p (of this frame) lives
+        if (!TILED) return gray + p;
+        return gray + ((((p >> tile_log2) * (size_t)n_frames + blockIdx.y) << tile_log2) | (p & (((size_t)1 << tile_log2) - 1)));
+    };
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int rnd = 1 << (shift - 1);
     const size_t wg_px0 = (size_t)blockIdx.x * 4096;
@@ -46,10 +55,27 @@ __global__ void __launch_bounds__(256) k_bgr_to_gray(const uint8_t *__restrict__
                            R = (w[(3 * j + 2) >> 2] >> (8 * ((3 * j + 2) & 3))) & 0xffu;
             out[j >> 2] |= (uint32_t)((int)(B * by + G * gy + R * ry + rnd) >> shift) << (8 * (j & 3));
         }
-        reinterpret_cast<uint4 *>(gray)[q] = make_uint4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<uint4 *>(out_at(q * 16)) = make_uint4(out[0], out[1], out[2], out[3]);      // (16 pixels never straddle a plane piece: 2^k >= 256)
     } else {
         for (size_t p = q * 16; p < npix && p < q * 16 + 16; ++p)
-            gray[p] = (uint8_t)(((int)bgr[3 * p] * by + (int)bgr[3 * p + 1] * gy + (int)bgr[3 * p + 2] * ry + rnd) >> shift);
+            *out_at(p) = (uint8_t)(((int)bgr[3 * p] * by + (int)bgr[3 * p + 1] * gy + (int)bgr[3 * p + 2] * ry + rnd) >> shift);
+    }
+}
+
+// planar [N][plane_stride] -> tile-interleaved [tile][N][2^k] (slgc_tile_stack_dev): for stacks that arrive grey and planar.  16 bytes per lane
+// where the frame allows it; blockIdx.y = frame.
+__global__ void __launch_bounds__(256) k_tile_stack(const uint8_t *__restrict__ planar, size_t plane_stride, size_t npix, int n_frames, int tile_log2,
+                                                    uint8_t *__restrict__ tiled)
+{
+    const size_t p = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p >= npix) return;
+    const uint8_t *src = planar + (size_t)blockIdx.y * plane_stride + p;
+    uint8_t *dst = tiled + ((((p >> tile_log2) * (size_t)n_frames + blockIdx.y) << tile_log2) | (p & (((size_t)1 << tile_log2) - 1)));
+    if (p + 16 <= npix && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<v4u_ *>(dst) = __builtin_nontemporal_load(reinterpret_cast<const v4u_ *>(src));
+    } else {
+        for (size_t i = 0; i < 16 && p + i < npix; ++i) dst[i] = src[i];
     }
 }
 
@@ -175,8 +201,27 @@ int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, siz
 {
     if (npix == 0) return SLGC_OK;
     const int ry = coeff_bits == 14 ? 4899 : 9798, gy = coeff_bits == 14 ? 9617 : 19235, by = coeff_bits == 14 ? 1868 : 3735;
-    hipLaunchKernelGGL(k_bgr_to_gray, dim3((unsigned)(((npix + 15) / 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, d_gray, npix, ry, gy, by,
-                       coeff_bits);
+    hipLaunchKernelGGL(k_bgr_to_gray<false>, dim3((unsigned)(((npix + 15) / 16 + 255) / 256)), dim3(256), 0, ctx->stream, d_bgr, d_gray, npix, ry, gy, by,
+                       coeff_bits, 1, 0);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+int launch_bgr_to_gray_tiled(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_tiled, int n_frames, size_t npix, int coeff_bits, int tile_log2)
+{
+    if (npix == 0 || n_frames == 0) return SLGC_OK;
+    const int ry = coeff_bits == 14 ? 4899 : 9798, gy = coeff_bits == 14 ? 9617 : 19235, by = coeff_bits == 14 ? 1868 : 3735;
+    hipLaunchKernelGGL(k_bgr_to_gray<true>, dim3((unsigned)(((npix + 15) / 16 + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, d_bgr, d_tiled, npix,
+                       ry, gy, by, coeff_bits, n_frames, tile_log2);
+    HIP_TRY(ctx, hipGetLastError());
+    return SLGC_OK;
+}
+
+int launch_tile_stack(slgc_ctx *ctx, const uint8_t *d_planar, size_t plane_stride, int n_frames, size_t npix, int tile_log2, uint8_t *d_tiled)
+{
+    if (npix == 0 || n_frames == 0) return SLGC_OK;
+    hipLaunchKernelGGL(k_tile_stack, dim3((unsigned)(((npix + 15) / 16 + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, d_planar, plane_stride, npix,
+                       n_frames, tile_log2, d_tiled);
     HIP_TRY(ctx, hipGetLastError());
     return SLGC_OK;
 }

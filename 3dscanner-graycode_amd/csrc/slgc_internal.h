@@ -59,6 +59,8 @@ struct slgc_ctx {
     int tune_prio;          // fused scan kernel: s_setprio per phase, head * 100 + body * 10 + tail (decode.hip: set_prio)
     int tune_lists_order;   // x-major scatter: workgroup -> tile order (correspond.hip): 0 row-major, 1 column-major, 2 column-major inside each XCD
     int tune_lists_lines;   // slgc_cloud_dev's scatter: 1 = k_xmajor_lines (whole 128-byte lines) for images of >= 2048 tiles (default), 2 = wherever the shape allows, 0 = k_xmajor_scatter<.., 2, ..>
+    int tune_stack_tile;    // slgc_tune "stack_tile_log2": k > 0 = the _dev scan entry points read their stacks tile-interleaved, [tile][N][2^k bytes] (0 = planar [N][H][W], default)
+    int stack_tile_active;  // the layout of the stack the decode launchers are about to read: set by every _dev entry (dev_geom), cleared by every host-buffer upload
     int tune_wire;          // slgc_scan_sharded_dev: 1 = exchange the maps in the 3-byte wire format, 0 = int16 (default)
     int tune_cam_nodes;     // scan kernels' camera rays: 0 per-pixel table, 1 node table when the per-pixel one would stream from HBM (default), 2 node table whenever accurate
     int tune_image_rows;    // height of the whole image a band belongs to (0 = the band IS the image): the node-table decision (size and accuracy) is taken
@@ -196,6 +198,8 @@ int launch_synth_bgr(slgc_ctx *ctx, const uint8_t *d_gray, size_t gray_stride, i
 int launch_synth_uniform(slgc_ctx *ctx, uint8_t *d_stack, size_t plane_stride, int N, int W, int row0, int rows, uint32_t seed);
 // ingest.hip
 int launch_bgr_to_gray(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_gray, size_t npix, int coeff_bits);
+int launch_bgr_to_gray_tiled(slgc_ctx *ctx, const uint8_t *d_bgr, uint8_t *d_tiled, int n_frames, size_t npix, int coeff_bits, int tile_log2);
+int launch_tile_stack(slgc_ctx *ctx, const uint8_t *d_planar, size_t plane_stride, int n_frames, size_t npix, int tile_log2, uint8_t *d_tiled);
 int launch_frame_diff_counts(slgc_ctx *ctx, const void *d_frames, int dtype, int n_frames, size_t elems, double thresh,
                              unsigned long long *d_counts);
 

@@ -62,6 +62,9 @@ SIGNATURES = {
     "slgc_compute_fetch": (_i, [_vp, _vp, _vp]),
     "slgc_to_gray": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slgc_to_gray_dev": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "slgc_tiled_stack_bytes": (_i, [_i, _sz, _i, C.POINTER(_sz)]),
+    "slgc_tile_stack_dev": (_i, [_vp, _vp, _sz, _i, _sz, _i, _vp]),
+    "slgc_to_gray_tiled_dev": (_i, [_vp, _vp, _i, _sz, _i, _i, _vp]),
     "slgc_frame_diff_counts": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
     "slgc_frame_diff_counts_dev": (_i, [_vp, _vp, _i, _i, _sz, _d, _vp]),
     "slgc_knn_mean_distance": (_i, [_vp, _vp, _i64, _i, _vp]),
@@ -566,6 +569,20 @@ class Context:
         out = _out((n, H, W), np.uint8)
         self._ck(lib().slgc_to_gray(self._h, _ptr(im), n, H, W, int(coeff_bits), _ptr(out)))
         return out
+
+    # ---- tile-interleaved stack layout (device-resident scans; include/slgc.h)
+    @staticmethod
+    def tiled_stack_bytes(N: int, npix: int, tile_log2: int) -> int:
+        n = _sz()
+        if lib().slgc_tiled_stack_bytes(int(N), int(npix), int(tile_log2), C.byref(n)):
+            raise ValueError("tile_log2 must be 8..24")
+        return int(n.value)
+
+    def tile_stack_dev(self, d_planar: int, plane_stride: int, N: int, npix: int, tile_log2: int, d_tiled: int):
+        self._ck(lib().slgc_tile_stack_dev(self._h, d_planar, int(plane_stride), int(N), int(npix), int(tile_log2), d_tiled))
+
+    def to_gray_tiled_dev(self, d_bgr: int, n_frames: int, npix: int, tile_log2: int, d_tiled: int, coeff_bits: int = 15):
+        self._ck(lib().slgc_to_gray_tiled_dev(self._h, d_bgr, int(n_frames), int(npix), int(coeff_bits), int(tile_log2), d_tiled))
 
     def frame_diff_counts(self, frames, thresh):
         fr = np.asarray(frames)

@@ -158,8 +158,9 @@ def main():
         args.extras = "none"
     args.pmc_live, args.pmc_note, args.cpu_baseline_result, args.pre_gpu_seconds = None, "not requested", None, {}
     single = world == 1 and args.gpus == 1 and not args.force_sharded
-    # Before this process touches the GPU: the counter children (GPU, one after the other, in a thread) and the CPU baseline (host cores, here)
-    # side by side -- neither is inside any timed region, and the two do not share a resource.
+    # Before this process touches the GPU: the counter children (GPU, one after the other), THEN the CPU baseline (host cores) -- neither is inside
+    # any timed region.  One after the other: each counter child is a Python process + the profiler + synthetic data generation on host cores,
+    # and the C-oracle thread sweep of the CPU baseline uses every core -- side by side (round 5) they biased the CPU figures low.
     pmc_thread = None
     if args.pmc != "off" and single and (args.pmc == "on" or args.extras != "none"):
         import threading
@@ -177,6 +178,8 @@ def main():
 
         pmc_thread = threading.Thread(target=counters, daemon=True)
         pmc_thread.start()
+        pmc_thread.join()
+        pmc_thread = None
     if single and args.extras != "none" and not args.no_cpu_baseline and os.environ.get("SLGC_BENCH_PMC_CHILD") != "1":
         from benchlib.cpu import cpu_baseline
         t0 = time.perf_counter()

@@ -31,18 +31,15 @@ def cpu_baseline(level="full"):
     """the reference-cost CPU path on BASELINE configs[0] (1280x720 camera, 1280x800 projector, 42 frames): get_codes with the
     reference's cost shape (fancy-index copies, np.repeat, ten np.where scatters), the per-pixel Python loops of src/3-capture_decode.py:99-100
     and triangulate.py:52-64, then the NumPy law of sines -- one thread, like the reference.
-    level "lite" (the default run): a bounded sample -- the first 360 rows of configs[0] (half of the image; every step of the port costs per
-    pixel), the C oracle on a 1024x512 crop, threads swept over {8, 32, all}.  level "full": configs[0] AND configs[1] at full size, the C oracle
-    on 2048x1024, the whole thread sweep."""
+    level "lite" (the default run): configs[0] at FULL size (1280x720x42: 5-10 s of one core), the C oracle on a 1024x512 crop, threads swept
+    over {8, 32, all}.  level "full": configs[0] AND configs[1] at full size, the C oracle on 2048x1024, the whole thread sweep."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c as oc
     import oracle_np as onp
     lite = level != "full"
     with_c2 = not lite
     cw, ch, pw, ph, n = WORKLOADS["c1_1280x720x42"]
-    if lite:
-        ch = 360
-    dt, t_codes, t_pix, npts = _port_scan(onp, "c1_1280x720x42", rows=ch if lite else None)
+    dt, t_codes, t_pix, npts = _port_scan(onp, "c1_1280x720x42")
     mpix = cw * ch / 1e6
     c2 = None
     if with_c2:
@@ -70,7 +67,7 @@ def cpu_baseline(level="full"):
             dt_mt, used = d, nthr
     oc.set_threads(1)
     mpix2 = c_w * c_h / 1e6
-    size = f"first {ch} rows of configs[0] ({cw}x{ch}x{n})" if lite else f"configs[0] full size ({cw}x{ch}x{n})"
+    size = f"configs[0] full size ({cw}x{ch}x{n})"
     out = {"value": round(mpix / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port", "level": level,
            "sample": f"{size}, decode+triangulate, {dt:.1f} s, {npts} points; NumPy/Python port, reference's cost shape, 1 thread",
            "sample_detail": f"BASELINE configs[0]: {cw}x{ch} camera rows, {pw}x{ph} projector, {n} frames, synthetic scene, decode + "
@@ -78,6 +75,11 @@ def cpu_baseline(level="full"):
                             "NumPy/Python port with the reference's cost shape (oracle/oracle_np.py *_loops), 1 thread like the reference",
            "reference_measured": {"value": 0.046, "unit": "Mpixels/s", "note": "the reference itself, end to end at 1920x1080x44 in the "
                                   "survey container (BASELINE.md section 2); it cannot travel to the GPU box"},
+           # measured in the build container (8 vCPU Xeon 2.1 GHz), reference imported from /root/reference, same stacks, results identical:
+           # 1280x720x42 reference 0.071 / port 0.089 Mpixels/s; 1920x1080x44 reference 0.068 / port 0.083; get_codes alone, alternated in
+           # one process: 3.6-4.3 s for both at 1920x1080 (notes/r06.md)
+           "why_port_differs": "same cost shape as the reference: build container, same stack, reference 0.068-0.071 vs port 0.083-0.089 Mpix/s "
+                               "(get_codes equal when alternated); the rest over the survey's 0.046 is this host's faster core and the survey's cold first calls",
            "c_oracle_value": round(mpix2 / dt_c, 3), "c_oracle_note": f"plain-C scalar oracle (oracle/slgc_oracle.c), 1 thread, {c_w}x{c_h}x44 crop of the headline scene",
            "c_oracle_all_cores_value": round(mpix2 / dt_mt, 3), "c_oracle_all_cores": used, "host_cores_visible": cores,
            "c_oracle_threads_sweep_mpix_s": sweep,
