@@ -654,8 +654,8 @@ __global__ void __launch_bounds__(BLOCK, (PX == 4 && (ABL == 0 || (ABL == 3 && N
             uint32_t s_vn = 3u * ps, s_vi = (uint32_t)(3 + 2 * L) * ps;
 #pragma unroll 2
             for (int t = 0; t < L; ++t) {
-                const Frame<NW, NT> hn = load_frame<NW, NT>(rs, off, s_hn), hi = load_frame<NW, NT>(rs, off, s_hi);
-                const Frame<NW, NT> vn = load_frame<NW, NT>(rs, off, s_vn), vi = load_frame<NW, NT>(rs, off, s_vi);
+                const Frame<NW, NT> hn = load_frame<NW, NT>(rs, voff, s_hn), hi = load_frame<NW, NT>(rs, voff, s_hi);
+                const Frame<NW, NT> vn = load_frame<NW, NT>(rs, voff, s_vn), vi = load_frame<NW, NT>(rs, voff, s_vi);
                 s_hn -= 2 * ps; s_hi -= 2 * ps; s_vn += 2 * ps; s_vi += 2 * ps;
                 step(hn, hi, vn, vi, (uint32_t)t);
             }

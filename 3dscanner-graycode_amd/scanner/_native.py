@@ -570,7 +570,7 @@ class Context:
         self._ck(lib().slgc_to_gray(self._h, _ptr(im), n, H, W, int(coeff_bits), _ptr(out)))
         return out
 
-    # ---- tile-interleaved stack layout (device-resident scans; include/slgc.h)
+    # ---- tile-interleaved stack layout (device-resident scans; an A/B kept reproducible, not a product layout: include/slgc_bench.h)
     @staticmethod
     def tiled_stack_bytes(N: int, npix: int, tile_log2: int) -> int:
         n = _sz()

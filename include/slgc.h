@@ -65,13 +65,12 @@ int slgc_create(int device, slgc_ctx **out);
 int slgc_destroy(slgc_ctx *ctx);
 const char *slgc_last_error(slgc_ctx *ctx);
 int slgc_synchronize(slgc_ctx *ctx);
-/* Settings of a context by name.  Four of them belong to the product: "image_rows" H > 0 = this context scans row bands of an image of H
+/* Settings of a context by name.  Three of them belong to the product: "image_rows" H > 0 = this context scans row bands of an image of H
  * rows (the multi-GPU plan sets it): the camera ray-table choice is then taken for the WHOLE image, so a pixel's XYZ is bit-identical whether
  * one GPU scans the image or N GPUs scan its bands (0, the default: the band is the image); "wire" 1 = slgc_scan_sharded_dev exchanges the
  * maps in the 3-byte wire format / 0 = int16 (default); "cam_nodes" 1 (default) = above 12 MB of per-pixel camera rays (1920x1080 and up) the
  * scan kernels interpolate the rays from an every-4th-column table (rays within 2 float32 ulp, XYZ inside the 1e-4 tolerance, maps
- * untouched) / 0 = always the per-pixel table: the one setting that changes result bits; "stack_tile_log2" k = the _dev scan entry points read
- * tile-interleaved stacks (see "tile-interleaved stack layout" below; 0 = planar, default).  Everything else slgc_tune accepts is an A/B
+ * untouched) / 0 = always the per-pixel table: the one setting that changes result bits.  Everything else slgc_tune accepts is an A/B
  * timing knob documented in slgc_bench.h.  Unknown names: SLGC_EINVAL. */
 int slgc_tune(slgc_ctx *ctx, const char *name, int value);
 /* How the last host-buffer decode call on this context took its stack in: 0 = uint8 as given; 1 = float64 whose samples were all
@@ -195,23 +194,6 @@ int slgc_knn_mean_distance(slgc_ctx *ctx, const float *pts, int64_t M, int k, do
  * work enqueued on the context's stream before it (the search grid is sized from statistics of the cloud); on return the last kernel is
  * enqueued, not finished (slgc_synchronize / slgc_d2h). */
 int slgc_knn_mean_distance_dev(slgc_ctx *ctx, const float *d_pts, int64_t M, int k, double *d_mean);
-
-/* ------------------------------------------------------------------ tile-interleaved stack layout (device-resident scans only)
- * SURVEY.md D5 leaves the device layout of the frame stack to the build; the host API keeps the reference's [N][H][W] (src/3-capture_decode.py:68-70).
- * Beside the planar stack the _dev scan entry points (slgc_decode_dev, slgc_scan_dev, slgc_scan_batch_dev, slgc_cloud_dev / slgc_cloud32_dev) read a
- * TILE-INTERLEAVED one: [tile][N][2^k bytes] -- pixel p of frame f at ((p >> k) * N + f) << k | (p & (2^k - 1)), a tile's N plane pieces
- * contiguous (k = 12: 44 x 4 KB = 176 KB per tile) instead of N streams a whole image apart.  Same kernels, same results bit for bit; the
- * decode kernel at 4096x3000x44 runs ~4-6 % faster on it (profiles/r06_stream_rates.txt, r06_tiled_layout.txt), smaller images gain nothing.
- * Select it per context with slgc_tune(ctx, "stack_tile_log2", k) (k = 8..24; 0 = planar, the default) and pass plane_stride = 2^k and
- * d_stack = the band's first tile to those entry points (run_stride / scan_stride = bytes between whole tiled stacks); bands must hold a
- * multiple of 4 pixels, start on a tile, and stay under 4 GB.  Host-buffer entry points and the BGR entry points are not affected (their
- * stacks are planar).  A stack gets into the layout at no extra pass from the camera's BGR frames (slgc_to_gray_tiled_dev: the ingest rewrites
- * every byte anyway) or from a planar grey stack (slgc_tile_stack_dev: one copy pass). */
-int slgc_tiled_stack_bytes(int N, size_t npix, int tile_log2, size_t *bytes);   /* ceil(npix / 2^k) * N * 2^k: allocate this much */
-int slgc_tile_stack_dev(slgc_ctx *ctx, const uint8_t *d_planar, size_t plane_stride, int N, size_t npix, int tile_log2, uint8_t *d_tiled);
-/* slgc_to_gray_dev (cv2.cvtColor BGR2GRAY, decode_codes.py:70-87 / src/3-capture_decode.py:66) writing the tile-interleaved stack:
- * d_bgr = n_frames frames of npix pixels, 3 bytes each, back to back. */
-int slgc_to_gray_tiled_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_frames, size_t npix, int coeff_bits, int tile_log2, uint8_t *d_tiled);
 
 /* ------------------------------------------------------------------ whole pipeline, one upload */
 

@@ -13,6 +13,23 @@
 extern "C" {
 #endif
 
+/* ------------------------------------------------------------------ tile-interleaved stack layout: the layout question, kept reproducible
+ * SURVEY.md D5 leaves the device layout of the frame stack to the build; the product reads the reference's planar [N][H][W]
+ * (src/3-capture_decode.py:68-70).  Round 6 asked whether N plane streams a whole image apart cost the decode kernel its last 8-10 %.  Movement-only
+ * kernels (tools/ubench/stream_rates.hip rows D / Dc / Dt / Dtk) move the same bytes 2-6 % faster from a TILE-INTERLEAVED stack
+ * [tile][N][2^k bytes] -- pixel p of frame f at ((p >> k) * N + f) << k | (p & (2^k - 1)) -- at 4096x3000 and no faster at 1920x1080; the REAL
+ * kernels, which can read that layout through the exports below, do not (tools/time_tiled.py, profiles/r06_tiled_layout.txt: decode and fused
+ * scan within +-1 % of planar at k = 10..16, results bit-identical).  So planar stays the product's layout and this stays an A/B:
+ * slgc_tune(ctx, "stack_tile_log2", k) (k = 8..24; 0 = planar, default) makes slgc_decode_dev, slgc_scan_dev, slgc_scan_batch_dev and
+ * slgc_cloud_dev / slgc_cloud32_dev of that context read tile-interleaved stacks: pass plane_stride = 2^k and d_stack = the band's first tile
+ * (run_stride / scan_stride = bytes between whole tiled stacks); bands hold a multiple of 4 pixels, start on a tile, stay under 4 GB.  Host-buffer
+ * and BGR entry points are unaffected (their stacks are planar).  A stack gets into the layout from BGR frames at no extra pass
+ * (slgc_to_gray_tiled_dev: cv2.cvtColor BGR2GRAY as slgc_to_gray_dev, d_bgr = n_frames frames of npix pixels back to back) or from a planar
+ * grey stack with one copy pass (slgc_tile_stack_dev). */
+int slgc_tiled_stack_bytes(int N, size_t npix, int tile_log2, size_t *bytes);   /* ceil(npix / 2^k) * N * 2^k: allocate this much */
+int slgc_tile_stack_dev(slgc_ctx *ctx, const uint8_t *d_planar, size_t plane_stride, int N, size_t npix, int tile_log2, uint8_t *d_tiled);
+int slgc_to_gray_tiled_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_frames, size_t npix, int coeff_bits, int tile_log2, uint8_t *d_tiled);
+
 /* ------------------------------------------------------------------ A/B knobs */
 /* slgc_tune (declared in slgc.h) -- the knobs for same-process A/B timing; no setting but the last one named here changes any result.  "fuse_tail" 1 = wave-local LDS exchange in the fused
  * scan kernel's tail (default) / 0 = workgroup-wide; "proj_tile" 1 = 16x8-pixel projector-table tiles (default) / 0 = 8x8;

@@ -26,6 +26,17 @@ def pytest_collection_modifyitems(config, items):
         items[:] = [it for it in items if not it.get_closest_marker("rccl_one_gpu")] + late
 
 
+# Cases that repeat a covered path at another rank count / frame count / scene: part of the suite (`SLGC_GPU_EXTENDED=1 pytest -m gpu`,
+# tools/jobs/gpu_extended.sh runs them every round) but not of the default `pytest -m gpu`, which has to fit the driver's 20-minute step with
+# every BASELINE configuration exercised (round 5's suite took 587 s there, 166 native processes).
+extended = pytest.mark.skipif(os.environ.get("SLGC_GPU_EXTENDED") != "1", reason="extended GPU case (SLGC_GPU_EXTENDED=1)")
+
+
+def ext(*values, **kw):
+    """pytest.param(...) that only runs with SLGC_GPU_EXTENDED=1"""
+    return pytest.param(*values, marks=extended, **kw)
+
+
 RCCL_STALLS = []          # (test id, attempt, where the evidence was written): filled by tests/test_gpu_rccl_multi.py, reported below
 
 

@@ -12,7 +12,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT, has_gpu
+from conftest import ROOT, ext, extended, has_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,8 @@ def test_single_rank_rccl_through_bench_self_verifies():
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
-@pytest.mark.parametrize("extra", [["--exchange", "maps"], ["--exchange", "maps", "--wire", "hv24"], ["--exchange", "xyz"]], ids=["maps-int16", "maps-hv24", "xyz"])
+@pytest.mark.parametrize("extra", [ext(["--exchange", "maps"], id="maps-int16"), pytest.param(["--exchange", "maps", "--wire", "hv24"], id="maps-hv24"),
+                                   pytest.param(["--exchange", "xyz"], id="xyz")])
 def test_single_rank_rccl_full_size_self_verifies(extra):
     """BASELINE.json configs[3]'s image (4096x3000x44) through every RCCL call of the sharded path at nranks = 1: in-place ncclAllGather on the
     communication stream, event slots, pipelined submit/flush -- and the run's own check against a single-GPU fused scan, bit for bit."""
@@ -154,6 +155,7 @@ def _skip_if_transport_unavailable(r, j):
         pytest.skip(f"RCCL could not form a communicator over the loopback socket transport on this box: {err[:300]}")
 
 
+EXTENDED_CASES = {1, 5, 6, 8}                                              # indices into CASES that only run with SLGC_GPU_EXTENDED=1 (same paths at other rank counts)
 CASES = [
     (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "int16"]),       # even bands: in-place ncclAllGather, both maps in one group
     (2, "t_512x1024x44", ["--exchange", "maps", "--wire", "hv24"]),        # packed 3 B/pixel wire, unpacked inside the triangulation kernel
@@ -173,7 +175,8 @@ CASES = [
 
 @pytest.mark.rccl_one_gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
-@pytest.mark.parametrize("nranks,workload,extra", CASES, ids=[f"{n}x-{w.split('_')[1]}-{'-'.join(e).replace('--', '')}" for n, w, e in CASES])
+@pytest.mark.parametrize("nranks,workload,extra", [pytest.param(n, w, e, id=f"{n}x-{w.split('_')[1]}-{'-'.join(e).replace('--', '')}",
+                                                                marks=[extended] if i in EXTENDED_CASES else []) for i, (n, w, e) in enumerate(CASES)])
 def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
     r, j = run_bench("--gpus", str(nranks), "--steps", "9", "--warmup", "2", "--no-extras", "--scene", "s-scene", "--workload", workload, *extra,
                      timeout=75, ranks_as_hosts=True, attempts=2, tag=f"{nranks}x-{workload}-{'-'.join(extra).replace('--', '')}")      # a healthy run takes 3-10 s
@@ -188,9 +191,10 @@ def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
 
 @pytest.mark.rccl_one_gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
-@pytest.mark.parametrize("nranks,extra", [(2, ["--exchange", "maps"]), (8, ["--exchange", "maps"]), (7, ["--exchange", "xyz"]),
-                                          (8, ["--exchange", "maps", "--exchange-impl", "direct"]), (7, ["--exchange", "xyz", "--exchange-impl", "direct"])],
-                         ids=["2-maps", "8-maps", "7-xyz-ragged", "8-maps-direct", "7-xyz-ragged-direct"])
+@pytest.mark.parametrize("nranks,extra", [ext(2, ["--exchange", "maps"], id="2-maps"), pytest.param(8, ["--exchange", "maps"], id="8-maps"),
+                                          ext(7, ["--exchange", "xyz"], id="7-xyz-ragged"),
+                                          ext(8, ["--exchange", "maps", "--exchange-impl", "direct"], id="8-maps-direct"),      # (16 processes polling on one GPU: 55 s)
+                                          pytest.param(7, ["--exchange", "xyz", "--exchange-impl", "direct"], id="7-xyz-ragged-direct")])
 def test_rccl_configs3_full_size_on_one_gpu_over_loopback(nranks, extra):
     """BASELINE.json configs[3] -- 4096x3000x44 row-sharded over 2 / 8 / (ragged) 7 ranks -- through the real RCCL exchange (loopback socket
     transport, all ranks on the one GPU), pipelined, self-verified bit for bit on every rank."""

@@ -13,7 +13,7 @@ import uuid
 import numpy as np
 import pytest
 
-from conftest import PKG, ROOT, has_gpu
+from conftest import PKG, ROOT, ext, has_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 
@@ -124,7 +124,7 @@ def _worker(rank, world, key, H, q):
         q.put((rank, "fail", traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (4, 3)])
+@pytest.mark.parametrize("world,H", [ext(2, 48), (3, 50), (4, 3)])
 def test_collectives_and_one_call_sharded_scan_with_real_rccl_ranks(world, H):
     """(4, 3): more ranks than rows -> a rank with an empty band takes part in every collective."""
     for attempt in range(3):                      # several RCCL ranks on ONE GPU occasionally stop making progress (tests/test_gpu_rccl_multi.py:

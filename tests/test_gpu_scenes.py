@@ -14,7 +14,7 @@ import pytest
 import bench
 import oracle_c as oc
 import oracle_np as onp
-from conftest import has_gpu
+from conftest import ext, has_gpu
 from test_gpu_fullsize import compare_scan
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
@@ -82,8 +82,13 @@ def test_covering_rig_generator_equals_numpy_twin(ctx, scene):
 # N = 46 (L = 11 code bits) is the only frame count the reference's own generator emits for the projectors of BASELINE.json
 # (generate_codes.py:22-25,53: 4 * ceil(log2(max(w, h))) + 2): codes reach 2047, so the projector clamp of triangulate.py:60-61 fires on every
 # pixel decoded right of / below the projector's edge, and the 46-frame kernels are separate compiled specialisations.
-@pytest.mark.parametrize("workload", ["c3_4096x3000x44", "c2_1920x1080x44", "c1_1280x720x42", "c3_4096x3000x46", "c2_1920x1080x46"])
-@pytest.mark.parametrize("scene", ["physical", "noisy-physical", "s-uniform", "s-scene"])
+SCENE_CASES = [(w, s) for w in ("c3_4096x3000x44", "c2_1920x1080x44", "c1_1280x720x42") for s in ("physical", "noisy-physical", "s-uniform", "s-scene")] + \
+              [("c3_4096x3000x46", "s-scene"), ("c2_1920x1080x46", "physical")] + \
+              [ext(w, s) for w in ("c3_4096x3000x46", "c2_1920x1080x46") for s in ("physical", "noisy-physical", "s-uniform", "s-scene")
+               if (w, s) not in (("c3_4096x3000x46", "s-scene"), ("c2_1920x1080x46", "physical"))]
+
+
+@pytest.mark.parametrize("workload,scene", SCENE_CASES)
 def test_bench_scene_every_pixel(ctx, workload, scene):
     from scanner import _native
     W, H, pw, ph, N = bench.WORKLOADS[workload]

@@ -27,7 +27,7 @@ import uuid
 import numpy as np
 import pytest
 
-from conftest import PKG, ROOT, has_gpu
+from conftest import PKG, ROOT, ext, has_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")]
 XYZ_RTOL = 1e-4           # BASELINE.json north_star: XYZ within 1e-4 relative
@@ -304,8 +304,8 @@ def _run_ranks(target, world, nbytes, args, timeout=900):
         board.close()
 
 
-@pytest.mark.parametrize("mode", ["sync", "deferred", "thread"])
-@pytest.mark.parametrize("world,H", [(2, 48), (3, 50), (4, 3)])
+@pytest.mark.parametrize("world,H,mode", [(2, 48, "sync"), (3, 50, "deferred"), (4, 3, "thread"), (3, 50, "thread"),      # every mode, every layout (even / ragged / empty bands)
+                                          ext(2, 48, "deferred"), ext(2, 48, "thread"), ext(3, 50, "sync"), ext(4, 3, "sync"), ext(4, 3, "deferred")])
 def test_sharded_scanner_ranks_share_one_gpu(world, H, mode):
     """(4, 3): more ranks than rows -> one rank owns an empty band."""
     W, N = 128, 26
@@ -429,7 +429,7 @@ def full_size_reference(tmp_path_factory):
     os.rmdir(ref_dir)
 
 
-@pytest.mark.parametrize("world,mode", [(2, "thread"), (8, "deferred"), (7, "deferred")])
+@pytest.mark.parametrize("world,mode", [(2, "thread"), (8, "deferred"), ext(7, "deferred")])
 def test_configs3_full_size_every_pixel(full_size_reference, world, mode):
     """BASELINE.json configs[3]: 4096x3000x44 row-sharded over `world` ranks (7: ragged bands, 428 / 429 rows), maps (int16 and 3-byte
     wire), xyz and records strategies, one scan and three pipelined scans each, every pixel of what every rank ends up holding."""

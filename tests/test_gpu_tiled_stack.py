@@ -1,4 +1,4 @@
-"""The tile-interleaved stack layout ([tile][N][2^k], slgc_tune "stack_tile_log2"; include/slgc.h) against the planar stack the reference's
+"""The tile-interleaved stack layout ([tile][N][2^k], slgc_tune "stack_tile_log2"; include/slgc_bench.h: an A/B of the layout question, not a product layout) against the planar stack the reference's
 [N][H][W] maps onto (src/3-capture_decode.py:68-70): the same kernels must give the same bits -- maps from the decode kernel, maps + XYZ from the
 fused and the two-kernel scan -- at BASELINE configs[1] / [2], on ragged sizes, with two runs, for several tile sizes; the two ways into the
 layout (slgc_tile_stack_dev, slgc_to_gray_tiled_dev) agree byte for byte; host-buffer entry points are unaffected by the setting."""
@@ -14,11 +14,10 @@ if conftest.has_gpu():
     from scanner import _native
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def ctx():
     c = _native.Context(0)
     yield c
-    c.tune("stack_tile_log2", 0)
     c.close()
 
 
