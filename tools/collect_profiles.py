@@ -109,7 +109,7 @@ for sub, name in (("kt_next", "kernel_stats_next_rows"), ("kt_lists", "kernel_st
         print("no", sub)
 for f, name in (("next_rows.log", "next_rows.txt"), ("lists_plain.log", "list_stage.txt"), ("host_api.log", "host_api.txt"), ("dropin.log", "dropin.txt"), ("write_patterns.txt", "write_patterns.txt"),
                 ("cloud.log", "reference_product.txt"), ("pmc_lists/summary.txt", "pmc_list_stage.txt"), ("stream_rates.txt", "stream_rates.txt"),
-                ("ingest.log", "ingest.txt"), ("batch_rounds.log", "batch_rounds.txt"), ("ab_guard.log", "guard_forms.txt")):
+                ("ingest.log", "ingest.txt"), ("batch_rounds.log", "batch_rounds.txt"), ("ab_guard.log", "guard_forms.txt"), ("tiled_layout.log", "tiled_layout.txt")):
     if os.path.exists(os.path.join(src, f)):
         keep = [ln for ln in open(os.path.join(src, f), errors="replace") if not re.match(r"^(RCCL|HIP|ROCm|Hostname|Librccl|[WEI]\d{8}) ", ln)]
         open(os.path.join(dst, f"{tag}_{name}"), "w").writelines(keep)

@@ -40,6 +40,7 @@ bash tools/jobs/pmc_lists.sh "$out/pmc_lists" > "$out/pmc_lists.log" 2>&1
 for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_cloud.py --workload $w 2>/dev/null | grep "per scan"; done > "$out/cloud.log"
 for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do python3 tools/time_ingest.py --workload $w 2>/dev/null | grep "scan from BGR"; done > "$out/ingest.log"
 python3 tools/time_batch_rounds.py 2>/dev/null | grep "batch of" > "$out/batch_rounds.log"
+for w in c3_4096x3000x44 c2_1920x1080x44; do python3 tools/time_tiled.py --workload $w --k 10 12 13 2>/dev/null; done > "$out/tiled_layout.log"     # the layout question (round 6): planar vs tile-interleaved stacks on the real kernels
 for w in c3_4096x3000x44 c2_1920x1080x44 c1_1280x720x42; do for sc in physical s-scene s-uniform noisy-physical; do
   python3 tools/ab_fused.py --knobs "guard_list=0,1" --workload $w --scene $sc --rounds 4 --iters 30 2>/dev/null | grep -E "scene=|guard_list="; done; done > "$out/ab_guard.log"
 python3 tools/time_host_api.py 2>/dev/null | grep Mpix > "$out/host_api.log"
