@@ -117,6 +117,7 @@ def test_single_rank_rccl_through_bench_self_verifies():
     for extra in (["--exchange", "maps"], ["--exchange", "xyz"], ["--exchange", "maps", "--wire", "hv24"]):
         r, j = run_bench("--force-sharded", "--steps", "12", "--warmup", "2", "--no-extras", "--workload", "t_516x1031x44", *extra)
         assert r.returncode == 0 and j["verify"]["ok"], (extra, r.stderr[-2000:])
+        assert j["sharded"]["rccl_nranks"] == 1 == j["sharded"]["distinct_devices"] and j["sharded"]["rccl_nranks_source"] == "ncclCommCount", j["sharded"]
 
 
 @pytest.mark.skipif(not has_gpu(), reason="needs a HIP device")
@@ -183,6 +184,11 @@ def test_rccl_several_ranks_on_one_gpu_over_loopback(nranks, workload, extra):
     _skip_if_transport_unavailable(r, j)
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     assert j["n_gpus"] == nranks and j["sharded"]["rccl_nranks"] == nranks and j["valid_pixels_per_scan"] > 1000
+    # RCCL's own account of the job: the rank count is ncclCommCount's, every rank's GPU is named -- here all the same one (test mode)
+    sh = j["sharded"]
+    assert sh["rccl_nranks_source"] == "ncclCommCount" and sh["rccl_info_error"] is None and sh["rccl_rank"] == 0
+    assert len(sh["rank_devices"]) == nranks and len(set(sh["rank_devices"])) == 1 == sh["distinct_devices"] and sh["ranks_share_gpus_test_mode"] is True
+    assert ":" in sh["rank_devices"][0]
     if "records" not in extra:
         v = j["verify"]
         assert v["ok"] and v["ranks_hold_identical_results"] and v["maps_equal_single_gpu_scan"] and v["xyz_sample_equal_single_gpu_scan"], v
@@ -204,6 +210,7 @@ def test_rccl_configs3_full_size_on_one_gpu_over_loopback(nranks, extra):
     assert r.returncode == 0 and j is not None and j.get("value"), (r.stdout[-1500:], r.stderr[-3000:])
     v = j["verify"]
     assert j["sharded"]["rccl_nranks"] == nranks and "configs[3]" in j["config"]["workload"]
+    assert j["sharded"]["distinct_devices"] == 1 and len(j["sharded"]["rank_devices"]) == nranks
     assert v["ok"] and v["ranks_hold_identical_results"] and v["maps_equal_single_gpu_scan"] and v["xyz_sample_equal_single_gpu_scan"] and v["valid_pixels"] > 1_000_000, v
 
 

@@ -24,19 +24,25 @@ def sharded_report(ctx, scanner, args, G, rank, stacks, plane, N, rows, cam_w, c
             ctx.synchronize()
             t_compute = time.perf_counter() - t0
         t_compute = ctx.comm_allreduce_max(t_compute)
-    # RCCL's own account of the job (not WORLD_SIZE): ncclCommCount, and the PCI bus id of every rank's GPU gathered over the communicator
-    comm = ctx.comm_info()
-    devices, distinct = ctx.comm_rank_devices()
+    # RCCL's own account of the job (not WORLD_SIZE): ncclCommCount, and the PCI bus id of every rank's GPU gathered over the communicator.  A
+    # library that cannot answer (an RCCL without ncclCommCount, a failing hipDeviceGetPCIBusId) costs these keys, not the line.
     test_mode = os.environ.get("SLGC_RANKS_AS_HOSTS") == "1"      # several ranks share the one GPU of a test box on purpose
-    if comm["nranks"] != G:
+    comm, devices, distinct, info_error = {"nranks": None, "rank": None}, None, None, None
+    try:
+        comm = ctx.comm_info()
+        devices, distinct = ctx.comm_rank_devices()
+    except Exception as e:  # noqa: BLE001
+        info_error = f"{type(e).__name__}: {e}"[:200]
+    if comm["nranks"] is not None and comm["nranks"] != G:
         raise RuntimeError(f"RCCL reports {comm['nranks']} ranks, the launcher promised {G}")
-    if distinct != comm["nranks"] and not test_mode:
+    if distinct is not None and distinct != comm["nranks"] and not test_mode:
         raise RuntimeError(f"{comm['nranks']} RCCL ranks sit on {distinct} distinct GPUs ({devices}): one rank per GPU is the plan "
                            "(SLGC_RANKS_AS_HOSTS=1 is the one-GPU test mode)")
     px = cam_w * cam_h
     per_px = {"maps": 3 if scanner.wire == "hv24" else 4, "xyz": 16, "records": 16}[args.exchange]
-    info = {"rccl_nranks": comm["nranks"], "rccl_rank": comm["rank"], "rank_devices": devices, "distinct_devices": distinct,
-            "ranks_share_gpus_test_mode": bool(test_mode and distinct != comm["nranks"]), "exchange": args.exchange, "exchange_impl": args.exchange_impl, "wire": scanner.wire if args.exchange == "maps" else None,
+    info = {"rccl_nranks": comm["nranks"] if comm["nranks"] is not None else G, "rccl_nranks_source": "ncclCommCount" if comm["nranks"] is not None else "WORLD_SIZE (unverified)",
+            "rccl_rank": comm["rank"], "rank_devices": devices, "distinct_devices": distinct, "rccl_info_error": info_error,
+            "ranks_share_gpus_test_mode": bool(test_mode and distinct is not None and distinct != comm["nranks"]), "exchange": args.exchange, "exchange_impl": args.exchange_impl, "wire": scanner.wire if args.exchange == "maps" else None,
             "overlap": not args.no_overlap and args.exchange != "records",
             "exchange_bytes_per_rank": {"sent": int(rows * cam_w * per_px), "received": int((px - rows * cam_w) * per_px)},
             "with_exchange_value": round(px / 1e6 * args.steps / elapsed, 1), "unit": "Mpixels/s"}
