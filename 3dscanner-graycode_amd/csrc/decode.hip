@@ -270,7 +270,7 @@ struct FuseArgs {            // triangulation appended to the decode kernel (slg
 };
 
 // Issue priority of the wave among the waves of its SIMD (s_setprio takes an immediate: a wave-uniform switch selects it).  Which phase of
-// k_decode_pk goes first decides how full the memory pipeline stays (round 5, NOTES.md): a wave that still has to ask for its threshold
+// k_decode_pk goes first decides how full the memory pipeline stays (round 5, notes/r05.md): a wave that still has to ask for its threshold
 // frames goes first at every size; in launches of a single round of resident waves the tail goes last.
 __device__ __forceinline__ void set_prio(int p)
 {

@@ -174,6 +174,11 @@ def main():
             args.pmc_note = note or "collected"
             if live:
                 args.pmc_live = {f"{args.pipeline}/{args.scene}": live}
+                if args.scene != "s-scene" and args.extras != "none":      # SURVEY 8(d)'s own capture rides inside the roofline object: its traffic too
+                    live_s, _ = pmc.collect(os.path.abspath(__file__), args.workload, "s-scene", args.pipeline, grid_size=-(-(cw * ch // 4) // 128) * 128,
+                                            timeout_s=args.pmc_timeout)
+                    if live_s:
+                        args.pmc_live[f"{args.pipeline}/s-scene"] = live_s
             args.pre_gpu_seconds["counter children"] = round(time.perf_counter() - t0, 3)
 
         pmc_thread = threading.Thread(target=counters, daemon=True)

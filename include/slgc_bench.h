@@ -49,7 +49,7 @@ int slgc_to_gray_tiled_dev(slgc_ctx *ctx, const uint8_t *d_bgr, int n_frames, si
  * every value other than 0 and 2 as plain column-major (1).
  * "prio" = head * 100 + body * 10 + tail: s_setprio (0..3) of a wave of the fused scan kernel while it fetches its threshold frames and computes its thresholds /
  * walks the bit loop / runs the triangulation tail; -1 (default) = by launch shape: 210 for launches that fill more than half of the chip's 8 192 wave slots in one
- * round (1920x1080: -3.5 %), 0 otherwise (NOTES.md round 5).  The setting assumes the launch has the GPU to itself: contexts whose scans overlap on
+ * round (1920x1080: -3.5 %), 0 otherwise (notes/r05.md).  The setting assumes the launch has the GPU to itself: contexts whose scans overlap on
  * the device (several streams) should set 0 -- two streams of 1920x1080 scans lose 12 % with "tail last".
  * "guard_list" 1 (default) = the fused scan kernel compacts its flat triangles over the wave and redoes 64 of them per float64 pass / 0 = redoes them lane by
  * lane (bit-identical XYZ; scattered wrong codes make the lane-by-lane form walk the float64 path in nearly every wave).

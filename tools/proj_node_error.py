@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Would a NODE table of tan(beta / 2) (every S-th projector column, cubic through four nodes -- what the scan kernels do for the camera rays) be accurate
 enough to replace the per-projector-pixel table the fused kernel gathers from?  CPU estimate with the oracle's cv2.undistortPoints restatement, for
-bench.py's two rigs.  Answer (NOTES.md round 5): no -- the reference's own projector lens (k1 -0.28, k2 6.7, k3 -31.6) makes the 5-iteration
+bench.py's two rigs.  Answer (notes/r05.md): no -- the reference's own projector lens (k1 -0.28, k2 6.7, k3 -31.6) makes the 5-iteration
 undistortion discontinuous towards the raster's edges (3-5 % of the pixels off by more than 2.4e-7 rad even at S = 4), and on the covering rig's mild
 lens the truncated iteration is only smooth enough at S = 4 (a 2 MB table: no longer L2-resident next to the streams).   python tools/proj_node_error.py"""
 import os
