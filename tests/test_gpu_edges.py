@@ -76,7 +76,7 @@ def test_nine_runs_are_refused_everywhere(ctx):
     runs = np.stack([onp.synth_scene_int(N, H, W, seed=3)[0]] * 9)
     stack = ctx.alloc(runs.nbytes).upload(runs)
     maps, xyz = ctx.alloc(px * 4), ctx.alloc(px * 12)
-    lists = ctx.alloc_cloud_lists(px)
+    lists = ctx.alloc_cloud_lists(px, colors=False)
     with pytest.raises(ERR, match="n_runs"):
         ctx.decode_dev(stack.ptr, 9, N * px, px, N, H, W, maps.at(0), maps.at(px * 2))
     for mode in (_native.TRI_ALGEBRAIC, _native.TRI_ALGEBRAIC | _native.TRI_SPLIT, _native.TRI_EXACT):
@@ -109,7 +109,7 @@ def test_frame_counts_outside_14_to_65_are_refused_by_every_entry_point(ctx, N):
     host = np.zeros((n_alloc, H, W), np.uint8)[:max(N, 0)]
     dev = ctx.alloc(max(n_alloc, 70) * px * 3)
     maps, xyz = ctx.alloc(px * 4 + 64), ctx.alloc(px * 12 + 64)
-    lists = ctx.alloc_cloud_lists(px)
+    lists = ctx.alloc_cloud_lists(px, colors=False)
     L = _native.lib()
     z = np.zeros((H, W))
     hc = np.zeros((16, H, W), np.int8)
@@ -151,7 +151,7 @@ def test_stack_of_4gb_and_more_takes_the_wide_offset_kernel(ctx):
     maps = ctx.alloc(px * 4).zero()
     ctx.decode_dev(stack.ptr, 1, N * px, px, N, H, W, maps.at(0), maps.at(px * 2))
     ctx.synchronize()
-    assert ctx.last_scan_ragged() & 1                                  # the fallback kernel ran, not the packed one
+    assert ctx.last_scan_path()["fallback_kernels"]["decode"]              # the wide-offset (lane-mask) kernel ran, not the packed one
     total_valid = 0
     for y0, rows in ((0, 6), (3997, 7), (H - 5, 5)):
         band = np.stack([stack.download((rows, W), np.uint8, byte_offset=f * px + y0 * W) for f in range(N)])
