@@ -89,7 +89,37 @@ def decode_case(stack_u8, second_run_u8=None):
     return out
 
 
+def multirun():
+    """src/3-capture_decode.py:48 (MAX_NB_RUNS), :75-100: get_codes per run, np.max over ALL runs' codes, then the two per-pixel loops -- with 4 and
+    8 runs (the reference's script ships with 2; the merge is an N-way max).  Runs differ in noise, and every run but one has a block of
+    pixels blacked out, so that the merged maps differ from every single run's.  -> tests/golden/multirun.npz (written on its own:
+    `python tests/golden/make_golden.py multirun`)."""
+    flat = {}
+    for N, H, W, R in ((26, 20, 36, 4), (44, 16, 32, 8), (14, 9, 13, 8)):
+        runs = np.stack([onp.synth_scene(N, H, W, seed=60 + r, noise=2 + r) for r in range(R)])
+        for r in range(R):
+            if r != 1:
+                runs[r, :, :, (3 * r) % W:(3 * r) % W + 3] = 0
+        codes = [ref_dc.get_codes(run.astype(np.float64)) for run in runs]          # :75 per run
+        bh = np.max([c[0] for c in codes], axis=0)                                   # :95
+        bv = np.max([c[1] for c in codes], axis=0)                                   # :96
+        mh, mv = ref_pixels(bh, bv)                                                  # :99-100
+        single = ref_pixels(*codes[0])
+        assert not np.array_equal(single[0], mh)
+        tag = f"runs{R}_N{N}_{H}x{W}"
+        flat[f"{tag}/stacks"] = runs
+        flat[f"{tag}/merged_h_codes"] = bh
+        flat[f"{tag}/merged_v_codes"] = bv
+        flat[f"{tag}/merged_h_pixels"] = mh.astype(np.int64)
+        flat[f"{tag}/merged_v_pixels"] = mv.astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "multirun.npz"), **flat)
+    print("multi-run cases:", len(flat) // 5)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "multirun":
+        return multirun()
+    multirun()
     # ------------------------------------------------------------------ decode cases
     cases = {}
     for N in (14, 15, 17, 26, 42, 44, 46):

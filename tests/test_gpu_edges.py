@@ -69,6 +69,28 @@ def test_many_runs_are_an_n_way_max(ctx, N, W, H, n_runs):
         b.free()
 
 
+def test_many_runs_against_the_reference_generated_goldens(ctx):
+    """tests/golden/multirun.npz (the reference's own code run on 4 / 8 runs): device-resident decode, host decode and the code-plane merge."""
+    cases = conftest.load_cases("multirun.npz")
+    for name, c in cases.items():
+        runs = c["stacks"]
+        R, N, H, W = runs.shape
+        px = H * W
+        hp, vp = ctx.decode(list(runs))
+        assert np.array_equal(hp, c["merged_h_pixels"]) and np.array_equal(vp, c["merged_v_pixels"]), name
+        hp, vp = ctx.decode([r.astype(np.float64) for r in runs])
+        assert np.array_equal(hp, c["merged_h_pixels"]) and np.array_equal(vp, c["merged_v_pixels"]), name
+        codes = [ctx.codes(r) for r in runs]
+        hp, vp = ctx.codes_to_pixels(np.stack([x[0] for x in codes]), np.stack([x[1] for x in codes]))
+        assert np.array_equal(hp, c["merged_h_pixels"]) and np.array_equal(vp, c["merged_v_pixels"]), name
+        stack, maps = ctx.alloc(runs.nbytes).upload(runs), ctx.alloc(px * 4 + 64)
+        ctx.decode_dev(stack.ptr, R, N * px, px, N, H, W, maps.at(0), maps.at(px * 2))
+        ctx.synchronize()
+        assert np.array_equal(maps.download((H, W), np.int16), c["merged_h_pixels"]) and np.array_equal(maps.download((H, W), np.int16, px * 2), c["merged_v_pixels"]), name
+        stack.free()
+        maps.free()
+
+
 def test_nine_runs_are_refused_everywhere(ctx):
     N, W, H = 44, 64, 32
     px = W * H
