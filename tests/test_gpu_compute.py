@@ -88,6 +88,29 @@ def test_compute_ragged_and_empty(ctx, tri_cases, W, H):
             _same(t.compute(None, threshold=thr), t.compute_by_calls(None, threshold=thr))
 
 
+def test_compute_fuzz_vs_three_calls(ctx, tri_cases):
+    """Seeded fuzz (SLGC_FUZZ_SCALE multiplies the case count): random sizes, maps with -1 / other negatives / values past the projector and past int16,
+    random thresholds and orders -- compute() must stay bit-identical to the three-call composition."""
+    import os
+    c = next(iter(tri_cases.values()))
+    rng = np.random.default_rng(2026)
+    for k in range(60 * int(os.environ.get("SLGC_FUZZ_SCALE", "1"))):
+        W, H = int(rng.integers(1, 160)), int(rng.integers(1, 120))
+        hi = int(rng.choice([40, 1500, 33000, 70000]))
+        h = rng.integers(-3, hi, (H, W)).astype(np.int64)
+        v = rng.integers(-3, hi, (H, W)).astype(np.int64)
+        h[rng.random((H, W)) < rng.random()] = -1
+        white = rng.integers(0, 256, (H, W, 3), dtype=np.uint8) if rng.random() < 0.7 else None
+        cc = dict(c)
+        cc["cam_size"] = np.array([W, H])
+        t = _tri(cc, ctx, h, v)
+        thr = None if rng.random() < 0.3 else float(rng.choice([0.05, 0.5, 3.0, 1e6]))
+        order = "x" if rng.random() < 0.7 else "row"
+        exact = bool(rng.random() < 0.5)
+        _same(t.compute(white, threshold=thr, exact=exact, order=order), t.compute_by_calls(white, threshold=thr, exact=exact, order=order))
+        assert ctx.last_input_path() == (2 if (h.max() > 32767 or v.max() > 32767) else 1), (k, W, H, hi)
+
+
 def test_compute_needs_calibration():
     c2 = _native.Context(0)
     try:
