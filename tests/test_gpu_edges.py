@@ -185,3 +185,55 @@ def test_stack_of_4gb_and_more_takes_the_wide_offset_kernel(ctx):
     assert total_valid > 50_000
     stack.free()
     maps.free()
+
+
+@pytest.mark.parametrize("n_cam,n_proj", [(0, 0), (4, 5), (5, 8), (8, 12), (12, 4), (14, 14)])
+def test_every_distortion_vector_length_the_abi_accepts(ctx, n_cam, n_proj):
+    """slgc_set_calibration takes k1,k2,p1,p2[,k3[,k4,k5,k6[,s1..s4[,tauX,tauY]]]] like cv2.undistortPoints (the reference's files hold 5, as 5x1 and
+    1x5: triangulate.py:84-85): rational (k4..k6) and thin-prism (s1..s4) terms against both oracles' restatement, through slgc_undistort_points,
+    slgc_triangulate and the dense scan; zero tilt accepted, non-zero tilt refused."""
+    rng = np.random.default_rng(100 * n_cam + n_proj)
+    full = np.array([-0.12, 0.09, 0.002, -0.003, -0.03, 0.05, -0.04, 0.02, 0.004, -0.002, 0.003, 0.001, 0.0, 0.0])
+    cd, pd = full[:n_cam] * rng.uniform(0.5, 1.5, n_cam), full[:n_proj] * rng.uniform(0.5, 1.5, n_proj)
+    W, H, pw, ph = 320, 200, 256, 160
+    K = np.array([[300.0, 0, W / 2], [0, 300.0, H / 2], [0, 0, 1]])
+    pk = np.array([[280.0, 0, pw / 2], [0, 280.0, ph / 2], [0, 0, 1]])
+    th = np.deg2rad(-18.0)
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    T = np.array([[0.22], [0.01], [0.03]])
+    ctx.set_calibration(K, cd, pk, pd, R, T)
+    M = 5000
+    cam = np.stack([rng.integers(0, W, M), rng.integers(0, H, M)], 1).astype(np.float32)
+    proj = np.stack([rng.integers(0, pw, M), rng.integers(0, ph, M)], 1).astype(np.float32)
+    for which, pts, Kx, dx, Rx in ((False, cam, K, cd, R), (True, proj, pk, pd, None)):
+        got = ctx.undistort_points(pts, projector=which)
+        ref_np = onp.undistort_points(pts, Kx, dx, R=Rx).reshape(-1, 2)
+        ref_c = oc.undistort(pts, Kx, dx, R=Rx)
+        assert np.array_equal(ref_np, ref_c)                              # the two oracles agree bit for bit (float32 out)
+        np.testing.assert_allclose(got, ref_np, rtol=2e-6, atol=1e-7)
+    want = oc.triangulate(cam, proj, K, cd, pk, pd, R, T)
+    got = ctx.triangulate(cam, proj)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-4, atol=0)
+    # dense scan (ray tables built from the same calibration)
+    N = 26
+    st, _, _ = onp.synth_scene_int(N, H, W, seed=4)
+    rh, rv, rx = oc.scan_dense(st, (pw, ph), K, cd, pk, pd, R, T)
+    px = W * H
+    stack, maps, xyz = ctx.alloc(st.nbytes).upload(st), ctx.alloc(px * 4), ctx.alloc(px * 12)
+    ctx.scan_dev(stack.ptr, 1, st.nbytes, px, N, H, W, 0, (pw, ph), xyz.ptr, None, maps.at(0), maps.at(px * 2))
+    ctx.synchronize()
+    gx = xyz.download((H, W, 3), np.float32)
+    ok = (rh != -1) & (rv != -1) & np.isfinite(np.moveaxis(rx, 0, -1)).all(axis=2)
+    assert np.array_equal(maps.download((H, W), np.int16), rh) and ok.sum() > 1000
+    np.testing.assert_allclose(gx[ok], np.moveaxis(rx, 0, -1)[ok], rtol=1e-4, atol=0)
+    for b in (stack, maps, xyz):
+        b.free()
+    if n_cam == 14:                                                       # tilted-sensor terms are not supported: refused, not ignored
+        bad = cd.copy()
+        bad[12] = 0.01
+        with pytest.raises(ERR, match="tilt"):
+            ctx.set_calibration(K, bad, pk, pd, R, T)
+        with pytest.raises(ERR):
+            ctx.set_calibration(K, np.zeros(15), pk, pd, R, T)
