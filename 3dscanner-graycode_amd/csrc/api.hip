@@ -1147,6 +1147,12 @@ struct TileOff {           // the context's tile-interleaved setting suspended f
     ~TileOff() { c->tune_stack_tile = saved; c->stack_tile_active = 0; }
 };
 
+struct TileScope {         // what dev_geom switched on for THIS call is switched off when the call returns: no later launch can inherit a stale layout
+    slgc_ctx *c;
+    explicit TileScope(slgc_ctx *ctx) : c(ctx) {}
+    ~TileScope() { c->stack_tile_active = 0; }
+};
+
 static int dev_geom(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, size_t run_stride, size_t plane_stride, int N, int rows, int W,
                     double eps, DecodeGeom *g, RunPtrs *runs, int *e)
 {
@@ -1179,6 +1185,7 @@ extern "C" int slgc_decode_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs
     DecodeGeom g;
     RunPtrs runs{};
     int e;
+    TileScope tile_scope(ctx);
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
     ctx->last_scan_path = SLGC_PATH_NONE;          // a decode alone is not a scan; slgc_triangulate_maps_dev after it completes the two-kernel path
     ctx->last_ragged = 0;
@@ -1295,6 +1302,7 @@ extern "C" int slgc_scan_dev(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, 
     DecodeGeom g;
     RunPtrs runs{};
     int e;
+    TileScope tile_scope(ctx);
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, rows, W, eps, &g, &runs, &e))) return rc;
     if (!d_h || !d_v) d_h = d_v = nullptr;          // no map buffers: the fused kernel then stores XYZ only
     const size_t npix = (size_t)rows * W;
@@ -1422,6 +1430,7 @@ extern "C" int slgc_scan_batch_dev(slgc_ctx *ctx, const uint8_t *d_stacks, int n
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
+    TileScope tile_scope(ctx);
     if (n_scans < 0 || !d_stacks || !d_xyz) return slgc_fail(ctx, SLGC_EINVAL, "null pointer / negative count");
     if (!d_h || !d_v) d_h = d_v = nullptr;          // XYZ only
     const size_t npix = (size_t)rows * W;
@@ -1502,6 +1511,7 @@ static int cloud_dev_common(slgc_ctx *ctx, const uint8_t *d_stack, int n_runs, s
     DecodeGeom g;
     RunPtrs runs{};
     int e;
+    TileScope tile_scope(ctx);
     if ((rc = dev_geom(ctx, d_stack, n_runs, run_stride, plane_stride, N, cam_h, cam_w, eps, &g, &runs, &e))) return rc;
     if (!d_h) {
         void *maps;
