@@ -2,14 +2,14 @@
 """How many DISTINCT 128-byte lines of the projector table (4 bytes per projector pixel, row-major) the 256 pixels of one wave of the fused scan
 kernel touch, per synthetic capture -- the bound on what sorting / coalescing a wave's gathers by line could save.  CPU only:
 the oracle decodes the capture, the statistic is taken on its maps.
-  python tools/gather_lines.py [--size 1920x1080] [--proj 1920x1200] [--frames 44]"""
+  python tests/analysis/gather_lines.py [--size 1920x1080] [--proj 1920x1200] [--frames 44]"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_c as oc  # noqa: E402
 import oracle_np as onp  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """CPU only: how compressible are the decoded (h, v) maps the `maps` exchange puts on the links?  Deltas to the previous valid pixel inside 64-pixel runs,
-by synthetic capture (NOTES.md: "Not tried yet").  python tools/map_delta_stats.py"""
+by synthetic capture (NOTES.md: "Not tried yet").  python tests/analysis/map_delta_stats.py"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT,"oracle")); sys.path.insert(0, os.path.join(ROOT,"tools")); sys.path.insert(0, ROOT)
 import oracle_c as oc, oracle_np as onp
 from benchlib.common import SCENES, calibration

@@ -3,12 +3,12 @@
 enough to replace the per-projector-pixel table the fused kernel gathers from?  CPU estimate with the oracle's cv2.undistortPoints restatement, for
 bench.py's two rigs.  Answer (notes/r05.md): no -- the reference's own projector lens (k1 -0.28, k2 6.7, k3 -31.6) makes the 5-iteration
 undistortion discontinuous towards the raster's edges (3-5 % of the pixels off by more than 2.4e-7 rad even at S = 4), and on the covering rig's mild
-lens the truncated iteration is only smooth enough at S = 4 (a 2 MB table: no longer L2-resident next to the streams).   python tools/proj_node_error.py"""
+lens the truncated iteration is only smooth enough at S = 4 (a 2 MB table: no longer L2-resident next to the streams).   python tests/analysis/proj_node_error.py"""
 import os
 import sys
 
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import bench, oracle_np as onp
